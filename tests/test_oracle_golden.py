@@ -147,10 +147,11 @@ def test_anderson_and_newton_reach_the_same_fixed_point():
     p = models.ssy_params(); arr = ssy.discretize_ssy(p, shapes)
     T = lambda w: ssy.T_ssy_factorised(w, shapes, p, arr)
     J = lambda w, v: ssy.jvp_ssy(w, v, shapes, p, arr)
-    xa, na = solvers.anderson_solver(T, np.full(shapes, 800.0), tol=1e-10, verbose=False)
+    xa, na = solvers.anderson_solver(T, np.full(shapes, 800.0), tol=1e-8, verbose=False)
     xs = solvers.newton_polish(T, J, xa.copy())
     assert na < 10000
-    np.testing.assert_allclose(xa, xs, rtol=0, atol=1e-6)
+    # distance to the fixed point ~ residual / (1 - modulus), modulus ~ 0.9988
+    np.testing.assert_allclose(xa, xs, rtol=0, atol=1e-5)
     assert np.max(np.abs(T(xs) - xs)) < 1e-11
 
 
