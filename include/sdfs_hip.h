@@ -1,0 +1,160 @@
+/*
+ * sdfs_hip.h -- C ABI of libsdfs_hip.so: the MI355X (gfx950) implementation of the
+ * wealth-consumption-ratio fixed-point path of jstac/sdfs_via_autodiff.
+ *
+ * The reference has no FFI layer; its boundary for this path is two Python call
+ * shapes (paths relative to the reference repo):
+ *
+ *   operator  T(w) = T_ssy(w, shapes, params, arrays)   code/ssy/discrete/ssy_wc_ratio.py:82-151
+ *             T(w) = T_gcy(w, shapes, params, arrays)   code/gcy/discrete/gcy_wc_ratio.py:134-238
+ *   solver    solver(f, x_init, algorithm, verbose)     code/solvers.py:154-177
+ *             successive_approx / newton_solver / anderson_solver   code/solvers.py:19-124
+ *
+ * Each entry point below names the reference call it replaces.  Conventions:
+ * opaque handle; every call returns 0 on success and a negative code on error
+ * (message via sdfs_last_error); no exceptions cross the boundary; the caller
+ * owns host buffers; the library owns its device buffers and one HIP stream per
+ * handle; a handle is not thread-safe, distinct handles are independent.
+ * Grids are C-order fp64 exactly as the reference lays them out
+ * (SSY: (h_lam, h_c, h_z, z), z fastest; GCY: (z, z_pi, h_z, h_c, h_zpi, h_lam),
+ * h_lam fastest).  "_dev" variants take device pointers (hipMalloc'd or
+ * torch.Tensor.data_ptr()) and never touch host memory.
+ */
+#ifndef SDFS_HIP_H
+#define SDFS_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct sdfs_handle sdfs_handle;
+
+enum { SDFS_MODEL_SSY = 0, SDFS_MODEL_GCY = 1 };
+enum { SDFS_ALGO_SA = 0, SDFS_ALGO_NEWTON = 1, SDFS_ALGO_ANDERSON = 2 };
+
+enum {
+  SDFS_OK = 0,
+  SDFS_ERR_ARG = -1,      /* bad argument (shape, count, null pointer) */
+  SDFS_ERR_HIP = -2,      /* a HIP runtime call failed */
+  SDFS_ERR_UNSUPPORTED = -3,
+  SDFS_ERR_NUMERIC = -4   /* NaN/Inf met in the iteration */
+};
+
+/* Options of sdfs_solve*.  Defaults (sdfs_default_opts) are the reference's:
+ * code/solvers.py:16-17 (tol 1e-7, max_iter 1e6), :55 (bicgstab_atol 1e-4),
+ * jax.scipy.sparse.linalg.bicgstab default tol 1e-5, :104-114 (Anderson
+ * history 10, mixing 4, beta 8, ridge 1e-6, max_iter 1e4). */
+typedef struct sdfs_opts {
+  double tol;            /* sup-norm step tolerance (SA, Newton); l2 residual (Anderson) */
+  int64_t max_iter;
+  double inner_rtol;     /* BiCGSTAB relative tolerance on |r|_2            */
+  double inner_atol;     /* BiCGSTAB absolute tolerance on |r|_2            */
+  int64_t inner_max_iter;/* 0 -> 10 * N (JAX default)                       */
+  int32_t history;       /* Anderson history size m                         */
+  int32_t mixing_freq;   /* Anderson mixing frequency                       */
+  double beta;           /* Anderson damping                                */
+  double ridge;          /* Anderson ridge                                  */
+  int32_t check_every;   /* host polls the device residual every k iterations (>=1) */
+  int32_t use_graph;     /* 1: replay the iteration chunk from a hipGraph   */
+  int32_t record_errors; /* 1: keep the per-iteration error trace (sdfs_error_trace) */
+  int32_t reserved;
+} sdfs_opts;
+
+/* Per-kernel counters for the roofline line of bench.py. */
+#define SDFS_MAX_KERNELS 16
+typedef struct sdfs_kernel_counter {
+  char name[48];
+  int64_t launches;       /* launches bracketed by HIP events               */
+  double total_ms;        /* sum of their durations (hipEventElapsedTime)   */
+  double alg_bytes;       /* algorithmic bytes of ONE launch    */
+  double alg_flops;       /* algorithmic flops of ONE launch                */
+} sdfs_kernel_counter;
+
+typedef struct sdfs_counters {
+  int32_t nkernels;
+  int32_t reserved;
+  sdfs_kernel_counter k[SDFS_MAX_KERNELS];
+} sdfs_counters;
+
+/* Build an operator handle.  Replaces the closure
+ *   T = lambda w: T_ssy(w, shapes, params, arrays)    (ssy_wc_ratio.py:230)
+ *   T = lambda w: T_gcy(w, shapes, params, arrays)    (gcy_wc_ratio.py:333)
+ * `params`: the 13 (SSY, ssy_model.py:81) or 18 (GCY, gcy_model.py:72-75) scalars.
+ * `arrays`: the 10 (discretize_ssy, ssy_wc_ratio.py:73-77) or 15 (discretize_gcy,
+ * gcy_wc_ratio.py:123-128) host arrays in the reference's order and layout;
+ * `array_sizes[i]` = element count of arrays[i] (checked against `shapes`). */
+int sdfs_create(int model, int ndim, const int64_t* shapes,
+                const double* params, int nparams,
+                const double* const* arrays, const int64_t* array_sizes, int narrays,
+                int device_id, sdfs_handle** out);
+
+/* Sharded variant for one rank of a multi-GPU run: this rank owns the
+ * index block [lo, lo+len) of `shard_axis` of its INPUT grid; see
+ * sdfs_apply_stage_dev.  shard_axis must be an axis no transition matrix is
+ * conditioned on. */
+int sdfs_create_sharded(int model, int ndim, const int64_t* shapes,
+                        const double* params, int nparams,
+                        const double* const* arrays, const int64_t* array_sizes, int narrays,
+                        int device_id, int axis_a, int64_t a_lo, int64_t a_len,
+                        int axis_b, int64_t b_lo, int64_t b_len, sdfs_handle** out);
+
+void sdfs_destroy(sdfs_handle* h);
+const char* sdfs_last_error(const sdfs_handle* h);   /* h may be NULL: last create error */
+int sdfs_default_opts(sdfs_opts* o);
+
+int64_t sdfs_grid_size(const sdfs_handle* h);        /* N = prod(shapes) */
+int sdfs_set_stream(sdfs_handle* h, void* hip_stream); /* NULL -> the handle's own stream */
+int sdfs_synchronize(sdfs_handle* h);
+
+/* Tw = T(w).  Replaces one call of T_ssy / T_gcy.  Host buffers of N doubles. */
+int sdfs_apply_T(sdfs_handle* h, const double* w_host, double* Tw_host);
+/* Same on device pointers; if resid_dev != NULL also writes max|Tw - w| there
+ * (the reduction of code/solvers.py:36 fused into the operator's last kernel). */
+int sdfs_apply_T_dev(sdfs_handle* h, const double* w_dev, double* Tw_dev, double* resid_dev);
+
+/* out = dT(w)[v], the map jax.jvp(f, (w,), (v,))[1] of code/solvers.py:87
+ * (without the "- v" of g = f - id). */
+int sdfs_apply_jvp(sdfs_handle* h, const double* w_host, const double* v_host, double* out_host);
+/* Device form: linearise once at w (caches the two diagonal scalings), then
+ * apply to any number of v.  If Tw_dev != NULL the linearisation also returns T(w). */
+int sdfs_linearize_dev(sdfs_handle* h, const double* w_dev, double* Tw_dev);
+int sdfs_apply_jvp_dev(sdfs_handle* h, const double* v_dev, double* out_dev, int minus_identity);
+
+/* max|T(w) - w| of the most recent apply that computed it. */
+int sdfs_residual(sdfs_handle* h, double* sup_norm);
+
+/* Fixed-point solve, all iterations on the device.  Replaces
+ * successive_approx / newton_solver / anderson_solver (code/solvers.py:19-124):
+ * w_inout holds x_init on entry and x_star on return; n_iter is the value the
+ * reference returns as its second tuple element; n_apply counts operator and
+ * JVP applications; final_err is the last value of the solver's own error. */
+int sdfs_solve(sdfs_handle* h, int algo, const sdfs_opts* opts, double* w_inout_host,
+               int64_t* n_iter, int64_t* n_apply, double* final_err);
+int sdfs_solve_dev(sdfs_handle* h, int algo, const sdfs_opts* opts, double* w_inout_dev,
+                   int64_t* n_iter, int64_t* n_apply, double* final_err);
+/* Error trace of the last solve (record_errors = 1): copies min(cap, n) values. */
+int64_t sdfs_error_trace(sdfs_handle* h, double* out, int64_t cap);
+
+/* Multi-GPU building block: run the local kernels of one operator application.
+ * stage 0: everything that needs no other rank's data (input sharded on axis_a);
+ * stage 1: after the grid re-shard (input sharded on axis_b): the axis_a contraction
+ * and the aggregator.  `mode` 0 = T, 1 = JVP (uses the cached linearisation),
+ * 2 = T + linearise. */
+int sdfs_apply_stage_dev(sdfs_handle* h, int stage, int mode, const double* in_dev,
+                         double* out_dev, const double* w_old_dev, double* resid_dev);
+
+/* Profiling: when enabled every kernel launch is bracketed by HIP events on the
+ * handle's stream; sdfs_get_counters synchronises and sums them. */
+int sdfs_set_profiling(sdfs_handle* h, int on);
+int sdfs_reset_counters(sdfs_handle* h);
+int sdfs_get_counters(sdfs_handle* h, sdfs_counters* out);
+
+/* Human-readable description of the kernel plan (passes, tiles, grid sizes). */
+int sdfs_describe_plan(const sdfs_handle* h, char* buf, int64_t cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SDFS_HIP_H */

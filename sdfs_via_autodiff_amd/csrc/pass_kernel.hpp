@@ -1,0 +1,279 @@
+// pass_kernel.hpp -- the expectation ("H-apply") kernel for gfx950.
+//
+// One launch = one PASS over the state grid.  A pass contracts up to three grid
+// axes with their transition matrices inside an LDS tile:
+//
+//   y[.., i, ..] = sum_I Q_g[cond.., i, I] * x[.., I, ..]           (per axis g)
+//
+// which is how the reference's  sum_{next states} H * w^theta
+// (code/ssy/discrete/ssy_wc_ratio.py:143-145, code/gcy/discrete/gcy_wc_ratio.py:230-232)
+// factorises (every H is a product of per-axis transition matrices).
+// The first pass applies the prologue  x = a1 * w^theta  while loading, the last
+// pass applies the Epstein-Zin aggregator  Tw = 1 + beta (K * S)^(1/theta)
+// (ssy_wc_ratio.py:148, gcy_wc_ratio.py:235) and the sup-norm residual of
+// code/solvers.py:36 while storing.
+//
+// Work decomposition: one workgroup per tile.  A tile has up to three "tile axes"
+// (full extent in LDS, slot 2 = fastest in memory -> coalesced runs); every other
+// grid axis is fixed for the block.  Each contraction is a batched
+// (n x n) . (n x columns) product done with v_mfma_f64_16x16x4_f64: a wave owns
+// 16 columns at a time, keeps the Q fragments in registers, reads the B operand
+// from LDS and writes the result back in place (a wave reads all rows of its 16
+// columns before it writes any of them).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace sdfs {
+
+constexpr int MAXF = 5;   // block-fixed axis slots
+constexpr int MAXN = 32;  // max extent of a contracted axis (2 MFMA row tiles, 8 k-steps)
+
+enum { PRO_NONE = 0, PRO_POW = 1, PRO_POW_LIN = 2, PRO_MUL = 3 };
+enum { EPI_NONE = 0, EPI_CES = 1, EPI_CES_LIN = 2, EPI_MUL = 3 };
+
+struct PassDesc {
+  // block-fixed axes (slowest first)
+  int nfixed;
+  int fext[MAXF];
+  int foff[MAXF];              // global index of local index 0 (sharded runs)
+  long long fstride[MAXF];     // element stride in the (local) grid
+  int fq[3][MAXF];             // matrix-index stride of step s's Q tensor
+  int fa1[MAXF], fa2[MAXF], fa3[MAXF];
+  // tile axes, slot 0 slowest .. slot 2 fastest; unused slots have extent 1
+  int m[3];
+  int toff[3];
+  long long gstride[3];
+  int L[3];                    // LDS strides (L[2] == 1)
+  int ta1[3], ta2[3], ta3[3];
+  // contraction steps
+  int nsteps;
+  int sslot[3];
+  int sn[3];
+  const double* Q[3];
+  // elementwise stages
+  int pro, epi;
+  int minus_identity;          // EPI_MUL: subtract old[idx]
+  double theta, inv_theta, beta;
+  const double* a1;
+  const double* a2;
+  const double* a3;
+  long long ntiles;
+};
+
+struct PassIO {
+  const double* in;        // grid read by the prologue
+  double* out;             // grid written by the epilogue
+  const double* aux_in;    // PRO_MUL: c1;  EPI_MUL: c2
+  double* aux_out;         // PRO_POW_LIN: c1;  EPI_CES_LIN: c2
+  const double* old;       // EPI_CES: w (for the residual);  EPI_MUL: v
+  unsigned long long* resid;        // EPI_CES: atomicMax target (bits of a non-negative double) or null
+  const unsigned long long* gate;   // if non-null and *gate <= tol bits: the iteration has converged, do nothing
+  double gate_tol;
+};
+
+typedef double v4d __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ double pow_pos(double x, double y) {
+  // x > 0 on this path (wealth-consumption ratios); pow() of the device libm.
+  return pow(x, y);
+}
+
+// XCD-aware block -> tile map: blocks b, b+8, b+16.. share an XCD (round-robin
+// dispatch), so give each XCD one contiguous chunk of tiles: neighbouring tiles
+// share 128-B lines and Q matrices in that XCD's L2.  Bijective for any count.
+__device__ __forceinline__ long long xcd_remap(long long b, long long n) {
+  const long long q = n >> 3, r = n & 7;
+  const long long x = b & 7, k = b >> 3;
+  const long long start = (x < r) ? x * (q + 1) : r * (q + 1) + (x - r) * q;
+  return start + k;
+}
+
+__device__ __forceinline__ void contract_step(double* __restrict__ lds, const PassDesc& P, const int s,
+                                              const double* __restrict__ Qm, const int lane,
+                                              const int wave, const int nwaves) {
+  const int slot = P.sslot[s];
+  const int n = P.sn[s];
+  int Ls, Lu, Lv, mu, mv;
+  if (slot == 0) { Ls = P.L[0]; Lu = P.L[1]; mu = P.m[1]; Lv = 1; mv = P.m[2]; }
+  else if (slot == 1) { Ls = P.L[1]; Lu = P.L[0]; mu = P.m[0]; Lv = 1; mv = P.m[2]; }
+  else { Ls = 1; Lu = P.L[0]; mu = P.m[0]; Lv = P.L[1]; mv = P.m[1]; }
+  const int ncols = mu * mv;
+  const int KT = (n + 3) >> 2;
+  const bool mt2 = n > 16;
+  const int li = lane & 15, lk = lane >> 4;
+
+  // A operand: Q[i][I], lane holds A[m = lane&15][k = lane>>4] per k-step (f64 16x16x4 map)
+  double qa[8], qb[8];
+#pragma unroll
+  for (int kk = 0; kk < 8; ++kk) {
+    const int I = 4 * kk + lk;
+    qa[kk] = (li < n && I < n) ? Qm[li * n + I] : 0.0;
+    qb[kk] = (16 + li < n && I < n) ? Qm[(16 + li) * n + I] : 0.0;
+  }
+
+  for (int ct = wave; ct * 16 < ncols; ct += nwaves) {
+    const int col = ct * 16 + li;
+    const int colc = col < ncols ? col : ncols - 1;
+    const int cu = colc / mv;
+    const int cv = colc - cu * mv;
+    const int cbase = cu * Lu + cv * Lv;
+    v4d acc0 = {0.0, 0.0, 0.0, 0.0};
+    v4d acc1 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) {
+      if (kk < KT) {
+        int I = 4 * kk + lk;
+        I = I < n ? I : n - 1;              // rows >= n meet zero Q columns; keep the read in bounds
+        const double b = lds[cbase + I * Ls];
+        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(qa[kk], b, acc0, 0, 0, 0);
+        if (mt2) acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(qb[kk], b, acc1, 0, 0, 0);
+      }
+    }
+    // D map of v_mfma_f64_16x16x4_f64: col = lane&15, row = (lane>>4) + 4*reg
+    if (col < ncols) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = lk + 4 * r;
+        if (i < n) lds[cbase + i * Ls] = acc0[r];
+      }
+      if (mt2) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int i = 16 + lk + 4 * r;
+          if (i < n) lds[cbase + i * Ls] = acc1[r];
+        }
+      }
+    }
+  }
+}
+
+__global__ void __launch_bounds__(512)
+pass_kernel(const PassDesc P, const PassIO io) {
+  extern __shared__ double lds[];
+  __shared__ double red[16];
+
+  if (io.gate != nullptr) {
+    const unsigned long long g = *io.gate;
+    if (g <= (unsigned long long)__double_as_longlong(io.gate_tol)) return;
+  }
+
+  const int tid = threadIdx.x;
+  const int B = blockDim.x;
+  const int lane = tid & 63, wave = tid >> 6, nwaves = B >> 6;
+
+  long long tile = xcd_remap((long long)blockIdx.x, P.ntiles);
+
+  // decode block-fixed coordinates
+  long long gbase = 0;
+  int ia1b = 0, ia2b = 0, ia3b = 0;
+  int q0 = 0, q1 = 0, q2 = 0;
+#pragma unroll
+  for (int k = MAXF - 1; k >= 0; --k) {
+    if (k < P.nfixed) {
+      const int e = P.fext[k];
+      const int c = (int)(tile % e);
+      tile /= e;
+      const int gc = c + P.foff[k];
+      gbase += (long long)c * P.fstride[k];
+      ia1b += gc * P.fa1[k]; ia2b += gc * P.fa2[k]; ia3b += gc * P.fa3[k];
+      q0 += gc * P.fq[0][k]; q1 += gc * P.fq[1][k]; q2 += gc * P.fq[2][k];
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    ia1b += P.toff[j] * P.ta1[j]; ia2b += P.toff[j] * P.ta2[j]; ia3b += P.toff[j] * P.ta3[j];
+  }
+
+  const int m0 = P.m[0], m1 = P.m[1], m2 = P.m[2];
+  const int tot = m0 * m1 * m2;
+  const int L0 = P.L[0], L1 = P.L[1];
+  const long long g0 = P.gstride[0], g1 = P.gstride[1], g2 = P.gstride[2];
+
+  // per-thread tile coordinates of element e = tid, advanced by B each trip
+  int t2 = tid % m2;
+  int rq = tid / m2;
+  int t1 = rq % m1;
+  int t0 = rq / m1;
+  const int d2 = B % m2;
+  const int dq = B / m2;
+  const int d1 = dq % m1;
+  const int d0 = dq / m1;
+  const int s0t = t0, s1t = t1, s2t = t2;
+
+  // ---- load + prologue ----------------------------------------------------
+  for (int e = tid; e < tot; e += B) {
+    const long long gi = gbase + t0 * g0 + t1 * g1 + t2 * g2;
+    double x = io.in[gi];
+    if (P.pro == PRO_POW || P.pro == PRO_POW_LIN) {
+      const int i1 = ia1b + t0 * P.ta1[0] + t1 * P.ta1[1] + t2 * P.ta1[2];
+      const double xw = P.a1[i1] * pow_pos(x, P.theta);
+      if (P.pro == PRO_POW_LIN) io.aux_out[gi] = xw / x;     // c1 = a1 w^(theta-1)
+      x = xw;
+    } else if (P.pro == PRO_MUL) {
+      x *= io.aux_in[gi];
+    }
+    lds[t0 * L0 + t1 * L1 + t2] = x;
+    t2 += d2; int c = t2 >= m2; t2 -= c ? m2 : 0;
+    t1 += d1 + c; c = t1 >= m1; t1 -= c ? m1 : 0;
+    t0 += d0 + c;
+  }
+  __syncthreads();
+
+  // ---- contractions -------------------------------------------------------
+  if (P.nsteps > 0) {
+    contract_step(lds, P, 0, P.Q[0] + (long long)q0 * P.sn[0] * P.sn[0], lane, wave, nwaves);
+    __syncthreads();
+  }
+  if (P.nsteps > 1) {
+    contract_step(lds, P, 1, P.Q[1] + (long long)q1 * P.sn[1] * P.sn[1], lane, wave, nwaves);
+    __syncthreads();
+  }
+  if (P.nsteps > 2) {
+    contract_step(lds, P, 2, P.Q[2] + (long long)q2 * P.sn[2] * P.sn[2], lane, wave, nwaves);
+    __syncthreads();
+  }
+
+  // ---- epilogue + store ---------------------------------------------------
+  t0 = s0t; t1 = s1t; t2 = s2t;
+  double rmax = 0.0;
+  for (int e = tid; e < tot; e += B) {
+    const long long gi = gbase + t0 * g0 + t1 * g1 + t2 * g2;
+    double y = lds[t0 * L0 + t1 * L1 + t2];
+    if (P.epi == EPI_CES || P.epi == EPI_CES_LIN) {
+      const int i2 = ia2b + t0 * P.ta2[0] + t1 * P.ta2[1] + t2 * P.ta2[2];
+      const int i3 = ia3b + t0 * P.ta3[0] + t1 * P.ta3[1] + t2 * P.ta3[2];
+      const double ks = P.a2[i2] * P.a3[i3] * y;
+      const double u = pow_pos(ks, P.inv_theta);
+      const double tw = 1.0 + P.beta * u;
+      if (P.epi == EPI_CES_LIN) io.aux_out[gi] = P.beta * u / y;   // c2 = beta K (K S)^(1/theta-1)
+      if (io.resid != nullptr) {
+        double r = fabs(tw - io.old[gi]);
+        if (!(r == r)) r = __longlong_as_double(0x7ff0000000000000LL);   // NaN -> +inf
+        rmax = fmax(rmax, r);
+      }
+      y = tw;
+    } else if (P.epi == EPI_MUL) {
+      y *= io.aux_in[gi];
+      if (P.minus_identity) y -= io.old[gi];
+    }
+    io.out[gi] = y;
+    t2 += d2; int c = t2 >= m2; t2 -= c ? m2 : 0;
+    t1 += d1 + c; c = t1 >= m1; t1 -= c ? m1 : 0;
+    t0 += d0 + c;
+  }
+
+  if (io.resid != nullptr && (P.epi == EPI_CES || P.epi == EPI_CES_LIN)) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) rmax = fmax(rmax, __shfl_xor(rmax, o));
+    if (lane == 0) red[wave] = rmax;
+    __syncthreads();
+    if (tid == 0) {
+      double r = red[0];
+      for (int w = 1; w < nwaves; ++w) r = fmax(r, red[w]);
+      atomicMax(io.resid, (unsigned long long)__double_as_longlong(r));
+    }
+  }
+}
+
+}  // namespace sdfs

@@ -1,0 +1,1115 @@
+// sdfs_api.hip -- host side of libsdfs_hip.so: model set-up, pass planner, launch
+// plumbing, the device-resident solver loops and the C ABI of include/sdfs_hip.h.
+//
+// Reference behaviour mirrored here (paths relative to the reference repo):
+//   operator      code/ssy/discrete/ssy_wc_ratio.py:82-151, code/gcy/discrete/gcy_wc_ratio.py:134-238
+//   SA loop       code/solvers.py:19-48
+//   Newton-Krylov code/solvers.py:51-95  (+ jax.scipy.sparse.linalg.bicgstab semantics)
+//   Anderson      code/solvers.py:98-124 (+ jaxopt.AndersonAcceleration semantics, unpinned)
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <limits>
+#include <string>
+#include <vector>
+
+#include "../../include/sdfs_hip.h"
+#include "pass_kernel.hpp"
+#include "vec_kernels.hpp"
+
+using namespace sdfs;
+
+namespace {
+
+constexpr int MAXD = 6;
+constexpr unsigned long long INF_BITS = 0x7ff0000000000000ULL;
+
+thread_local std::string g_create_error;
+
+struct AxisInfo {
+  int n = 1;            // global extent
+  int nloc = 1;         // local extent (== n unless this axis is sharded in this stage)
+  int off = 0;          // global index of local index 0
+  const double* Q = nullptr;   // device transition tensor [.., n, n]
+  int qs[MAXD] = {0, 0, 0, 0, 0, 0};  // matrix-index stride per conditioning axis
+  long long qcount = 0;        // number of n x n matrices in Q
+  int a1s = 0, a2s = 0, a3s = 0;
+  char name[8] = "";
+};
+
+struct Pass {
+  PassDesc d;
+  int block = 256;
+  size_t lds_bytes = 0;
+  int tile_axes[3] = {-1, -1, -1};
+  int step_axes[3] = {-1, -1, -1};
+  double q_bytes = 0;
+  double flops = 0;
+  int counter = -1;
+  std::string label;
+};
+
+struct Plan {
+  std::vector<Pass> passes;
+  long long nloc = 0;     // local grid points
+  int shape[MAXD];
+};
+
+struct EventPair { hipEvent_t a, b; int counter; };
+
+}  // namespace
+
+struct sdfs_handle {
+  int device = 0;
+  hipStream_t own_stream = nullptr;
+  hipStream_t stream = nullptr;
+  int model = 0, ndim = 0;
+  int shape[MAXD] = {1, 1, 1, 1, 1, 1};
+  long long N = 0;
+  double theta = 0, beta = 0;
+  std::string err;
+
+  // device copies of the model tensors
+  std::vector<double*> dev_allocs;
+  double *a1 = nullptr, *a2 = nullptr, *a3 = nullptr;
+  AxisInfo ax[MAXD];
+
+  // plans: [0] full grid (or stage 0 of a sharded run), [1] stage 1 of a sharded run
+  Plan plan[2];
+  bool sharded = false;
+  int axis_a = -1, axis_b = -1;
+
+  // work buffers (lazy)
+  double* tmp = nullptr;
+  double *c1 = nullptr, *c2 = nullptr;
+  double *buf0 = nullptr, *buf1 = nullptr;
+  double *hostio = nullptr;          // device staging for the host-pointer entry points
+  double *hostio2 = nullptr, *hostio3 = nullptr;
+  std::vector<double*> kry;          // r, rhat, p, q, t, step, g
+  double* partial = nullptr;         // reduction partials
+  double* sc = nullptr;              // device scalars
+  double* sc_host = nullptr;         // pinned
+  unsigned long long* slots = nullptr;      // residual slots (device)
+  unsigned long long* slots_host = nullptr; // pinned mirror
+  int nslots = 0;
+  std::vector<double*> andX, andR;
+  double* gram_row = nullptr;
+  double* gram_row_host = nullptr;
+
+  double last_resid = std::numeric_limits<double>::quiet_NaN();
+  std::vector<double> trace;
+
+  // profiling
+  bool profiling = false;
+  sdfs_counters counters;
+  std::vector<EventPair> pending;
+  std::vector<hipEvent_t> event_pool;
+
+  // graph cache for the SA chunk
+  hipGraphExec_t sa_graph = nullptr;
+  int sa_graph_chunk = 0;
+};
+
+namespace {
+
+int fail(sdfs_handle* h, int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  if (h) h->err = buf; else g_create_error = buf;
+  return code;
+}
+
+#define HIPCHK(h, call)                                                                   \
+  do {                                                                                    \
+    hipError_t e_ = (call);                                                               \
+    if (e_ != hipSuccess)                                                                 \
+      return fail((h), SDFS_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), \
+                  __FILE__, __LINE__);                                                    \
+  } while (0)
+
+int dev_alloc(sdfs_handle* h, double** p, size_t count) {
+  HIPCHK(h, hipMalloc((void**)p, std::max<size_t>(count, 1) * sizeof(double)));
+  h->dev_allocs.push_back(*p);
+  return 0;
+}
+
+int upload(sdfs_handle* h, double** dst, const double* src, size_t count) {
+  int rc = dev_alloc(h, dst, count);
+  if (rc) return rc;
+  HIPCHK(h, hipMemcpy(*dst, src, count * sizeof(double), hipMemcpyHostToDevice));
+  return 0;
+}
+
+int env_int(const char* name, int dflt) {
+  const char* s = getenv(name);
+  return (s && *s) ? atoi(s) : dflt;
+}
+
+// ---------------------------------------------------------------------------
+// Planner: group the axes into passes (legal order, LDS budget, coalesced runs).
+// `todo` = axes to contract in this plan (all, or a stage's subset); `done` = axes
+// already in current-state form when the plan starts.
+int build_plan(sdfs_handle* h, Plan& plan, const std::vector<int>& todo_in, std::vector<bool> done) {
+  const int D = h->ndim;
+  long long nloc = 1;
+  for (int a = 0; a < D; ++a) { plan.shape[a] = h->ax[a].nloc; nloc *= h->ax[a].nloc; }
+  plan.nloc = nloc;
+  long long stride[MAXD];
+  {
+    long long s = 1;
+    for (int a = D - 1; a >= 0; --a) { stride[a] = s; s *= h->ax[a].nloc; }
+  }
+  long long budget = env_int("SDFS_TILE_BUDGET", 0);
+  if (budget <= 0) budget = std::max<long long>(256, std::min<long long>(8192, nloc / 128));
+
+  std::vector<int> todo = todo_in;
+  auto cond_ok = [&](int g, const std::vector<bool>& dn) {
+    for (int c = 0; c < D; ++c) if (h->ax[g].qs[c] != 0 && !dn[c]) return false;
+    return true;
+  };
+  auto in = [](const std::vector<int>& v, int x) { return std::find(v.begin(), v.end(), x) != v.end(); };
+
+  while (!todo.empty()) {
+    std::vector<int> cand;
+    for (int g : todo) if (cond_ok(g, done)) cand.push_back(g);
+    if (cand.empty()) return fail(h, SDFS_ERR_ARG, "planner: cyclic conditioning between axes");
+    std::sort(cand.begin(), cand.end(), [](int x, int y) { return x > y; });   // fastest first
+
+    std::vector<int> G, tile;
+    auto tile_elems = [&](const std::vector<int>& t) {
+      long long e = 1; for (int a : t) e *= h->ax[a].nloc; return e; };
+      auto conflicts = [&](const std::vector<int>& grp, const std::vector<int>& t) {
+      for (int g : grp) for (int a : t) if (h->ax[g].qs[a] != 0) return true;
+      return false;
+    };
+    const int F = D - 1;
+    for (int g : cand) {
+      if (h->ax[g].nloc != h->ax[g].n) continue;          // a sharded axis cannot be contracted locally
+      std::vector<int> ng = G; ng.push_back(g);
+      std::vector<int> nt = tile; if (!in(nt, g)) nt.push_back(g);
+      std::vector<int> ntF = nt; if (!in(ntF, F)) ntF.push_back(F);
+      if ((int)ntF.size() <= 3 && tile_elems(ntF) <= budget && !conflicts(ng, ntF)) { G = ng; tile = ntF; continue; }
+      if (G.empty() && (int)nt.size() <= 3 && !conflicts(ng, nt)) {    // no room for the run axis
+        if (h->ax[g].nloc > MAXN) return fail(h, SDFS_ERR_UNSUPPORTED, "axis extent %d > %d", h->ax[g].nloc, MAXN);
+        G = ng; tile = nt;
+      }
+    }
+    if (G.empty()) return fail(h, SDFS_ERR_ARG, "planner: no contractible axis (sharded axis still pending?)");
+    // filler axes: amortise a conditional Q over more columns / keep >= 16 columns per step
+    while ((int)tile.size() < 3) {
+      int pick = -1;
+      for (int a = D - 1; a >= 0; --a) {
+        if (in(tile, a)) continue;
+        bool bad = false;
+        for (int g : G) if (h->ax[g].qs[a] != 0) bad = true;
+        if (bad) continue;
+        pick = a; break;
+      }
+      if (pick < 0) break;
+      std::vector<int> nt = tile; nt.push_back(pick);
+      const long long e = tile_elems(nt);
+      long long mincols = 1LL << 60;
+      for (int g : G) mincols = std::min(mincols, tile_elems(tile) / h->ax[g].nloc);
+      const bool want = (mincols < 16) || (nloc / e >= 512);
+      if (e > budget || !want) break;
+      tile = nt;
+    }
+    std::sort(tile.begin(), tile.end());                    // slow -> fast
+    // steps: fastest axis first
+    std::sort(G.begin(), G.end(), [](int x, int y) { return x > y; });
+
+    Pass P;
+    memset(&P.d, 0, sizeof P.d);
+    PassDesc& d = P.d;
+    const int nt = (int)tile.size();
+    for (int j = 0; j < 3; ++j) { d.m[j] = 1; d.toff[j] = 0; d.gstride[j] = 0; d.ta1[j] = d.ta2[j] = d.ta3[j] = 0; }
+    for (int j = 0; j < nt; ++j) {
+      const int slot = 3 - nt + j, a = tile[j];
+      d.m[slot] = h->ax[a].nloc; d.toff[slot] = h->ax[a].off; d.gstride[slot] = stride[a];
+      d.ta1[slot] = h->ax[a].a1s; d.ta2[slot] = h->ax[a].a2s; d.ta3[slot] = h->ax[a].a3s;
+      P.tile_axes[slot] = a;
+    }
+    d.nfixed = 0;
+    long long ntiles = 1;
+    for (int a = 0; a < D; ++a) {
+      if (in(tile, a)) continue;
+      if (d.nfixed >= MAXF) return fail(h, SDFS_ERR_UNSUPPORTED, "too many fixed axes");
+      const int k = d.nfixed++;
+      d.fext[k] = h->ax[a].nloc; d.foff[k] = h->ax[a].off; d.fstride[k] = stride[a];
+      d.fa1[k] = h->ax[a].a1s; d.fa2[k] = h->ax[a].a2s; d.fa3[k] = h->ax[a].a3s;
+      for (int s = 0; s < (int)G.size(); ++s) d.fq[s][k] = h->ax[G[s]].qs[a];
+      ntiles *= h->ax[a].nloc;
+    }
+    d.ntiles = ntiles;
+    d.nsteps = (int)G.size();
+    bool contracts_fast_slot = false;
+    long long maxct = 1;
+    for (int s = 0; s < d.nsteps; ++s) {
+      const int g = G[s];
+      if (h->ax[g].n > MAXN) return fail(h, SDFS_ERR_UNSUPPORTED, "axis extent %d > %d", h->ax[g].n, MAXN);
+      int slot = -1;
+      for (int j = 0; j < 3; ++j) if (P.tile_axes[j] == g) slot = j;
+      d.sslot[s] = slot; d.sn[s] = h->ax[g].n; d.Q[s] = h->ax[g].Q;
+      P.step_axes[s] = g;
+      if (slot == 2) contracts_fast_slot = true;
+      const long long cols = tile_elems(tile) / h->ax[g].nloc;
+      maxct = std::max(maxct, (cols + 15) / 16);
+      P.q_bytes += 8.0 * (double)h->ax[g].qcount * h->ax[g].n * h->ax[g].n;
+      P.flops += 2.0 * (double)nloc * h->ax[g].n;
+    }
+    // LDS strides: pad the fastest stride to == 2 (mod 4) doubles when it is the
+    // K dimension of an MFMA step (16 columns x 2 rows then hit 32 distinct b64 banks)
+    int L1 = d.m[2];
+    if (contracts_fast_slot && d.m[1] * d.m[0] > 1) { while ((L1 & 3) != 2) ++L1; }
+    d.L[2] = 1; d.L[1] = L1; d.L[0] = L1 * d.m[1];
+    const long long lds_elems = (long long)d.L[0] * d.m[0];
+    P.lds_bytes = (size_t)lds_elems * 8;
+    if (P.lds_bytes > 150 * 1024) return fail(h, SDFS_ERR_UNSUPPORTED, "tile of %lld doubles exceeds LDS", lds_elems);
+    // block size: balance column tiles over waves, keep enough lanes for the elementwise stages
+    const long long tot = tile_elems(tile);
+    int w_elem = (int)std::min<long long>(8, std::max<long long>(1, (tot + 127) / 128));
+    int w_mfma = (int)std::min<long long>(maxct, 8);
+    if (maxct > 4) {
+      long long best = 1LL << 60;
+      for (int w = 8; w >= 4; --w) {
+        long long cost = 0;
+        for (int s = 0; s < d.nsteps; ++s) {
+          const long long ct = (tot / d.sn[s] + 15) / 16;
+          cost += (ct + w - 1) / w;
+        }
+        if (cost < best) { best = cost; w_mfma = w; }
+      }
+    }
+    int fw = env_int("SDFS_FORCE_WAVES", 0);
+    P.block = 64 * (fw > 0 ? fw : std::max(w_elem, w_mfma));
+    char lab[96];
+    int o = snprintf(lab, sizeof lab, "expect[");
+    for (int s = 0; s < d.nsteps; ++s) o += snprintf(lab + o, sizeof lab - o, "%s%s", s ? "," : "", h->ax[G[s]].name);
+    o += snprintf(lab + o, sizeof lab - o, "|tile");
+    for (int j = 0; j < 3; ++j) if (P.tile_axes[j] >= 0) o += snprintf(lab + o, sizeof lab - o, " %s", h->ax[P.tile_axes[j]].name);
+    snprintf(lab + o, sizeof lab - o, "]");
+    P.label = lab;
+    plan.passes.push_back(P);
+
+    for (int g : G) { done[g] = true; todo.erase(std::find(todo.begin(), todo.end(), g)); }
+  }
+  return 0;
+}
+
+// ---------------------------------------------------------------------------
+int get_event(sdfs_handle* h, hipEvent_t* e) {
+  if (!h->event_pool.empty()) { *e = h->event_pool.back(); h->event_pool.pop_back(); return 0; }
+  HIPCHK(h, hipEventCreate(e));
+  return 0;
+}
+
+int drain_events(sdfs_handle* h) {
+  if (h->pending.empty()) return 0;
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  for (auto& p : h->pending) {
+    float ms = 0.f;
+    HIPCHK(h, hipEventElapsedTime(&ms, p.a, p.b));
+    h->counters.k[p.counter].launches += 1;
+    h->counters.k[p.counter].total_ms += ms;
+    h->event_pool.push_back(p.a);
+    h->event_pool.push_back(p.b);
+  }
+  h->pending.clear();
+  return 0;
+}
+
+int counter_id(sdfs_handle* h, const char* name, double bytes, double flops) {
+  for (int i = 0; i < h->counters.nkernels; ++i)
+    if (strncmp(h->counters.k[i].name, name, sizeof h->counters.k[i].name - 1) == 0) return i;
+  if (h->counters.nkernels >= SDFS_MAX_KERNELS) return SDFS_MAX_KERNELS - 1;
+  const int i = h->counters.nkernels++;
+  memset(&h->counters.k[i], 0, sizeof h->counters.k[i]);
+  strncpy(h->counters.k[i].name, name, sizeof h->counters.k[i].name - 1);
+  h->counters.k[i].alg_bytes = bytes;
+  h->counters.k[i].alg_flops = flops;
+  return i;
+}
+
+struct ProfScope {
+  sdfs_handle* h; hipEvent_t a = nullptr, b = nullptr; int counter; bool on;
+  ProfScope(sdfs_handle* h_, int counter_) : h(h_), counter(counter_), on(h_->profiling && counter_ >= 0) {
+    if (on) {
+      if (get_event(h, &a) || get_event(h, &b)) { on = false; return; }
+      hipEventRecord(a, h->stream);
+    }
+  }
+  ~ProfScope() {
+    if (on) {
+      hipEventRecord(b, h->stream);
+      h->pending.push_back({a, b, counter});
+      if (h->pending.size() > 4096) drain_events(h);
+    }
+  }
+};
+
+int vec_grid(long long n) {
+  long long g = (n + VEC_BLOCK * 4 - 1) / (VEC_BLOCK * 4);
+  return (int)std::max<long long>(1, std::min<long long>(g, MAX_PARTIAL_BLOCKS));
+}
+
+// modes of one operator application
+enum { MODE_T = 0, MODE_JVP = 1, MODE_T_LIN = 2 };
+
+int launch_pass(sdfs_handle* h, Pass& P, int pro, int epi, const PassIO& io, int minus_identity,
+                const char* tag, double bytes) {
+  PassDesc d = P.d;
+  d.pro = pro; d.epi = epi; d.minus_identity = minus_identity;
+  d.theta = h->theta; d.inv_theta = 1.0 / h->theta; d.beta = h->beta;
+  d.a1 = h->a1; d.a2 = h->a2; d.a3 = h->a3;
+  int cid = -1;
+  if (h->profiling) {
+    char nm[48];
+    snprintf(nm, sizeof nm, "%s:%s", tag, P.label.c_str());
+    cid = counter_id(h, nm, bytes, P.flops);
+  }
+  ProfScope ps(h, cid);
+  hipLaunchKernelGGL(pass_kernel, dim3((unsigned)d.ntiles), dim3(P.block), P.lds_bytes, h->stream, d, io);
+  HIPCHK(h, hipGetLastError());
+  return 0;
+}
+
+int ensure_tmp(sdfs_handle* h) {
+  if (!h->tmp) return dev_alloc(h, &h->tmp, (size_t)std::max(h->plan[0].nloc, h->plan[1].nloc));
+  return 0;
+}
+int ensure_lin(sdfs_handle* h) {
+  const size_t n = (size_t)std::max(h->plan[0].nloc, h->plan[1].nloc);
+  if (!h->c1) { int rc = dev_alloc(h, &h->c1, n); if (rc) return rc; }
+  if (!h->c2) { int rc = dev_alloc(h, &h->c2, n); if (rc) return rc; }
+  return 0;
+}
+
+// Run the passes of `plan`.  first/last tell whether this plan holds the operator's
+// first pass (prologue) and last pass (epilogue) -- a sharded stage holds only one.
+int run_plan(sdfs_handle* h, Plan& plan, int mode, bool has_first, bool has_last,
+             const double* in, double* out, const double* old, unsigned long long* resid,
+             const unsigned long long* gate, double gate_tol, int minus_identity) {
+  int rc = ensure_tmp(h);
+  if (rc) return rc;
+  if (mode != MODE_T) { rc = ensure_lin(h); if (rc) return rc; }
+  const int np = (int)plan.passes.size();
+  const double n8 = 8.0 * (double)plan.nloc;
+  for (int i = 0; i < np; ++i) {
+    Pass& P = plan.passes[i];
+    const bool first = has_first && i == 0, last = has_last && i == np - 1;
+    PassIO io;
+    memset(&io, 0, sizeof io);
+    io.in = (i == 0) ? in : h->tmp;
+    io.out = (i == np - 1) ? out : h->tmp;
+    io.gate = gate; io.gate_tol = gate_tol;
+    int pro = PRO_NONE, epi = EPI_NONE;
+    double bytes = 2 * n8 + P.q_bytes;
+    if (first) {
+      if (mode == MODE_T) pro = PRO_POW;
+      else if (mode == MODE_T_LIN) { pro = PRO_POW_LIN; io.aux_out = h->c1; bytes += n8; }
+      else { pro = PRO_MUL; io.aux_in = h->c1; bytes += n8; }
+    }
+    if (last) {
+      if (mode == MODE_T) { epi = EPI_CES; io.old = old; io.resid = resid; if (resid) bytes += n8; }
+      else if (mode == MODE_T_LIN) {
+        epi = EPI_CES_LIN; io.old = old; io.resid = resid; bytes += n8; if (resid) bytes += n8;
+        // aux_out of the LAST pass is c2; if the same pass is also the first, c1 and c2
+        // would collide on aux_out -- a single-pass plan splits linearisation in two launches
+        if (first) return fail(h, SDFS_ERR_UNSUPPORTED, "single-pass linearise not supported");
+        io.aux_out = h->c2;
+      } else {
+        epi = EPI_MUL; bytes += n8;
+        if (first) return fail(h, SDFS_ERR_UNSUPPORTED, "single-pass JVP not supported");
+        io.aux_in = h->c2; io.old = old; if (minus_identity) bytes += n8;
+      }
+    }
+    const char* tag = (mode == MODE_JVP) ? "jvp" : (mode == MODE_T_LIN ? "Tlin" : "T");
+    rc = launch_pass(h, P, pro, epi, io, minus_identity, tag, bytes);
+    if (rc) return rc;
+  }
+  return 0;
+}
+
+int apply_T_dev(sdfs_handle* h, const double* w, double* Tw, unsigned long long* resid,
+                const unsigned long long* gate, double gate_tol) {
+  return run_plan(h, h->plan[0], MODE_T, true, true, w, Tw, w, resid, gate, gate_tol, 0);
+}
+
+int ensure_slots(sdfs_handle* h, int n) {
+  if (h->nslots >= n + 2) return 0;
+  if (h->slots) { hipFree(h->slots); hipHostFree(h->slots_host); }
+  h->nslots = n + 2;
+  HIPCHK(h, hipMalloc((void**)&h->slots, sizeof(unsigned long long) * h->nslots));
+  HIPCHK(h, hipHostMalloc((void**)&h->slots_host, sizeof(unsigned long long) * h->nslots));
+  return 0;
+}
+
+int ensure_buf(sdfs_handle* h, double** p) {
+  if (*p) return 0;
+  return dev_alloc(h, p, (size_t)h->N);
+}
+
+int ensure_scalars(sdfs_handle* h) {
+  if (!h->partial) { int rc = dev_alloc(h, &h->partial, (size_t)MAX_PARTIAL_BLOCKS * AND_MAX_M); if (rc) return rc; }
+  if (!h->sc) {
+    int rc = dev_alloc(h, &h->sc, SC_COUNT); if (rc) return rc;
+    HIPCHK(h, hipHostMalloc((void**)&h->sc_host, sizeof(double) * SC_COUNT));
+  }
+  return 0;
+}
+
+double bits_to_double(unsigned long long b) { double d; memcpy(&d, &b, 8); return d; }
+
+// ---------------------------------------------------------------------------
+// successive approximation (code/solvers.py:19-48), all iterations on the device.
+// Iteration it computes x_{it+1} = T(x_it) and err_it = max|x_{it+1} - x_it| into
+// slot it%chunk; every later kernel is gated on the previous slot, so once
+// err <= tol the remaining launches of the chunk are no-ops and the iterate stays.
+int solve_sa(sdfs_handle* h, const sdfs_opts& o, double* w, int64_t* n_iter, int64_t* n_apply, double* final_err) {
+  int rc;
+  if ((rc = ensure_buf(h, &h->buf0)) || (rc = ensure_buf(h, &h->buf1)) || (rc = ensure_tmp(h))) return rc;
+  int chunk = std::max(1, o.check_every);
+  if (o.use_graph && (chunk & 1)) ++chunk;                  // even: ping-pong parity repeats per replay
+  if ((rc = ensure_slots(h, chunk))) return rc;
+  unsigned long long* carry = h->slots + chunk;             // error of the last iteration of the previous chunk
+  const size_t nb = sizeof(double) * (size_t)h->N;
+  HIPCHK(h, hipMemcpyAsync(h->buf0, w, nb, hipMemcpyDeviceToDevice, h->stream));
+  h->slots_host[chunk] = ~0ULL;                             // "not converged yet"
+  HIPCHK(h, hipMemcpyAsync(carry, h->slots_host + chunk, 8, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  h->trace.clear();
+  double* bufs[2] = {h->buf0, h->buf1};
+
+  // `count` iterations starting at global iteration it0 (it0 even whenever count == chunk)
+  auto enqueue = [&](long long it0, int count) -> int {
+    HIPCHK(h, hipMemsetAsync(h->slots, 0, 8 * (size_t)chunk, h->stream));
+    for (int i = 0; i < count; ++i) {
+      const long long it = it0 + i;
+      int r2 = apply_T_dev(h, bufs[it & 1], bufs[(it + 1) & 1], h->slots + i,
+                           i == 0 ? carry : h->slots + i - 1, o.tol);
+      if (r2) return r2;
+    }
+    HIPCHK(h, hipMemcpyAsync(carry, h->slots + count - 1, 8, hipMemcpyDeviceToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->slots_host, h->slots, 8 * (size_t)count, hipMemcpyDeviceToHost, h->stream));
+    return 0;
+  };
+  const bool graph = o.use_graph && !h->profiling;
+  if (graph && (h->sa_graph == nullptr || h->sa_graph_chunk != chunk)) {
+    if (h->sa_graph) { hipGraphExecDestroy(h->sa_graph); h->sa_graph = nullptr; }
+    hipGraph_t g = nullptr;
+    HIPCHK(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+    rc = enqueue(0, chunk);
+    hipError_t e = hipStreamEndCapture(h->stream, &g);
+    if (rc) return rc;
+    HIPCHK(h, e);
+    HIPCHK(h, hipGraphInstantiate(&h->sa_graph, g, nullptr, nullptr, 0));
+    hipGraphDestroy(g);
+    h->sa_graph_chunk = chunk;
+  }
+
+  long long it = 0;            // completed iterations (the reference's current_iter)
+  long long buf_it = 0;        // iterations whose result the buffers hold
+  double err = o.tol + 1;
+  bool stop = false;
+  int status = 0;
+  while (!stop && it < o.max_iter) {
+    const int count = (int)std::min<long long>(chunk, o.max_iter - it);
+    if (graph && count == chunk) { HIPCHK(h, hipGraphLaunch(h->sa_graph, h->stream)); }
+    else if ((rc = enqueue(it, count))) return rc;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    const long long it0 = it;
+    buf_it = it0 + count;                                   // unless the gate closed earlier
+    for (int i = 0; i < count; ++i) {
+      err = bits_to_double(h->slots_host[i]);
+      if (o.record_errors) h->trace.push_back(err);
+      it = it0 + i + 1;
+      if (!std::isfinite(err)) { stop = true; status = SDFS_ERR_NUMERIC; break; }   // buffers ran on to it0+count
+      if (!(err > o.tol)) { stop = true; buf_it = it; break; }                      // later launches were gated off
+    }
+  }
+  HIPCHK(h, hipMemcpyAsync(w, bufs[buf_it & 1], nb, hipMemcpyDeviceToDevice, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  h->last_resid = err;
+  *n_iter = it; *n_apply = buf_it; *final_err = err;
+  if (status) return fail(h, status, "non-finite error at iteration %lld", it);
+  return 0;
+}
+
+// ---------------------------------------------------------------------------
+// BiCGSTAB on device vectors (jax.scipy.sparse.linalg.bicgstab semantics: x0 = 0,
+// stop when |r|^2 <= max(rtol^2 |b|^2, atol^2), breakdown flags, maxiter 10 N).
+// b in kry[6]; solution in kry[5].  One host sync per iteration (reads rr).
+int bicgstab_dev(sdfs_handle* h, const sdfs_opts& o, int64_t* matvecs) {
+  double *r = h->kry[0], *rhat = h->kry[1], *p = h->kry[2], *q = h->kry[3], *t = h->kry[4],
+         *x = h->kry[5], *b = h->kry[6];
+  const long long n = h->N;
+  const int g = vec_grid(n);
+  hipStream_t st = h->stream;
+  const int cvec = h->profiling ? counter_id(h, "bicgstab_blas1", 0, 0) : -1;
+  {
+    ProfScope ps(h, cvec);
+    hipLaunchKernelGGL(k_bicg_init, dim3(g), dim3(VEC_BLOCK), 0, st, b, r, rhat, p, q, x, n);
+    hipLaunchKernelGGL(k_dot, dim3(g), dim3(VEC_BLOCK), 0, st, b, b, n, h->partial);
+    hipLaunchKernelGGL(k_bicg_init_finish, dim3(1), dim3(VEC_BLOCK), 0, st, h->partial, g, h->sc, o.inner_rtol, o.inner_atol);
+  }
+  HIPCHK(h, hipMemcpyAsync(h->sc_host, h->sc, sizeof(double) * SC_COUNT, hipMemcpyDeviceToHost, st));
+  HIPCHK(h, hipStreamSynchronize(st));
+  const double atol2 = h->sc_host[SC_ATOL2];
+  double rr = h->sc_host[SC_RR];
+  const long long maxit = o.inner_max_iter > 0 ? o.inner_max_iter : 10 * n;
+  long long k = 0;
+  while (rr > atol2 && k < maxit) {
+    int rc;
+    { ProfScope ps(h, cvec);
+      hipLaunchKernelGGL(k_bicg_update_p, dim3(g), dim3(VEC_BLOCK), 0, st, r, p, q, n, h->sc); }
+    if ((rc = run_plan(h, h->plan[0], MODE_JVP, true, true, p, q, p, nullptr, nullptr, 0.0, 1))) return rc;
+    { ProfScope ps(h, cvec);
+      hipLaunchKernelGGL(k_dot, dim3(g), dim3(VEC_BLOCK), 0, st, rhat, q, n, h->partial);
+      hipLaunchKernelGGL(k_bicg_alpha_finish, dim3(1), dim3(VEC_BLOCK), 0, st, h->partial, g, h->sc);
+      hipLaunchKernelGGL(k_bicg_s, dim3(g), dim3(VEC_BLOCK), 0, st, r, q, n, h->sc, h->partial);
+      hipLaunchKernelGGL(k_bicg_s_finish, dim3(1), dim3(VEC_BLOCK), 0, st, h->partial, g, h->sc); }
+    if ((rc = run_plan(h, h->plan[0], MODE_JVP, true, true, r, t, r, nullptr, nullptr, 0.0, 1))) return rc;
+    { ProfScope ps(h, cvec);
+      hipLaunchKernelGGL(k_dot2, dim3(g), dim3(VEC_BLOCK), 0, st, t, r, n, h->partial);
+      hipLaunchKernelGGL(k_bicg_omega_finish, dim3(1), dim3(VEC_BLOCK), 0, st, h->partial, g, h->sc);
+      hipLaunchKernelGGL(k_bicg_update_xr, dim3(g), dim3(VEC_BLOCK), 0, st, x, r, p, t, rhat, n, h->sc, h->partial);
+      hipLaunchKernelGGL(k_bicg_iter_finish, dim3(1), dim3(VEC_BLOCK), 0, st, h->partial, g, h->sc); }
+    *matvecs += 2;
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipMemcpyAsync(h->sc_host, h->sc, sizeof(double) * SC_COUNT, hipMemcpyDeviceToHost, st));
+    HIPCHK(h, hipStreamSynchronize(st));
+    rr = h->sc_host[SC_RR];
+    if (h->sc_host[SC_BREAK] != 0.0) break;
+    if (!(rr == rr)) break;
+    ++k;
+  }
+  return 0;
+}
+
+// Newton on g = T - id (code/solvers.py:51-95): x <- x - J(x)^{-1} g(x), outer loop is
+// the successive_approx stopping rule on the Newton map.
+int solve_newton(sdfs_handle* h, const sdfs_opts& o, double* w, int64_t* n_iter, int64_t* n_apply, double* final_err) {
+  int rc;
+  if ((rc = ensure_buf(h, &h->buf0)) || (rc = ensure_buf(h, &h->buf1)) || (rc = ensure_scalars(h)) ||
+      (rc = ensure_slots(h, 2)))
+    return rc;
+  while (h->kry.size() < 7) { double* p = nullptr; if ((rc = dev_alloc(h, &p, (size_t)h->N))) return rc; h->kry.push_back(p); }
+  const long long n = h->N;
+  const int g = vec_grid(n);
+  const size_t nb = sizeof(double) * (size_t)n;
+  hipStream_t st = h->stream;
+  double* x = h->buf0;
+  double* Tx = h->buf1;
+  HIPCHK(h, hipMemcpyAsync(x, w, nb, hipMemcpyDeviceToDevice, st));
+  h->trace.clear();
+  long long it = 0;
+  double err = o.tol + 1;
+  int64_t applies = 0;
+  int status = 0;
+  const int cvec = h->profiling ? counter_id(h, "newton_blas1", 0, 0) : -1;
+  while (err > o.tol && it < o.max_iter) {
+    // g(x) = T(x) - x, linearisation cached for the J.v products
+    if ((rc = run_plan(h, h->plan[0], MODE_T_LIN, true, true, x, Tx, x, nullptr, nullptr, 0.0, 0))) return rc;
+    ++applies;
+    { ProfScope ps(h, cvec);
+      hipLaunchKernelGGL(k_sub_dot, dim3(g), dim3(VEC_BLOCK), 0, st, Tx, x, h->kry[6], n, h->partial); }
+    if ((rc = bicgstab_dev(h, o, &applies))) return rc;
+    HIPCHK(h, hipMemsetAsync(h->slots, 0, 8, st));
+    { ProfScope ps(h, cvec);
+      hipLaunchKernelGGL(k_newton_update, dim3(g), dim3(VEC_BLOCK), 0, st, x, h->kry[5], x, n, h->slots); }
+    HIPCHK(h, hipMemcpyAsync(h->slots_host, h->slots, 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(h, hipStreamSynchronize(st));
+    err = bits_to_double(h->slots_host[0]);
+    if (o.record_errors) h->trace.push_back(err);
+    ++it;
+    if (!std::isfinite(err)) { status = SDFS_ERR_NUMERIC; break; }
+  }
+  HIPCHK(h, hipMemcpyAsync(w, x, nb, hipMemcpyDeviceToDevice, st));
+  HIPCHK(h, hipStreamSynchronize(st));
+  *n_iter = it; *n_apply = applies; *final_err = err;
+  if (status) return fail(h, status, "non-finite Newton step at iteration %lld", it);
+  return 0;
+}
+
+// dense solve of the (m+1) x (m+1) bordered Anderson system, partial pivoting
+bool solve_dense(std::vector<double>& A, std::vector<double>& b, int n) {
+  for (int c = 0; c < n; ++c) {
+    int piv = c;
+    for (int r = c + 1; r < n; ++r) if (std::fabs(A[r * n + c]) > std::fabs(A[piv * n + c])) piv = r;
+    if (A[piv * n + c] == 0.0) return false;
+    if (piv != c) { for (int k = 0; k < n; ++k) std::swap(A[c * n + k], A[piv * n + k]); std::swap(b[c], b[piv]); }
+    for (int r = c + 1; r < n; ++r) {
+      const double f = A[r * n + c] / A[c * n + c];
+      if (f == 0.0) continue;
+      for (int k = c; k < n; ++k) A[r * n + k] -= f * A[c * n + k];
+      b[r] -= f * b[c];
+    }
+  }
+  for (int r = n - 1; r >= 0; --r) {
+    double s = b[r];
+    for (int k = r + 1; k < n; ++k) s -= A[r * n + k] * b[k];
+    b[r] = s / A[r * n + r];
+  }
+  return true;
+}
+
+// Anderson acceleration with jaxopt's parametrisation (code/solvers.py:98-124).
+int solve_anderson(sdfs_handle* h, const sdfs_opts& o, double* w, int64_t* n_iter, int64_t* n_apply, double* final_err) {
+  int rc;
+  const int m = o.history;
+  if (m < 1 || m > AND_MAX_M) return fail(h, SDFS_ERR_ARG, "Anderson history must be in 1..%d", AND_MAX_M);
+  if (o.mixing_freq < 1) return fail(h, SDFS_ERR_ARG, "mixing_freq must be >= 1");
+  if ((rc = ensure_buf(h, &h->buf0)) || (rc = ensure_buf(h, &h->buf1)) || (rc = ensure_scalars(h))) return rc;
+  while ((int)h->andX.size() < m) {
+    double *a = nullptr, *b = nullptr;
+    if ((rc = dev_alloc(h, &a, (size_t)h->N)) || (rc = dev_alloc(h, &b, (size_t)h->N))) return rc;
+    h->andX.push_back(a); h->andR.push_back(b);
+  }
+  if (!h->gram_row) {
+    if ((rc = dev_alloc(h, &h->gram_row, AND_MAX_M))) return rc;
+    HIPCHK(h, hipHostMalloc((void**)&h->gram_row_host, sizeof(double) * AND_MAX_M));
+  }
+  AndPtrs hp;
+  memset(&hp, 0, sizeof hp);
+  for (int j = 0; j < m; ++j) { hp.X[j] = h->andX[j]; hp.R[j] = h->andR[j]; }
+  const long long n = h->N;
+  const int g = vec_grid(n);
+  const size_t nb = sizeof(double) * (size_t)n;
+  hipStream_t st = h->stream;
+  double* x = h->buf0;
+  double* fx = h->buf1;
+  HIPCHK(h, hipMemcpyAsync(x, w, nb, hipMemcpyDeviceToDevice, st));
+  for (int j = 0; j < m; ++j) HIPCHK(h, hipMemsetAsync(h->andR[j], 0, nb, st));
+  std::vector<double> G((size_t)m * m, 0.0);
+  h->trace.clear();
+  long long it = 0;
+  double err = std::numeric_limits<double>::infinity();
+  int status = 0;
+  const int cvec = h->profiling ? counter_id(h, "anderson_blas1", 0, 0) : -1;
+  while (err > o.tol && it < o.max_iter) {
+    if ((rc = apply_T_dev(h, x, fx, nullptr, nullptr, 0.0))) return rc;
+    const int pos = (int)(it % m);
+    { ProfScope ps(h, cvec);
+      hipLaunchKernelGGL(k_and_push, dim3(g), dim3(VEC_BLOCK), 0, st, x, fx, hp, m, pos, n, h->partial);
+      hipLaunchKernelGGL(k_and_push_finish, dim3(1), dim3(VEC_BLOCK), 0, st, h->partial, g, m, h->gram_row); }
+    HIPCHK(h, hipMemcpyAsync(h->gram_row_host, h->gram_row, sizeof(double) * m, hipMemcpyDeviceToHost, st));
+    HIPCHK(h, hipStreamSynchronize(st));
+    for (int j = 0; j < m; ++j) { G[(size_t)pos * m + j] = h->gram_row_host[j]; G[(size_t)j * m + pos] = h->gram_row_host[j]; }
+    err = std::sqrt(G[(size_t)pos * m + pos]);
+    if (o.record_errors) h->trace.push_back(err);
+    bool mixed = false;
+    if (it + 1 >= m && (it + 1) % o.mixing_freq == 0 && std::isfinite(err)) {
+      const int d = m + 1;
+      std::vector<double> A((size_t)d * d, 0.0), b(d, 0.0);
+      for (int j = 1; j < d; ++j) { A[j] = 1.0; A[(size_t)j * d] = 1.0; }
+      for (int i = 0; i < m; ++i)
+        for (int j = 0; j < m; ++j) A[(size_t)(i + 1) * d + j + 1] = G[(size_t)i * m + j] + (i == j ? o.ridge : 0.0);
+      b[0] = 1.0;
+      if (solve_dense(A, b, d)) {
+        AndCoef c;
+        memset(&c, 0, sizeof c);
+        for (int j = 0; j < m; ++j) c.a[j] = b[j + 1];
+        ProfScope ps(h, cvec);
+        hipLaunchKernelGGL(k_and_mix, dim3(g), dim3(VEC_BLOCK), 0, st, hp, c, m, o.beta, x, n);
+        mixed = true;
+      }
+    }
+    if (!mixed) std::swap(x, fx);
+    ++it;
+    if (!std::isfinite(err)) { status = SDFS_ERR_NUMERIC; break; }
+  }
+  HIPCHK(h, hipGetLastError());
+  HIPCHK(h, hipMemcpyAsync(w, x, nb, hipMemcpyDeviceToDevice, st));
+  HIPCHK(h, hipStreamSynchronize(st));
+  *n_iter = it; *n_apply = it; *final_err = err;
+  if (status) return fail(h, status, "non-finite Anderson residual at iteration %lld", it);
+  return 0;
+}
+
+// ---------------------------------------------------------------------------
+int setup_model(sdfs_handle* h, int model, int ndim, const int64_t* shapes, const double* params, int nparams,
+                const double* const* arrays, const int64_t* sizes, int narrays) {
+  h->model = model; h->ndim = ndim;
+  long long N = 1;
+  for (int a = 0; a < ndim; ++a) {
+    if (shapes[a] < 2) return fail(h, SDFS_ERR_ARG, "shapes[%d] = %lld: every axis needs >= 2 states (Rouwenhorst)", a, (long long)shapes[a]);
+    if (shapes[a] > MAXN) return fail(h, SDFS_ERR_UNSUPPORTED, "shapes[%d] = %lld > %d unsupported", a, (long long)shapes[a], MAXN);
+    h->shape[a] = (int)shapes[a]; N *= shapes[a];
+    h->ax[a].n = h->ax[a].nloc = (int)shapes[a]; h->ax[a].off = 0;
+  }
+  h->N = N;
+  auto need = [&](int i, long long cnt, const char* nm) -> int {
+    if (!arrays[i]) return fail(h, SDFS_ERR_ARG, "arrays[%d] (%s) is NULL", i, nm);
+    if (sizes[i] != cnt) return fail(h, SDFS_ERR_ARG, "arrays[%d] (%s) has %lld elements, expected %lld", i, nm, (long long)sizes[i], cnt);
+    return 0;
+  };
+  int rc;
+  std::vector<double> a1, a2, a3;
+  if (model == SDFS_MODEL_SSY) {
+    if (ndim != 4 || nparams != 13 || narrays != 10) return fail(h, SDFS_ERR_ARG, "SSY needs ndim 4, 13 params, 10 arrays");
+    // params: beta, gamma, psi, mu_c, ...  (ssy_model.py:81)
+    const double beta = params[0], gamma = params[1], psi = params[2], mu_c = params[3];
+    h->beta = beta; h->theta = (1 - gamma) / (1 - 1 / psi);
+    const int nl = h->shape[0], nc = h->shape[1], nz = h->shape[2], nj = h->shape[3];
+    if ((rc = need(0, nl, "h_lam_states")) || (rc = need(1, (long long)nl * nl, "h_lam_Q")) ||
+        (rc = need(2, nc, "h_c_states")) || (rc = need(3, (long long)nc * nc, "h_c_Q")) ||
+        (rc = need(4, nz, "h_z_states")) || (rc = need(5, (long long)nz * nz, "h_z_Q")) ||
+        (rc = need(6, (long long)nz * nj, "z_states")) || (rc = need(7, (long long)nz * nj * nj, "z_Q")) ||
+        (rc = need(8, nc, "sigma_c_states")) || (rc = need(9, nz, "sigma_z_states")))
+      return rc;
+    a1.resize(nl); a2.resize(nc); a3.resize((size_t)nz * nj);
+    for (int l = 0; l < nl; ++l) a1[l] = std::exp(h->theta * arrays[0][l]);                       // ssy_wc_ratio.py:116
+    for (int k = 0; k < nc; ++k) { const double s = (1 - gamma) * arrays[8][k]; a2[k] = std::exp(0.5 * s * s); }   // :120
+    for (size_t i = 0; i < a3.size(); ++i) a3[i] = std::exp((1 - gamma) * (mu_c + arrays[6][i])); // :124
+    const int qi[4] = {1, 3, 5, 7};
+    const char* nm[4] = {"h_lam", "h_c", "h_z", "z"};
+    for (int a = 0; a < 4; ++a) {
+      double* q = nullptr;
+      if ((rc = upload(h, &q, arrays[qi[a]], (size_t)sizes[qi[a]]))) return rc;
+      h->ax[a].Q = q; h->ax[a].qcount = sizes[qi[a]] / ((long long)h->shape[a] * h->shape[a]);
+      strncpy(h->ax[a].name, nm[a], sizeof h->ax[a].name - 1);
+    }
+    h->ax[3].qs[2] = 1;                 // z_Q[i, j, J] conditioned on the current h_z index
+    h->ax[0].a1s = 1;                   // a1[l]
+    h->ax[1].a2s = 1;                   // a2[k]
+    h->ax[2].a3s = nj; h->ax[3].a3s = 1;  // a3[i, j]
+  } else if (model == SDFS_MODEL_GCY) {
+    if (ndim != 6 || nparams != 18 || narrays != 15) return fail(h, SDFS_ERR_ARG, "GCY needs ndim 6, 18 params, 15 arrays");
+    // params: beta, psi, gamma, rho_lam, s_lam, mu_c, ...  (gcy_model.py:72-75)
+    const double beta = params[0], psi = params[1], gamma = params[2], mu_c = params[5];
+    h->beta = beta; h->theta = (1 - gamma) / (1 - 1 / psi);
+    const long long na = h->shape[0], nbp = h->shape[1], nc = h->shape[2], nd = h->shape[3], ne = h->shape[4], nf = h->shape[5];
+    if ((rc = need(0, nbp * nc * ne * na, "z_states")) || (rc = need(1, nbp * nc * ne * na * na, "z_Q")) ||
+        (rc = need(2, ne * nbp, "z_pi_states")) || (rc = need(3, ne * nbp * nbp, "z_pi_Q")) ||
+        (rc = need(4, nc, "h_z_states")) || (rc = need(5, nc * nc, "h_z_Q")) || (rc = need(6, nc, "sigma_z_states")) ||
+        (rc = need(7, nd, "h_c_states")) || (rc = need(8, nd * nd, "h_c_Q")) || (rc = need(9, nd, "sigma_c_states")) ||
+        (rc = need(10, ne, "h_zpi_states")) || (rc = need(11, ne * ne, "h_zpi_Q")) || (rc = need(12, ne, "sigma_zpi_states")) ||
+        (rc = need(13, nf, "h_lam_states")) || (rc = need(14, nf * nf, "h_lam_Q")))
+      return rc;
+    a1.resize(nf); a2.resize(nd); a3.resize((size_t)(nbp * nc * ne * na));
+    for (int f = 0; f < nf; ++f) a1[f] = std::exp(h->theta * arrays[13][f]);                        // gcy_wc_ratio.py:178
+    for (int d = 0; d < nd; ++d) { const double s = (1 - gamma) * arrays[9][d]; a2[d] = std::exp(0.5 * s * s); }   // :182
+    for (size_t i = 0; i < a3.size(); ++i) a3[i] = std::exp((1 - gamma) * (mu_c + arrays[0][i]));   // :186, layout [b,c,e,a]
+    const int qi[6] = {1, 3, 5, 8, 11, 14};
+    const char* nm[6] = {"z", "z_pi", "h_z", "h_c", "h_zpi", "h_lam"};
+    for (int a = 0; a < 6; ++a) {
+      double* q = nullptr;
+      if ((rc = upload(h, &q, arrays[qi[a]], (size_t)sizes[qi[a]]))) return rc;
+      h->ax[a].Q = q; h->ax[a].qcount = sizes[qi[a]] / ((long long)h->shape[a] * h->shape[a]);
+      strncpy(h->ax[a].name, nm[a], sizeof h->ax[a].name - 1);
+    }
+    // z_Q[b, c, e, a, A]: conditioned on current (z_pi, h_z, h_zpi)
+    h->ax[0].qs[1] = (int)(nc * ne); h->ax[0].qs[2] = (int)ne; h->ax[0].qs[4] = 1;
+    // z_pi_Q[e, b, B]: conditioned on current h_zpi
+    h->ax[1].qs[4] = 1;
+    h->ax[5].a1s = 1;                   // a1[f]
+    h->ax[3].a2s = 1;                   // a2[d]
+    h->ax[0].a3s = 1; h->ax[4].a3s = (int)na; h->ax[2].a3s = (int)(ne * na); h->ax[1].a3s = (int)(nc * ne * na);  // a3[b,c,e,a]
+  } else {
+    return fail(h, SDFS_ERR_ARG, "unknown model %d", model);
+  }
+  if (!(h->theta == h->theta) || h->theta == 0.0 || !std::isfinite(h->theta))
+    return fail(h, SDFS_ERR_ARG, "theta = (1-gamma)/(1-1/psi) is not finite / zero");
+  if ((rc = upload(h, &h->a1, a1.data(), a1.size())) || (rc = upload(h, &h->a2, a2.data(), a2.size())) ||
+      (rc = upload(h, &h->a3, a3.data(), a3.size())))
+    return rc;
+  return 0;
+}
+
+int create_common(int model, int ndim, const int64_t* shapes, const double* params, int nparams,
+                  const double* const* arrays, const int64_t* sizes, int narrays, int device_id,
+                  int axis_a, int64_t a_lo, int64_t a_len, int axis_b, int64_t b_lo, int64_t b_len,
+                  sdfs_handle** out) {
+  if (!out) return fail(nullptr, SDFS_ERR_ARG, "out is NULL");
+  *out = nullptr;
+  if (!shapes || !params || !arrays || !sizes) return fail(nullptr, SDFS_ERR_ARG, "NULL argument");
+  if (ndim < 1 || ndim > MAXD) return fail(nullptr, SDFS_ERR_ARG, "ndim %d out of range", ndim);
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+    return fail(nullptr, SDFS_ERR_HIP, "no HIP device available (libsdfs_hip has no CPU fallback)");
+  if (device_id < 0 || device_id >= ndev) return fail(nullptr, SDFS_ERR_ARG, "device_id %d out of range (%d devices)", device_id, ndev);
+  sdfs_handle* h = new sdfs_handle();
+  memset(&h->counters, 0, sizeof h->counters);
+  h->device = device_id;
+  auto bail = [&](int rc) { g_create_error = h->err; sdfs_destroy(h); return rc; };
+  if (hipSetDevice(device_id) != hipSuccess) return bail(fail(h, SDFS_ERR_HIP, "hipSetDevice(%d) failed", device_id));
+  if (hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking) != hipSuccess)
+    return bail(fail(h, SDFS_ERR_HIP, "hipStreamCreate failed"));
+  h->stream = h->own_stream;
+  int rc = setup_model(h, model, ndim, shapes, params, nparams, arrays, sizes, narrays);
+  if (rc) return bail(rc);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute((const void*)pass_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
+    attr_set = true;
+  }
+  std::vector<int> all;
+  for (int a = 0; a < ndim; ++a) all.push_back(a);
+  if (axis_a < 0) {
+    rc = build_plan(h, h->plan[0], all, std::vector<bool>(ndim, false));
+    if (rc) return bail(rc);
+  } else {
+    if (axis_a >= ndim || axis_b < 0 || axis_b >= ndim || axis_a == axis_b)
+      return bail(fail(h, SDFS_ERR_ARG, "bad shard axes %d / %d", axis_a, axis_b));
+    for (int g = 0; g < ndim; ++g)
+      if (h->ax[g].qs[axis_a] != 0 || h->ax[g].qs[axis_b] != 0 )
+        return bail(fail(h, SDFS_ERR_ARG, "shard axes must not condition any transition matrix"));
+    for (int c = 0; c < ndim; ++c)
+      if (h->ax[axis_a].qs[c] != 0) return bail(fail(h, SDFS_ERR_ARG, "shard axis A must be unconditional"));
+    if (a_lo < 0 || a_len < 1 || a_lo + a_len > h->shape[axis_a] || b_lo < 0 || b_len < 1 || b_lo + b_len > h->shape[axis_b])
+      return bail(fail(h, SDFS_ERR_ARG, "shard block out of range"));
+    h->sharded = true; h->axis_a = axis_a; h->axis_b = axis_b;
+    // stage 0: input sharded on A; contract everything but A
+    h->ax[axis_a].nloc = (int)a_len; h->ax[axis_a].off = (int)a_lo;
+    std::vector<int> s0;
+    for (int a = 0; a < ndim; ++a) if (a != axis_a) s0.push_back(a);
+    rc = build_plan(h, h->plan[0], s0, std::vector<bool>(ndim, false));
+    if (rc) return bail(rc);
+    // stage 1: data re-sharded on B; contract A
+    h->ax[axis_a].nloc = h->ax[axis_a].n; h->ax[axis_a].off = 0;
+    h->ax[axis_b].nloc = (int)b_len; h->ax[axis_b].off = (int)b_lo;
+    std::vector<bool> done(ndim, true); done[axis_a] = false;
+    rc = build_plan(h, h->plan[1], std::vector<int>{axis_a}, done);
+    h->ax[axis_b].nloc = h->ax[axis_b].n; h->ax[axis_b].off = 0;
+    if (rc) return bail(rc);
+  }
+  *out = h;
+  return 0;
+}
+
+int check(sdfs_handle* h) {
+  if (!h) return SDFS_ERR_ARG;
+  if (hipSetDevice(h->device) != hipSuccess) return fail(h, SDFS_ERR_HIP, "hipSetDevice failed");
+  return 0;
+}
+
+}  // namespace
+
+// ===========================================================================
+extern "C" {
+
+int sdfs_create(int model, int ndim, const int64_t* shapes, const double* params, int nparams,
+                const double* const* arrays, const int64_t* array_sizes, int narrays, int device_id,
+                sdfs_handle** out) {
+  return create_common(model, ndim, shapes, params, nparams, arrays, array_sizes, narrays, device_id,
+                       -1, 0, 0, -1, 0, 0, out);
+}
+
+int sdfs_create_sharded(int model, int ndim, const int64_t* shapes, const double* params, int nparams,
+                        const double* const* arrays, const int64_t* array_sizes, int narrays, int device_id,
+                        int axis_a, int64_t a_lo, int64_t a_len, int axis_b, int64_t b_lo, int64_t b_len,
+                        sdfs_handle** out) {
+  if (axis_a < 0) return fail(nullptr, SDFS_ERR_ARG, "axis_a must be >= 0");
+  return create_common(model, ndim, shapes, params, nparams, arrays, array_sizes, narrays, device_id,
+                       axis_a, a_lo, a_len, axis_b, b_lo, b_len, out);
+}
+
+void sdfs_destroy(sdfs_handle* h) {
+  if (!h) return;
+  hipSetDevice(h->device);
+  if (h->stream) hipStreamSynchronize(h->stream);
+  if (h->sa_graph) hipGraphExecDestroy(h->sa_graph);
+  for (double* p : h->dev_allocs) hipFree(p);
+  if (h->slots) hipFree(h->slots);
+  if (h->slots_host) hipHostFree(h->slots_host);
+  if (h->sc_host) hipHostFree(h->sc_host);
+  if (h->gram_row_host) hipHostFree(h->gram_row_host);
+  for (auto& p : h->pending) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
+  for (auto e : h->event_pool) hipEventDestroy(e);
+  if (h->own_stream) hipStreamDestroy(h->own_stream);
+  delete h;
+}
+
+const char* sdfs_last_error(const sdfs_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int sdfs_default_opts(sdfs_opts* o) {
+  if (!o) return SDFS_ERR_ARG;
+  memset(o, 0, sizeof *o);
+  o->tol = 1e-7;               // code/solvers.py:16
+  o->max_iter = 1000000;       // code/solvers.py:17
+  o->inner_rtol = 1e-5;        // jax bicgstab default tol
+  o->inner_atol = 1e-4;        // code/solvers.py:55
+  o->inner_max_iter = 0;
+  o->history = 10; o->mixing_freq = 4; o->beta = 8.0; o->ridge = 1e-6;   // code/solvers.py:104-114
+  o->check_every = 32;
+  o->use_graph = 1;
+  o->record_errors = 0;
+  return 0;
+}
+
+int64_t sdfs_grid_size(const sdfs_handle* h) { return h ? h->N : -1; }
+
+int sdfs_set_stream(sdfs_handle* h, void* s) {
+  int rc = check(h); if (rc) return rc;
+  hipStream_t ns = s ? (hipStream_t)s : h->own_stream;
+  if (ns != h->stream && h->sa_graph) { hipGraphExecDestroy(h->sa_graph); h->sa_graph = nullptr; }
+  h->stream = ns;
+  return 0;
+}
+
+int sdfs_synchronize(sdfs_handle* h) {
+  int rc = check(h); if (rc) return rc;
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+int sdfs_apply_T_dev(sdfs_handle* h, const double* w, double* Tw, double* resid_dev) {
+  int rc = check(h); if (rc) return rc;
+  if (!w || !Tw) return fail(h, SDFS_ERR_ARG, "NULL grid pointer");
+  if (h->sharded) return fail(h, SDFS_ERR_ARG, "sharded handle: use sdfs_apply_stage_dev");
+  if (resid_dev) HIPCHK(h, hipMemsetAsync(resid_dev, 0, 8, h->stream));
+  return apply_T_dev(h, w, Tw, (unsigned long long*)resid_dev, nullptr, 0.0);
+}
+
+int sdfs_apply_T(sdfs_handle* h, const double* w_host, double* Tw_host) {
+  int rc = check(h); if (rc) return rc;
+  if (!w_host || !Tw_host) return fail(h, SDFS_ERR_ARG, "NULL host pointer");
+  if (h->sharded) return fail(h, SDFS_ERR_ARG, "sharded handle: use sdfs_apply_stage_dev");
+  if ((rc = ensure_buf(h, &h->hostio)) || (rc = ensure_buf(h, &h->hostio2)) || (rc = ensure_slots(h, 2))) return rc;
+  const size_t nb = sizeof(double) * (size_t)h->N;
+  HIPCHK(h, hipMemcpyAsync(h->hostio, w_host, nb, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipMemsetAsync(h->slots, 0, 8, h->stream));
+  if ((rc = apply_T_dev(h, h->hostio, h->hostio2, h->slots, nullptr, 0.0))) return rc;
+  HIPCHK(h, hipMemcpyAsync(Tw_host, h->hostio2, nb, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipMemcpyAsync(h->slots_host, h->slots, 8, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  h->last_resid = bits_to_double(h->slots_host[0]);
+  return 0;
+}
+
+int sdfs_linearize_dev(sdfs_handle* h, const double* w, double* Tw) {
+  int rc = check(h); if (rc) return rc;
+  if (!w) return fail(h, SDFS_ERR_ARG, "NULL grid pointer");
+  if (h->sharded) return fail(h, SDFS_ERR_ARG, "sharded handle: use sdfs_apply_stage_dev");
+  double* out = Tw;
+  if (!out) { if ((rc = ensure_buf(h, &h->hostio3))) return rc; out = h->hostio3; }
+  return run_plan(h, h->plan[0], MODE_T_LIN, true, true, w, out, w, nullptr, nullptr, 0.0, 0);
+}
+
+int sdfs_apply_jvp_dev(sdfs_handle* h, const double* v, double* out, int minus_identity) {
+  int rc = check(h); if (rc) return rc;
+  if (!v || !out) return fail(h, SDFS_ERR_ARG, "NULL grid pointer");
+  if (h->sharded) return fail(h, SDFS_ERR_ARG, "sharded handle: use sdfs_apply_stage_dev");
+  if (!h->c1 || !h->c2) return fail(h, SDFS_ERR_ARG, "sdfs_apply_jvp_dev before sdfs_linearize_dev");
+  return run_plan(h, h->plan[0], MODE_JVP, true, true, v, out, v, nullptr, nullptr, 0.0, minus_identity);
+}
+
+int sdfs_apply_jvp(sdfs_handle* h, const double* w_host, const double* v_host, double* out_host) {
+  int rc = check(h); if (rc) return rc;
+  if (!w_host || !v_host || !out_host) return fail(h, SDFS_ERR_ARG, "NULL host pointer");
+  if ((rc = ensure_buf(h, &h->hostio)) || (rc = ensure_buf(h, &h->hostio2)) || (rc = ensure_buf(h, &h->hostio3))) return rc;
+  const size_t nb = sizeof(double) * (size_t)h->N;
+  HIPCHK(h, hipMemcpyAsync(h->hostio, w_host, nb, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipMemcpyAsync(h->hostio2, v_host, nb, hipMemcpyHostToDevice, h->stream));
+  if ((rc = sdfs_linearize_dev(h, h->hostio, h->hostio3))) return rc;
+  if ((rc = sdfs_apply_jvp_dev(h, h->hostio2, h->hostio3, 0))) return rc;
+  HIPCHK(h, hipMemcpyAsync(out_host, h->hostio3, nb, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+int sdfs_residual(sdfs_handle* h, double* sup_norm) {
+  if (!h || !sup_norm) return SDFS_ERR_ARG;
+  *sup_norm = h->last_resid;
+  return 0;
+}
+
+int sdfs_solve_dev(sdfs_handle* h, int algo, const sdfs_opts* opts, double* w, int64_t* n_iter,
+                   int64_t* n_apply, double* final_err) {
+  int rc = check(h); if (rc) return rc;
+  if (!w || !n_iter || !n_apply || !final_err) return fail(h, SDFS_ERR_ARG, "NULL argument");
+  if (h->sharded) return fail(h, SDFS_ERR_ARG, "sharded handle: the multi-GPU loop lives in the host layer");
+  sdfs_opts o;
+  if (opts) o = *opts; else sdfs_default_opts(&o);
+  if (o.check_every < 1) o.check_every = 1;
+  if (o.max_iter < 0) return fail(h, SDFS_ERR_ARG, "max_iter < 0");
+  switch (algo) {
+    case SDFS_ALGO_SA: return solve_sa(h, o, w, n_iter, n_apply, final_err);
+    case SDFS_ALGO_NEWTON: return solve_newton(h, o, w, n_iter, n_apply, final_err);
+    case SDFS_ALGO_ANDERSON: return solve_anderson(h, o, w, n_iter, n_apply, final_err);
+    default: return fail(h, SDFS_ERR_ARG, "unknown algorithm %d", algo);
+  }
+}
+
+int sdfs_solve(sdfs_handle* h, int algo, const sdfs_opts* opts, double* w_host, int64_t* n_iter,
+               int64_t* n_apply, double* final_err) {
+  int rc = check(h); if (rc) return rc;
+  if (!w_host) return fail(h, SDFS_ERR_ARG, "NULL host pointer");
+  if ((rc = ensure_buf(h, &h->hostio))) return rc;
+  const size_t nb = sizeof(double) * (size_t)h->N;
+  HIPCHK(h, hipMemcpyAsync(h->hostio, w_host, nb, hipMemcpyHostToDevice, h->stream));
+  rc = sdfs_solve_dev(h, algo, opts, h->hostio, n_iter, n_apply, final_err);
+  if (rc && rc != SDFS_ERR_NUMERIC) return rc;
+  hipError_t e = hipMemcpyAsync(w_host, h->hostio, nb, hipMemcpyDeviceToHost, h->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+  if (e != hipSuccess) return fail(h, SDFS_ERR_HIP, "copy back failed: %s", hipGetErrorString(e));
+  return rc;
+}
+
+int64_t sdfs_error_trace(sdfs_handle* h, double* out, int64_t cap) {
+  if (!h) return -1;
+  const int64_t n = (int64_t)h->trace.size();
+  if (out) for (int64_t i = 0; i < std::min(n, cap); ++i) out[i] = h->trace[i];
+  return n;
+}
+
+int sdfs_apply_stage_dev(sdfs_handle* h, int stage, int mode, const double* in, double* out,
+                         const double* old, double* resid_dev) {
+  int rc = check(h); if (rc) return rc;
+  if (!h->sharded) return fail(h, SDFS_ERR_ARG, "not a sharded handle");
+  if (stage < 0 || stage > 1 || mode < 0 || mode > 2) return fail(h, SDFS_ERR_ARG, "bad stage/mode");
+  if (!in || !out) return fail(h, SDFS_ERR_ARG, "NULL grid pointer");
+  if (resid_dev && stage == 1) HIPCHK(h, hipMemsetAsync(resid_dev, 0, 8, h->stream));
+  return run_plan(h, h->plan[stage], mode, stage == 0, stage == 1, in, out, old,
+                  stage == 1 ? (unsigned long long*)resid_dev : nullptr, nullptr, 0.0,
+                  (mode == MODE_JVP && old) ? 1 : 0);
+}
+
+int sdfs_set_profiling(sdfs_handle* h, int on) {
+  if (!h) return SDFS_ERR_ARG;
+  int rc = drain_events(h); if (rc) return rc;
+  h->profiling = on != 0;
+  return 0;
+}
+
+int sdfs_reset_counters(sdfs_handle* h) {
+  if (!h) return SDFS_ERR_ARG;
+  int rc = drain_events(h); if (rc) return rc;
+  for (int i = 0; i < h->counters.nkernels; ++i) { h->counters.k[i].launches = 0; h->counters.k[i].total_ms = 0; }
+  return 0;
+}
+
+int sdfs_get_counters(sdfs_handle* h, sdfs_counters* out) {
+  if (!h || !out) return SDFS_ERR_ARG;
+  int rc = check(h); if (rc) return rc;
+  if ((rc = drain_events(h))) return rc;
+  *out = h->counters;
+  return 0;
+}
+
+int sdfs_describe_plan(const sdfs_handle* h, char* buf, int64_t cap) {
+  if (!h || !buf || cap < 1) return SDFS_ERR_ARG;
+  std::string s;
+  char line[256];
+  for (int st = 0; st < 2; ++st) {
+    const Plan& pl = h->plan[st];
+    for (size_t i = 0; i < pl.passes.size(); ++i) {
+      const Pass& P = pl.passes[i];
+      snprintf(line, sizeof line, "stage %d pass %zu: %s tile %dx%dx%d lds %zu B block %d tiles %lld\n", st, i,
+               P.label.c_str(), P.d.m[0], P.d.m[1], P.d.m[2], P.lds_bytes, P.block, P.d.ntiles);
+      s += line;
+    }
+  }
+  snprintf(buf, (size_t)cap, "%s", s.c_str());
+  return 0;
+}
+
+}  // extern "C"

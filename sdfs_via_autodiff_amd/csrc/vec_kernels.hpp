@@ -1,0 +1,298 @@
+// vec_kernels.hpp -- fused BLAS-1 kernels for the Krylov / Anderson loops.
+//
+// They replace the vector arithmetic that jax.scipy.sparse.linalg.bicgstab
+// (called at code/solvers.py:91-93) and jaxopt.AndersonAcceleration
+// (code/solvers.py:104-114) generate through XLA.  All are HBM-bound streams:
+// 16-byte accesses, grid-stride, wave-shuffle + LDS reductions, deterministic
+// two-stage sums (per-block partials, then one finishing block that also does the
+// scalar recurrences so no scalar ever round-trips to the host inside an iteration).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace sdfs {
+
+constexpr int VEC_BLOCK = 256;
+constexpr int MAX_PARTIAL_BLOCKS = 1024;
+
+// device scalar block of the BiCGSTAB recurrence
+enum {
+  SC_RHO = 0, SC_ALPHA, SC_OMEGA, SC_RHO_NEW, SC_BETA, SC_RHAT_Q, SC_SS, SC_TS, SC_TT,
+  SC_RR, SC_BB, SC_ATOL2, SC_EARLY, SC_BREAK, SC_STEPMAX, SC_COUNT = 16
+};
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
+  return v;
+}
+
+// block-level sum of up to NV values per thread -> partial[blockIdx.x + k*gridDim.x]
+template <int NV>
+__device__ __forceinline__ void block_partials(const double (&v)[NV], double* __restrict__ partial) {
+  __shared__ double sm[NV][VEC_BLOCK / 64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    const double s = wave_sum(v[k]);
+    if (lane == 0) sm[k][wave] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      double s = 0.0;
+      for (int w = 0; w < VEC_BLOCK / 64; ++w) s += sm[k][w];
+      partial[blockIdx.x + (size_t)k * gridDim.x] = s;
+    }
+  }
+}
+
+// sum `nb` partials of stream k inside ONE block (finishing kernels)
+__device__ __forceinline__ double finish_sum(const double* __restrict__ partial, int nb, int k) {
+  __shared__ double sm[VEC_BLOCK / 64];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < nb; i += blockDim.x) s += partial[i + (size_t)k * nb];
+  s = wave_sum(s);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = s;
+  __syncthreads();
+  double t = 0.0;
+  for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += sm[w];
+  return t;
+}
+
+// ---- generic helpers --------------------------------------------------------
+// out = a - b ; partial sums of out.out ; block max of |out| folded into stepmax (optional)
+__global__ void __launch_bounds__(VEC_BLOCK)
+k_sub_dot(const double* __restrict__ a, const double* __restrict__ b, double* __restrict__ out,
+          long long n, double* __restrict__ partial) {
+  double acc[1] = {0.0};
+  for (long long i = (long long)blockIdx.x * VEC_BLOCK + threadIdx.x; i < n;
+       i += (long long)gridDim.x * VEC_BLOCK) {
+    const double d = a[i] - b[i];
+    out[i] = d;
+    acc[0] += d * d;
+  }
+  block_partials<1>(acc, partial);
+}
+
+// BiCGSTAB start: r = rhat = p = q = b (x0 = 0, so r0 = b); x = 0; partial sums of <b,b>
+__global__ void __launch_bounds__(VEC_BLOCK)
+k_bicg_init(const double* __restrict__ b, double* __restrict__ r, double* __restrict__ rhat,
+            double* __restrict__ p, double* __restrict__ q, double* __restrict__ x, long long n) {
+  for (long long i = (long long)blockIdx.x * VEC_BLOCK + threadIdx.x; i < n;
+       i += (long long)gridDim.x * VEC_BLOCK) {
+    const double v = b[i];
+    r[i] = v; rhat[i] = v; p[i] = v; q[i] = v; x[i] = 0.0;
+  }
+}
+
+// one block: bb = sum(partials); atol2 = max(rtol^2 bb, atol^2); rho=alpha=omega=1;
+// rho_new = <rhat, r> = bb; beta = rho_new/rho * alpha/omega; rr = bb
+__global__ void __launch_bounds__(VEC_BLOCK)
+k_bicg_init_finish(const double* __restrict__ partial, int nb, double* __restrict__ sc,
+                   double rtol, double atol) {
+  const double bb = finish_sum(partial, nb, 0);
+  if (threadIdx.x == 0) {
+    sc[SC_BB] = bb;
+    sc[SC_ATOL2] = fmax(rtol * rtol * bb, atol * atol);
+    sc[SC_RHO] = 1.0; sc[SC_ALPHA] = 1.0; sc[SC_OMEGA] = 1.0;
+    sc[SC_RHO_NEW] = bb;
+    sc[SC_BETA] = bb;            // rho_new / 1 * 1 / 1
+    sc[SC_RR] = bb;
+    sc[SC_EARLY] = 0.0; sc[SC_BREAK] = 0.0;
+  }
+}
+
+// p = r + beta (p - omega q)
+__global__ void __launch_bounds__(VEC_BLOCK)
+k_bicg_update_p(const double* __restrict__ r, double* __restrict__ p, const double* __restrict__ q,
+                long long n, const double* __restrict__ sc) {
+  const double beta = sc[SC_BETA], omega = sc[SC_OMEGA];
+  for (long long i = (long long)blockIdx.x * VEC_BLOCK + threadIdx.x; i < n;
+       i += (long long)gridDim.x * VEC_BLOCK) {
+    p[i] = r[i] + beta * (p[i] - omega * q[i]);
+  }
+}
+
+// partial sums of <a, b>
+__global__ void __launch_bounds__(VEC_BLOCK)
+k_dot(const double* __restrict__ a, const double* __restrict__ b, long long n,
+      double* __restrict__ partial) {
+  double acc[1] = {0.0};
+  for (long long i = (long long)blockIdx.x * VEC_BLOCK + threadIdx.x; i < n;
+       i += (long long)gridDim.x * VEC_BLOCK)
+    acc[0] += a[i] * b[i];
+  block_partials<1>(acc, partial);
+}
+
+// alpha = rho_new / <rhat, q>
+__global__ void __launch_bounds__(VEC_BLOCK)
+k_bicg_alpha_finish(const double* __restrict__ partial, int nb, double* __restrict__ sc) {
+  const double d = finish_sum(partial, nb, 0);
+  if (threadIdx.x == 0) { sc[SC_RHAT_Q] = d; sc[SC_ALPHA] = sc[SC_RHO_NEW] / d; }
+}
+
+// s = r - alpha q (in place in r); partial sums of <s,s>
+__global__ void __launch_bounds__(VEC_BLOCK)
+k_bicg_s(double* __restrict__ r, const double* __restrict__ q, long long n,
+         const double* __restrict__ sc, double* __restrict__ partial) {
+  const double alpha = sc[SC_ALPHA];
+  double acc[1] = {0.0};
+  for (long long i = (long long)blockIdx.x * VEC_BLOCK + threadIdx.x; i < n;
+       i += (long long)gridDim.x * VEC_BLOCK) {
+    const double s = r[i] - alpha * q[i];
+    r[i] = s;
+    acc[0] += s * s;
+  }
+  block_partials<1>(acc, partial);
+}
+
+__global__ void __launch_bounds__(VEC_BLOCK)
+k_bicg_s_finish(const double* __restrict__ partial, int nb, double* __restrict__ sc) {
+  const double ss = finish_sum(partial, nb, 0);
+  if (threadIdx.x == 0) { sc[SC_SS] = ss; sc[SC_EARLY] = (ss < sc[SC_ATOL2]) ? 1.0 : 0.0; }
+}
+
+// partial sums of <t,s> and <t,t>
+__global__ void __launch_bounds__(VEC_BLOCK)
+k_dot2(const double* __restrict__ t, const double* __restrict__ s, long long n,
+       double* __restrict__ partial) {
+  double acc[2] = {0.0, 0.0};
+  for (long long i = (long long)blockIdx.x * VEC_BLOCK + threadIdx.x; i < n;
+       i += (long long)gridDim.x * VEC_BLOCK) {
+    const double tv = t[i];
+    acc[0] += tv * s[i];
+    acc[1] += tv * tv;
+  }
+  block_partials<2>(acc, partial);
+}
+
+__global__ void __launch_bounds__(VEC_BLOCK)
+k_bicg_omega_finish(const double* __restrict__ partial, int nb, double* __restrict__ sc) {
+  const double ts = finish_sum(partial, nb, 0);
+  const double tt = finish_sum(partial, nb, 1);
+  if (threadIdx.x == 0) { sc[SC_TS] = ts; sc[SC_TT] = tt; sc[SC_OMEGA] = ts / tt; }
+}
+
+// x += alpha p (+ omega s);  r = s (- omega t);  partial sums of <r,r>, <rhat,r>
+// (`s` lives in r on entry.)  early = s already below tolerance (JAX's exit_early select).
+__global__ void __launch_bounds__(VEC_BLOCK)
+k_bicg_update_xr(double* __restrict__ x, double* __restrict__ r, const double* __restrict__ p,
+                 const double* __restrict__ t, const double* __restrict__ rhat, long long n,
+                 const double* __restrict__ sc, double* __restrict__ partial) {
+  const double alpha = sc[SC_ALPHA];
+  const bool early = sc[SC_EARLY] != 0.0;
+  const double omega = early ? 0.0 : sc[SC_OMEGA];
+  double acc[2] = {0.0, 0.0};
+  for (long long i = (long long)blockIdx.x * VEC_BLOCK + threadIdx.x; i < n;
+       i += (long long)gridDim.x * VEC_BLOCK) {
+    const double s = r[i];
+    const double rn = early ? s : s - omega * t[i];
+    x[i] += alpha * p[i] + omega * s;
+    r[i] = rn;
+    acc[0] += rn * rn;
+    acc[1] += rhat[i] * rn;
+  }
+  block_partials<2>(acc, partial);
+}
+
+// rr, next rho/beta and JAX's breakdown flags (k = -10 / -11 in its while_loop)
+__global__ void __launch_bounds__(VEC_BLOCK)
+k_bicg_iter_finish(const double* __restrict__ partial, int nb, double* __restrict__ sc) {
+  const double rr = finish_sum(partial, nb, 0);
+  const double rho_next = finish_sum(partial, nb, 1);
+  if (threadIdx.x == 0) {
+    const double rho_new = sc[SC_RHO_NEW], alpha = sc[SC_ALPHA], omega = sc[SC_OMEGA];
+    double brk = 0.0;
+    if (omega == 0.0 || alpha == 0.0) brk = 11.0;
+    if (rho_new == 0.0) brk = 10.0;
+    sc[SC_BREAK] = brk;
+    sc[SC_RR] = rr;
+    sc[SC_RHO] = rho_new;
+    sc[SC_RHO_NEW] = rho_next;
+    sc[SC_BETA] = rho_next / rho_new * alpha / omega;
+  }
+}
+
+// Newton update: x_new = x - step ; stepmax = max|step| (bits, atomicMax)
+__global__ void __launch_bounds__(VEC_BLOCK)
+k_newton_update(const double* __restrict__ x, const double* __restrict__ step,
+                double* __restrict__ xnew, long long n, unsigned long long* __restrict__ stepmax) {
+  __shared__ double sm[VEC_BLOCK / 64];
+  double mx = 0.0;
+  for (long long i = (long long)blockIdx.x * VEC_BLOCK + threadIdx.x; i < n;
+       i += (long long)gridDim.x * VEC_BLOCK) {
+    const double st = step[i];
+    xnew[i] = x[i] - st;
+    double a = fabs(st);
+    if (!(a == a)) a = __longlong_as_double(0x7ff0000000000000LL);
+    mx = fmax(mx, a);
+  }
+  mx = wave_max(mx);
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = mx;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < VEC_BLOCK / 64; ++w) mx = fmax(mx, sm[w]);
+    atomicMax(stepmax, (unsigned long long)__double_as_longlong(mx));
+  }
+}
+
+// ---- Anderson ---------------------------------------------------------------
+// r = fx - x stored into R[pos]; X[pos] = x; partial sums of <r, R[j]> for j < m
+// (row `pos` of the Gram matrix; R[pos] itself is the fresh r).
+constexpr int AND_MAX_M = 16;
+struct AndPtrs { double* X[AND_MAX_M]; double* R[AND_MAX_M]; };
+
+__global__ void __launch_bounds__(VEC_BLOCK)
+k_and_push(const double* __restrict__ x, const double* __restrict__ fx, AndPtrs h, int m, int pos,
+           long long n, double* __restrict__ partial) {
+  double acc[AND_MAX_M];
+#pragma unroll
+  for (int j = 0; j < AND_MAX_M; ++j) acc[j] = 0.0;
+  for (long long i = (long long)blockIdx.x * VEC_BLOCK + threadIdx.x; i < n;
+       i += (long long)gridDim.x * VEC_BLOCK) {
+    const double xv = x[i];
+    const double r = fx[i] - xv;
+    h.X[pos][i] = xv;
+    h.R[pos][i] = r;
+#pragma unroll
+    for (int j = 0; j < AND_MAX_M; ++j) {
+      if (j < m) acc[j] += r * ((j == pos) ? r : h.R[j][i]);
+    }
+  }
+  block_partials<AND_MAX_M>(acc, partial);
+}
+
+// one block: gram_row[j] = sum of partial stream j
+__global__ void __launch_bounds__(VEC_BLOCK)
+k_and_push_finish(const double* __restrict__ partial, int nb, int m, double* __restrict__ gram_row) {
+  for (int j = 0; j < m; ++j) {
+    const double s = finish_sum(partial, nb, j);
+    if (threadIdx.x == 0) gram_row[j] = s;
+    __syncthreads();
+  }
+}
+
+struct AndCoef { double a[AND_MAX_M]; };
+// x_next = sum_j alpha_j (X[j] + beta R[j])
+__global__ void __launch_bounds__(VEC_BLOCK)
+k_and_mix(AndPtrs h, AndCoef c, int m, double beta, double* __restrict__ xnext, long long n) {
+  for (long long i = (long long)blockIdx.x * VEC_BLOCK + threadIdx.x; i < n;
+       i += (long long)gridDim.x * VEC_BLOCK) {
+    double xa = 0.0, ra = 0.0;
+#pragma unroll
+    for (int j = 0; j < AND_MAX_M; ++j) {
+      if (j < m) { xa += c.a[j] * h.X[j][i]; ra += c.a[j] * h.R[j][i]; }
+    }
+    xnext[i] = xa + beta * ra;
+  }
+}
+
+}  // namespace sdfs

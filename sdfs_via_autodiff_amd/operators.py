@@ -1,0 +1,192 @@
+"""
+The discretised Koopmans operator T w = 1 + β (H w^θ)^(1/θ) on MI355X.
+
+Mirrors the reference's call shapes:
+  T_ssy(w, shapes, params, arrays)  -- code/ssy/discrete/ssy_wc_ratio.py:82-151
+  T_gcy(w, shapes, params, arrays)  -- code/gcy/discrete/gcy_wc_ratio.py:134-238
+and the closure the drivers build from them, ``T = lambda w: T_ssy(w, shapes, params, arrays)``
+(ssy_wc_ratio.py:230, gcy_wc_ratio.py:333).
+
+``KoopmansOperator`` is that closure as an object: ``T(w)`` applies the operator,
+``T.jvp(w, v)`` is the directional derivative jax.jvp gives the reference
+(code/solvers.py:87), and ``sdfs_via_autodiff_amd.solvers`` recognises it and runs
+the whole fixed-point loop on the device instead of calling back per iteration.
+All arithmetic happens in libsdfs_hip.so (hand-written HIP, gfx950); nothing here
+computes on the CPU.
+"""
+import ctypes as C
+import weakref
+
+import numpy as np
+
+from . import _lib
+from ._lib import lib, check
+
+
+def _as_f64(a):
+    return np.ascontiguousarray(np.asarray(a, dtype=np.float64))
+
+
+class KoopmansOperator:
+    """Device-resident operator for one (model, shapes, params, arrays)."""
+
+    def __init__(self, model, shapes, params, arrays, device=0):
+        self.model = {"ssy": _lib.SDFS_MODEL_SSY, "gcy": _lib.SDFS_MODEL_GCY}[model]
+        self.model_name = model
+        self.shapes = tuple(int(s) for s in shapes)
+        self.params = tuple(float(p) for p in params)
+        self._arrays = [_as_f64(a) for a in arrays]
+        self.device = int(device)
+        nd = len(self.shapes)
+        shp = (C.c_int64 * nd)(*self.shapes)
+        par = (C.c_double * len(self.params))(*self.params)
+        ptrs = (C.POINTER(C.c_double) * len(self._arrays))(
+            *[a.ctypes.data_as(C.POINTER(C.c_double)) for a in self._arrays])
+        sizes = (C.c_int64 * len(self._arrays))(*[a.size for a in self._arrays])
+        h = C.c_void_p()
+        rc = lib.sdfs_create(self.model, nd, shp, par, len(self.params), ptrs, sizes,
+                             len(self._arrays), self.device, C.byref(h))
+        if rc != 0:
+            raise _lib.SdfsError(f"sdfs_create failed ({rc}): {_lib.last_error(None)}")
+        self._h = h
+        self._finalizer = weakref.finalize(self, lib.sdfs_destroy, h)
+        self.size = int(lib.sdfs_grid_size(h))
+
+    # -- handle plumbing ------------------------------------------------------
+    @property
+    def handle(self):
+        return self._h
+
+    def close(self):
+        self._finalizer()
+
+    def describe_plan(self):
+        buf = C.create_string_buffer(4096)
+        check(lib.sdfs_describe_plan(self._h, buf, len(buf)), self._h)
+        return buf.value.decode()
+
+    def _host_in(self, w, name="w"):
+        w = _as_f64(w)
+        if w.shape != self.shapes:
+            raise ValueError(f"{name} has shape {w.shape}, operator grid is {self.shapes}")
+        return w
+
+    # -- the reference's call shapes -----------------------------------------
+    def __call__(self, w):
+        """Tw = T(w); host ndarray in, new host ndarray out (inputs never mutated)."""
+        w = self._host_in(w)
+        out = np.empty_like(w)
+        check(lib.sdfs_apply_T(self._h, w.ctypes.data, out.ctypes.data), self._h)
+        return out
+
+    def jvp(self, w, v):
+        """dT(w)[v] -- what jax.jvp(T, (w,), (v,))[1] returns in the reference."""
+        w = self._host_in(w)
+        v = self._host_in(v, "v")
+        out = np.empty_like(w)
+        check(lib.sdfs_apply_jvp(self._h, w.ctypes.data, v.ctypes.data, out.ctypes.data), self._h)
+        return out
+
+    def residual(self):
+        """max|T(w) - w| of the most recent ``T(w)`` call."""
+        r = C.c_double()
+        check(lib.sdfs_residual(self._h, C.byref(r)), self._h)
+        return r.value
+
+    # -- device-pointer forms (torch tensors / raw pointers) ------------------
+    def apply_dev(self, w_ptr, out_ptr, resid_ptr=None):
+        check(lib.sdfs_apply_T_dev(self._h, w_ptr, out_ptr, resid_ptr), self._h)
+
+    def linearize_dev(self, w_ptr, out_ptr=None):
+        check(lib.sdfs_linearize_dev(self._h, w_ptr, out_ptr), self._h)
+
+    def jvp_dev(self, v_ptr, out_ptr, minus_identity=False):
+        check(lib.sdfs_apply_jvp_dev(self._h, v_ptr, out_ptr, int(minus_identity)), self._h)
+
+    def synchronize(self):
+        check(lib.sdfs_synchronize(self._h), self._h)
+
+    def set_stream(self, stream_ptr):
+        check(lib.sdfs_set_stream(self._h, stream_ptr), self._h)
+
+    # -- device-resident solve --------------------------------------------------
+    def solve(self, x_init, algorithm="successive_approx", record_errors=False, **kw):
+        """Run the whole fixed-point iteration on the GPU.  Returns
+        (x_star, n_iter, info) with info = dict(n_apply, final_err, errors, status)."""
+        algo = {"successive_approx": _lib.SDFS_ALGO_SA, "newton": _lib.SDFS_ALGO_NEWTON,
+                "anderson": _lib.SDFS_ALGO_ANDERSON}[algorithm]
+        o = _lib.default_opts()
+        if algorithm == "anderson":
+            o.max_iter = 10000               # code/solvers.py:101
+        for k, v in kw.items():
+            if v is None:
+                continue
+            if not hasattr(o, k):
+                raise TypeError(f"unknown solver option {k!r}")
+            setattr(o, k, type(getattr(o, k))(v))
+        o.record_errors = int(record_errors)
+        x = self._host_in(x_init, "x_init").copy()
+        n_iter, n_apply, err = C.c_int64(), C.c_int64(), C.c_double()
+        rc = lib.sdfs_solve(self._h, algo, C.byref(o), x.ctypes.data, C.byref(n_iter),
+                            C.byref(n_apply), C.byref(err))
+        check(rc, self._h, allow=(_lib.SDFS_ERR_NUMERIC,))
+        errors = None
+        if record_errors:
+            n = lib.sdfs_error_trace(self._h, None, 0)
+            errors = np.empty(n)
+            lib.sdfs_error_trace(self._h, errors.ctypes.data, n)
+        info = dict(n_apply=n_apply.value, final_err=err.value, errors=errors, status=rc)
+        return x, n_iter.value, info
+
+    # -- profiling counters (bench.py) -----------------------------------------
+    def set_profiling(self, on):
+        check(lib.sdfs_set_profiling(self._h, int(on)), self._h)
+
+    def reset_counters(self):
+        check(lib.sdfs_reset_counters(self._h), self._h)
+
+    def counters(self):
+        c = _lib.sdfs_counters()
+        check(lib.sdfs_get_counters(self._h, C.byref(c)), self._h)
+        out = []
+        for i in range(c.nkernels):
+            k = c.k[i]
+            out.append(dict(name=k.name.decode(), launches=k.launches, total_ms=k.total_ms,
+                            alg_bytes=k.alg_bytes, alg_flops=k.alg_flops))
+        return out
+
+
+def ssy_operator(shapes, params, arrays, device=0):
+    return KoopmansOperator("ssy", shapes, params, arrays, device)
+
+
+def gcy_operator(shapes, params, arrays, device=0):
+    return KoopmansOperator("gcy", shapes, params, arrays, device)
+
+
+# -- functional forms with the reference's signatures ---------------------------
+_cache = {}
+_CACHE_MAX = 8
+
+
+def _cached(model, shapes, params, arrays):
+    key = (model, tuple(int(s) for s in shapes), tuple(float(p) for p in params),
+           tuple(id(a) for a in arrays))
+    op = _cache.get(key)
+    if op is None:
+        if len(_cache) >= _CACHE_MAX:
+            _cache.pop(next(iter(_cache))).close()
+        op = KoopmansOperator(model, shapes, params, arrays)
+        op._keepalive = list(arrays)     # the id()-based key stays valid while these live
+        _cache[key] = op
+    return op
+
+
+def T_ssy(w, shapes, params, arrays):
+    """Drop-in for the reference's T_ssy: one operator application on the GPU."""
+    return _cached("ssy", shapes, params, arrays)(w)
+
+
+def T_gcy(w, shapes, params, arrays):
+    """Drop-in for the reference's T_gcy: one operator application on the GPU."""
+    return _cached("gcy", shapes, params, arrays)(w)

@@ -1,0 +1,246 @@
+"""
+GPU parity tests: the HIP path (through the C ABI of libsdfs_hip.so) against
+ (1) the golden vectors captured from the reference's own modules,
+ (2) the oracle (CPU restatement) on the same seeded inputs,
+ (3) size-independent properties at larger grids.
+Tolerances: one operator application agrees with the fp64 oracle to 1e-12
+relative (both evaluate the same sums in different orders; pow differs by a
+few ulp); converged fixed points agree to 1e-8 absolute (BASELINE north_star).
+"""
+import numpy as np
+import pytest
+
+from conftest import load_golden, golden_arrays
+
+pytestmark = pytest.mark.gpu
+
+APPLY_RTOL = 1e-12
+
+
+def tag(s):
+    return "x".join(map(str, s))
+
+
+@pytest.fixture(scope="module")
+def S():
+    import sdfs_via_autodiff_amd as S
+    return S
+
+
+def make_op(S, model, shapes):
+    if model == "ssy":
+        m = S.SSY(); arr = S.discretize_ssy(m, shapes)
+        return S.ssy_operator(shapes, m.params, arr), m.params, arr
+    m = S.GCY(); arr = S.discretize_gcy(m, shapes)
+    return S.gcy_operator(shapes, m.params, arr), m.params, arr
+
+
+def oracle_T(model, shapes):
+    from oracle import models, ssy, gcy
+    if model == "ssy":
+        p = models.ssy_params(); arr = ssy.discretize_ssy(p, shapes)
+        return (lambda w: ssy.T_ssy_factorised(w, shapes, p, arr),
+                lambda w, v: ssy.jvp_ssy(w, v, shapes, p, arr))
+    p = models.gcy_params(); arr = gcy.discretize_gcy(p, shapes)
+    return (lambda w: gcy.T_gcy_factorised(w, shapes, p, arr),
+            lambda w, v: gcy.jvp_gcy(w, v, shapes, p, arr))
+
+
+def wbench(shapes, seed=0):
+    return 400 + 500 * np.random.default_rng(seed).random(shapes)
+
+
+# ---------------------------------------------------------------- golden vectors
+@pytest.mark.parametrize("shapes", [(3, 3, 3, 3), (2, 3, 4, 5), (4, 7, 6, 5), (10, 10, 10, 10)])
+def test_T_ssy_vs_reference_golden(S, shapes):
+    g = load_golden(f"ssy_{tag(shapes)}.npz")
+    arr = golden_arrays(g, "ssy")
+    T = S.ssy_operator(shapes, tuple(g["params"]), arr)
+    np.testing.assert_allclose(T(g["w_rand"]), g["T_rand"], rtol=APPLY_RTOL)
+    np.testing.assert_allclose(T(np.full(shapes, 800.0)), g["T_800"], rtol=APPLY_RTOL)
+    # functional drop-in form, reference signature
+    np.testing.assert_allclose(S.T_ssy(g["w_rand"], shapes, tuple(g["params"]), arr), g["T_rand"],
+                               rtol=APPLY_RTOL)
+
+
+@pytest.mark.parametrize("shapes", [(2, 3, 2, 3, 2, 3), (3,) * 6, (2, 3, 4, 5, 6, 7)])
+def test_T_gcy_vs_reference_golden(S, shapes):
+    g = load_golden(f"gcy_{tag(shapes)}.npz")
+    arr = golden_arrays(g, "gcy")
+    T = S.gcy_operator(shapes, tuple(g["params"]), arr)
+    np.testing.assert_allclose(T(g["w_rand"]), g["T_rand"], rtol=APPLY_RTOL)
+    np.testing.assert_allclose(T(np.full(shapes, 800.0)), g["T_800"], rtol=APPLY_RTOL)
+    np.testing.assert_allclose(S.T_gcy(g["w_rand"], shapes, tuple(g["params"]), arr), g["T_rand"],
+                               rtol=APPLY_RTOL)
+
+
+# ---------------------------------------------------------------- oracle, same seeded inputs
+@pytest.mark.parametrize("model,shapes", [
+    ("ssy", (15, 15, 15, 15)), ("ssy", (2, 2, 2, 2)), ("ssy", (17, 5, 20, 3)), ("ssy", (32, 4, 4, 32)),
+    ("gcy", (6,) * 6), ("gcy", (2,) * 6), ("gcy", (8, 7, 6, 5, 4, 9)), ("gcy", (3, 2, 17, 2, 3, 20)),
+])
+def test_T_and_jvp_vs_oracle(S, model, shapes):
+    T, _, _ = make_op(S, model, shapes)
+    oT, oJ = oracle_T(model, shapes)
+    w = wbench(shapes)
+    want = oT(w)
+    got = T(w)
+    np.testing.assert_allclose(got, want, rtol=APPLY_RTOL)
+    assert abs(T.residual() - np.max(np.abs(want - w))) <= 1e-12 * np.max(np.abs(want - w)) + 1e-9
+    v = np.random.default_rng(1).standard_normal(shapes)
+    jw = oJ(w, v)
+    np.testing.assert_allclose(T.jvp(w, v), jw, rtol=1e-11, atol=1e-12 * np.max(np.abs(jw)))
+    # inputs are never mutated (functional ownership rule of the reference)
+    np.testing.assert_array_equal(w, wbench(shapes))
+
+
+def test_conditional_transition_tensors_are_honoured(S):
+    """Rouwenhorst gives identical conditional matrices; perturb them so every
+    (i) / (b,c,e) slice differs and check the conditioning is really applied."""
+    from oracle import models, ssy, gcy
+    rng = np.random.default_rng(5)
+
+    def rand_stochastic(shape):
+        q = rng.random(shape) + 0.05
+        return q / q.sum(axis=-1, keepdims=True)
+
+    shapes = (4, 5, 6, 7)
+    p = models.ssy_params(); arr = list(ssy.discretize_ssy(p, shapes))
+    arr[7] = rand_stochastic(arr[7].shape)
+    for i in (1, 3, 5):
+        arr[i] = rand_stochastic(arr[i].shape)
+    w = wbench(shapes)
+    np.testing.assert_allclose(S.ssy_operator(shapes, p, arr)(w),
+                               ssy.T_ssy_factorised(w, shapes, p, arr), rtol=APPLY_RTOL)
+    np.testing.assert_allclose(ssy.T_ssy_factorised(w, shapes, p, arr), ssy.T_ssy(w, shapes, p, arr), rtol=1e-13)
+
+    shapes = (3, 4, 2, 3, 5, 6)
+    p = models.gcy_params(); arr = list(gcy.discretize_gcy(p, shapes))
+    for i in (1, 3, 5, 8, 11, 14):
+        arr[i] = rand_stochastic(arr[i].shape)
+    w = wbench(shapes)
+    np.testing.assert_allclose(S.gcy_operator(shapes, p, arr)(w),
+                               gcy.T_gcy_factorised(w, shapes, p, arr), rtol=APPLY_RTOL)
+
+
+# ---------------------------------------------------------------- solvers
+@pytest.mark.parametrize("graph,check_every", [(1, 32), (0, 7), (1, 1)])
+def test_sa_iteration_count_matches_reference(S, graph, check_every):
+    shapes = (3, 3, 3, 3)
+    g = load_golden("sa_ssy_3x3x3x3.npz")
+    T, _, _ = make_op(S, "ssy", shapes)
+    x, n, info = T.solve(np.full(shapes, 800.0), "successive_approx", tol=1e-8, record_errors=True,
+                         use_graph=graph, check_every=check_every)
+    assert n == int(g["n_1e8"]) == 12253
+    np.testing.assert_allclose(x, g["w_1e8"], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(info["errors"][:200], g["errors"][:200], rtol=1e-9)
+    assert len(info["errors"]) == n and info["final_err"] <= 1e-8
+
+
+def test_sa_gcy_matches_reference(S):
+    shapes = (3,) * 6
+    g = load_golden("sa_gcy_3x3x3x3x3x3.npz")
+    T, _, _ = make_op(S, "gcy", shapes)
+    x, n = S.successive_approx(T, np.full(shapes, 800.0), verbose=False)
+    assert n == int(g["n_1e7"]) == 7520
+    np.testing.assert_allclose(x, g["w_1e7"], rtol=0, atol=1e-9)
+
+
+def test_sa_max_iter_is_exact(S):
+    shapes = (3, 3, 3, 3)
+    g = load_golden("sa_ssy_3x3x3x3.npz")
+    T, _, _ = make_op(S, "ssy", shapes)
+    for mi in (1, 5, 37, 64):
+        x, n, info = T.solve(np.full(shapes, 800.0), "successive_approx", tol=1e-8, max_iter=mi,
+                             record_errors=True, check_every=16)
+        assert n == mi and len(info["errors"]) == mi
+        np.testing.assert_allclose(info["errors"], g["errors"][:mi], rtol=1e-9)
+
+
+def test_solver_front_end_and_printing(S, capsys):
+    shapes = (2, 3, 4, 5)
+    g = load_golden("solver_front_ssy_2x3x4x5.npz")
+    T, _, _ = make_op(S, "ssy", shapes)
+    x = S.solver(T, np.full(shapes, 800.0), algorithm="successive_approx")
+    np.testing.assert_allclose(x, g["w"], rtol=0, atol=1e-9)
+    out = capsys.readouterr().out
+    assert "iter = 0, error = " in out and "Iteration converged after 10428 iterations" in out
+
+
+def test_newton_matches_sandpit_trace_and_oracle(S):
+    """Reference defaults (inner atol 1e-4, rtol 1e-5): recorded trace sandpit.ipynb:41-44."""
+    from oracle import solvers as osol
+    g = load_golden("sandpit_trace.npz")
+    shapes = tuple(int(s) for s in g["shapes"])
+    T, _, _ = make_op(S, "ssy", shapes)
+    x, n, info = T.solve(np.full(shapes, 800.0), "newton", record_errors=True)
+    for got, want, rtol in zip(info["errors"][:4], g["errors"], (2e-6, 5e-6, 5e-5, 2e-3)):
+        assert abs(got - want) <= rtol * want, (got, want)
+    oT, oJ = oracle_T("ssy", shapes)
+    xo, no = osol.newton_solver(oT, np.full(shapes, 800.0), verbose=False, jvp=oJ)
+    assert n == no
+    np.testing.assert_allclose(x, xo, rtol=0, atol=1e-4)   # both stop ~1e-5 from the fixed point
+
+
+@pytest.mark.parametrize("model,shapes", [("ssy", (15, 15, 15, 15)), ("gcy", (6,) * 6)])
+def test_newton_tight_fixed_point_within_1e8_of_oracle(S, model, shapes):
+    from oracle import solvers as osol
+    T, _, _ = make_op(S, model, shapes)
+    x, n, info = T.solve(np.full(shapes, 800.0), "newton", tol=1e-10, inner_rtol=1e-8, inner_atol=0.0)
+    oT, oJ = oracle_T(model, shapes)
+    xs = osol.newton_polish(oT, oJ, x.copy())
+    assert np.max(np.abs(oT(xs) - xs)) < 1e-10
+    assert np.max(np.abs(x - xs)) < 1e-8
+    assert n < 20
+
+
+def test_anderson_matches_oracle_anderson(S):
+    from oracle import solvers as osol
+    shapes = (3, 3, 3, 3)
+    T, _, _ = make_op(S, "ssy", shapes)
+    oT, oJ = oracle_T("ssy", shapes)
+    x, n = S.anderson_solver(T, np.full(shapes, 800.0), tol=1e-6, verbose=False)
+    xo, no = osol.anderson_solver(oT, np.full(shapes, 800.0), tol=1e-6, verbose=False)
+    assert abs(n - no) <= 8          # same algorithm, different summation order in the Gram matrix
+    xs = osol.newton_polish(oT, oJ, xo.copy())
+    assert np.max(np.abs(x - xs)) < 1e-2 and np.max(np.abs(T(x) - x)) < 1e-5
+
+
+# ---------------------------------------------------------------- properties at bench sizes
+def test_properties_large_grid(S):
+    """GCY 12^6 (3M points): monotone, T(800) bounded, JVP linear and consistent with
+    finite differences, device solve lands on a fixed point."""
+    shapes = (12,) * 6
+    T, _, _ = make_op(S, "gcy", shapes)
+    w = wbench(shapes)
+    Tw = T(w)
+    assert np.all(np.isfinite(Tw)) and np.all(Tw > 1.0)
+    Tw2 = T(w + 1.0)
+    assert np.all(Tw2 >= Tw)                                  # T is monotone
+    rng = np.random.default_rng(2)
+    v1, v2 = rng.standard_normal(shapes), rng.standard_normal(shapes)
+    j1, j2, j12 = T.jvp(w, v1), T.jvp(w, v2), T.jvp(w, 2.0 * v1 - 3.0 * v2)
+    np.testing.assert_allclose(j12, 2.0 * j1 - 3.0 * j2, rtol=1e-10, atol=1e-12)
+    h = 1e-3
+    fd = (T(w + h * v1) - T(w - h * v1)) / (2 * h)
+    np.testing.assert_allclose(j1, fd, rtol=1e-5, atol=1e-8)
+    x, n, info = T.solve(np.full(shapes, 800.0), "newton", tol=1e-9, inner_rtol=1e-7, inner_atol=0.0)
+    assert np.max(np.abs(T(x) - x)) < 1e-8
+
+
+# ---------------------------------------------------------------- error behaviour
+def test_bad_arguments_raise(S):
+    m = S.SSY(); shapes = (3, 3, 3, 3); arr = S.discretize_ssy(m, shapes)
+    with pytest.raises(S.SdfsError, match="expected"):
+        S.ssy_operator((3, 3, 3, 4), m.params, arr)
+    with pytest.raises(S.SdfsError, match="unsupported"):
+        S.ssy_operator((3, 3, 3, 40), m.params, S.discretize_ssy(m, (3, 3, 3, 40)))
+    with pytest.raises(S.SdfsError):
+        S.KoopmansOperator("ssy", shapes, m.params[:5], arr)
+    T = S.ssy_operator(shapes, m.params, arr)
+    with pytest.raises(ValueError):
+        T(np.ones((3, 3, 3)))
+    out = T(np.full(shapes, -1.0))            # w <= 0: NaN like the reference's jnp power
+    assert np.all(np.isnan(out))
+    x, n, info = T.solve(np.full(shapes, -1.0), "successive_approx")
+    assert n == 1 and info["status"] == -4

@@ -1,0 +1,148 @@
+"""
+CPU-side checks (no GPU needed): the C-ABI library loads and exports every symbol
+include/sdfs_hip.h declares, the host discretisation matches the golden vectors,
+the model classes match the reference's params order, and the host solver loops
+(the path taken for foreign callables) reproduce the reference's iteration counts.
+No compute call goes through the HIP library here.
+"""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import REPO, load_golden, golden_arrays
+
+
+def tag(s):
+    return "x".join(map(str, s))
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(REPO, "include", "sdfs_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(sdfs_[a-z_A-Z0-9]+)\s*\(", hdr))
+    assert len(declared) >= 20
+    from sdfs_via_autodiff_amd import _lib
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in sdfs_hip.h but not exported"
+    assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
+
+
+def test_opts_struct_layout_and_defaults():
+    from sdfs_via_autodiff_amd import _lib
+    o = _lib.default_opts()
+    assert (o.tol, o.max_iter, o.inner_rtol, o.inner_atol) == (1e-7, 1000000, 1e-5, 1e-4)
+    assert (o.history, o.mixing_freq, o.beta, o.ridge) == (10, 4, 8.0, 1e-6)
+    assert ctypes.sizeof(_lib.sdfs_opts) == 80
+
+
+def test_no_gpu_fails_loudly():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    import sdfs_via_autodiff_amd as S
+    with pytest.raises(S.SdfsError, match="no HIP device"):
+        S.ssy_operator((3, 3, 3, 3), S.SSY().params, S.discretize_ssy(S.SSY(), (3, 3, 3, 3)))
+
+
+def test_model_params_order():
+    import sdfs_via_autodiff_amd as S
+    assert np.array_equal(np.array(S.SSY().params), load_golden("ssy_3x3x3x3.npz")["params"])
+    assert np.array_equal(np.array(S.GCY().params), load_golden("gcy_3x3x3x3x3x3.npz")["params"])
+    assert S.SSY(γ=5.0).params[1] == 5.0 and S.GCY(ψ=1.2).params[1] == 1.2
+    assert abs(S.SSY().θ - (1 - 8.89) / (1 - 1 / 1.97)) < 1e-15
+
+
+@pytest.mark.parametrize("shapes", [(3, 3, 3, 3), (2, 3, 4, 5), (4, 7, 6, 5), (10, 10, 10, 10)])
+def test_discretize_ssy_matches_reference(shapes):
+    import sdfs_via_autodiff_amd as S
+    g = load_golden(f"ssy_{tag(shapes)}.npz")
+    got = S.discretize_ssy(S.SSY(), shapes)
+    assert len(got) == 10
+    for a, b in zip(got, golden_arrays(g, "ssy")):
+        assert a.shape == b.shape and a.dtype == np.float64
+        np.testing.assert_allclose(a, b, rtol=1e-14, atol=0)
+
+
+@pytest.mark.parametrize("shapes", [(2, 3, 2, 3, 2, 3), (3,) * 6, (2, 3, 4, 5, 6, 7)])
+def test_discretize_gcy_matches_reference(shapes):
+    import sdfs_via_autodiff_amd as S
+    g = load_golden(f"gcy_{tag(shapes)}.npz")
+    got = S.discretize_gcy(S.GCY(), shapes)
+    assert len(got) == 15
+    for a, b in zip(got, golden_arrays(g, "gcy")):
+        assert a.shape == b.shape and a.dtype == np.float64
+        np.testing.assert_allclose(a, b, rtol=1e-14, atol=0)
+
+
+def test_rouwenhorst_rows_sum_to_one_and_moments():
+    import sdfs_via_autodiff_amd as S
+    mc = S.rouwenhorst(9, 0.9, 0.3, 0.2)
+    np.testing.assert_allclose(mc.P.sum(axis=1), 1.0, rtol=1e-14)
+    assert abs(mc.state_values.mean() - 0.2 / (1 - 0.9)) < 1e-12
+    with pytest.raises(ValueError):
+        S.rouwenhorst(1, 0.9, 0.3)
+
+
+def _oracle_T(shapes):
+    from oracle import models, ssy
+    p = models.ssy_params()
+    arr = ssy.discretize_ssy(p, shapes)
+    T = lambda w: ssy.T_ssy_factorised(w, shapes, p, arr)
+    T.jvp = lambda w, v: ssy.jvp_ssy(w, v, shapes, p, arr)
+    return T
+
+
+def test_host_loop_successive_approx_foreign_callable(capsys):
+    """Foreign callables go through the host loop; counts must equal the reference's."""
+    import sdfs_via_autodiff_amd as S
+    shapes = (3, 3, 3, 3)
+    g = load_golden("sa_ssy_3x3x3x3.npz")
+    T = _oracle_T(shapes)
+    x, n = S.successive_approx(lambda w: T(w), np.full(shapes, 800.0), verbose=True)
+    assert n == int(g["n_1e7"]) == 10385
+    np.testing.assert_allclose(x, g["w_1e7"], atol=1e-9, rtol=0)
+    out = capsys.readouterr().out
+    assert out.startswith("Beginning iteration\n\n")
+    assert "iter = 0, error = " in out and "iter = 10000, error = " in out
+    assert "Iteration converged after 10385 iterations" in out
+
+
+def test_host_loop_newton_and_anderson_foreign_callable():
+    import sdfs_via_autodiff_amd as S
+    from oracle import solvers as osol
+    shapes = (3, 3, 3, 3)
+    T = _oracle_T(shapes)
+    x, n = S.newton_solver(T, np.full(shapes, 800.0), verbose=False)
+    xo, no = osol.newton_solver(T, np.full(shapes, 800.0), verbose=False, jvp=T.jvp)
+    assert n == no
+    np.testing.assert_allclose(x, xo, atol=1e-8, rtol=0)
+    xa, na = S.anderson_solver(lambda w: T(w), np.full(shapes, 800.0), tol=1e-6, verbose=False)
+    xb, nb = osol.anderson_solver(T, np.full(shapes, 800.0), tol=1e-6, verbose=False)
+    assert na == nb
+    np.testing.assert_allclose(xa, xb, atol=1e-9, rtol=0)
+    with pytest.raises(TypeError):
+        S.newton_solver(lambda w: T(w), np.full(shapes, 800.0), verbose=False)
+
+
+def test_solver_front_end_fallback_and_registry(capsys):
+    import sdfs_via_autodiff_amd as S
+    assert set(S.solvers) == {"newton", "anderson", "gd", "successive_approx"}
+    f = lambda x: 0.5 * x + 1.0
+    x = S.solver(f, np.zeros(3), algorithm="no-such-algorithm")
+    np.testing.assert_allclose(x, 2.0, atol=1e-6)
+    out = capsys.readouterr().out
+    assert "Algorithm no-such-algorithm not found." in out
+    assert "Falling back to successive approximation." in out
+    with pytest.raises(NotImplementedError):
+        S.solver(f, np.zeros(3), algorithm="gd")
+
+
+def test_max_iter_warning(capsys):
+    import sdfs_via_autodiff_amd as S
+    x, n = S.successive_approx(lambda x: x + 1.0, np.zeros(2), max_iter=5, verbose=False)
+    assert n == 5
+    assert "Warning: Hit maximum iteration number 5" in capsys.readouterr().out
