@@ -1,0 +1,172 @@
+#!/usr/bin/env python3
+"""
+bench.py -- fixed-point iterations/sec of the wealth-consumption-ratio operator on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W [--workload gcy20|gcy16|ssy15] [--no-cpu]
+
+A "step" is one successive-approximation iteration: one application of the Koopmans
+operator T (expectation passes + fused Epstein-Zin aggregator) with the sup-norm
+residual max|Tw - w| fused into the last kernel -- the body of the reference's hot loop
+(code/solvers.py:34-36).  Inputs are resident in HBM when the timed region starts.
+Default workload: GCY (20,)*6 fp64 (BASELINE.json configs[3] grid; the grid the
+north_star roofline/CPU targets are quoted on), synthetic w = 400 + 500*U(0,1).
+
+Prints ONE JSON line (rank 0).  Extra objects:
+  roofline     dominant kernel: algorithmic bytes per launch / mean launch duration,
+               measured with HIP events on the library's stream inside the timed region
+  cpu_baseline the oracle's C/OpenMP port of the same operator, timed on this box's cores
+  secondary    time-to-converge runs (SSY 15^4 SA / Newton) for context
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    "gcy20": ("gcy", (20,) * 6),
+    "gcy16": ("gcy", (16,) * 6),
+    "gcy12": ("gcy", (12,) * 6),
+    "ssy15": ("ssy", (15,) * 4),
+}
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def build_model(S, model, shapes):
+    if model == "ssy":
+        m = S.SSY()
+        return m.params, S.discretize_ssy(m, shapes)
+    m = S.GCY()
+    return m.params, S.discretize_gcy(m, shapes)
+
+
+def cpu_baseline(model, shapes, params, arrays, w_host, budget_s=12.0):
+    """Oracle C/OpenMP port, bounded sample: as many full applications as fit ~budget_s."""
+    from oracle.c_oracle import COperator, num_threads
+    op = COperator(model, shapes, params, arrays)
+    op(w_host)                                   # warm-up (page faults, thread pool)
+    n, t0 = 0, time.perf_counter()
+    while True:
+        op(w_host)
+        n += 1
+        dt = time.perf_counter() - t0
+        if dt > budget_s or n >= 50:
+            break
+    return {"value": n / dt, "unit": "iterations/s", "cores": num_threads(), "kind": "port",
+            "sample": f"{n} applications of T on the same {'x'.join(map(str, shapes))} grid "
+                      f"(oracle/c/wc_oracle.c, factorised, OpenMP), {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--workload", default="gcy20", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE {world}")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import sdfs_via_autodiff_amd as S
+    model, shapes = WORKLOADS[args.workload]
+    params, arrays = build_model(S, model, shapes)
+    N = int(np.prod(shapes))
+
+    if world > 1:
+        from sdfs_via_autodiff_amd.distributed import bench_sharded
+        line = bench_sharded(S, model, shapes, params, arrays, args, rank, local_rank, world)
+        if rank == 0:
+            print(json.dumps(line), flush=True)
+        dist.destroy_process_group()
+        return
+
+    op = S.KoopmansOperator(model, shapes, params, arrays, device=local_rank)
+    stream = torch.cuda.current_stream()
+    op.set_stream(stream.cuda_stream)
+    w_host = 400 + 500 * np.random.default_rng(0).random(shapes)
+    bufs = [torch.from_numpy(w_host).cuda(), torch.empty(shapes, dtype=torch.float64, device="cuda")]
+    resid = torch.zeros(1, dtype=torch.float64, device="cuda")
+
+    def step(i):
+        op.apply_dev(bufs[i & 1].data_ptr(), bufs[(i + 1) & 1].data_ptr(), resid.data_ptr())
+
+    for i in range(args.warmup):
+        step(i)
+    torch.cuda.synchronize()
+    op.set_profiling(True)       # HIP events around every launch, on the launch stream
+    op.reset_counters()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    counters = op.counters()
+    op.set_profiling(False)
+    last_resid = float(resid.item())
+
+    dom = max(counters, key=lambda c: c["total_ms"])
+    avg_ms = dom["total_ms"] / max(dom["launches"], 1)
+    achieved = dom["alg_bytes"] / (avg_ms * 1e-3) / 1e9
+    kernels = [{"name": c["name"], "launches": c["launches"],
+                "avg_ms": c["total_ms"] / max(c["launches"], 1),
+                "alg_GB": c["alg_bytes"] / 1e9,
+                "GBps": c["alg_bytes"] / (c["total_ms"] / max(c["launches"], 1) * 1e-3) / 1e9,
+                "frac_hbm": c["alg_bytes"] / (c["total_ms"] / max(c["launches"], 1) * 1e-3) / 1e9 / HBM_PEAK_GBS}
+               for c in counters]
+    line = {
+        "metric": "fixed-point iterations/sec",
+        "value": args.steps / dt,
+        "unit": "iterations/s",
+        "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"{model.upper()} {'x'.join(map(str, shapes))} grid, successive-approximation "
+                               f"step (T apply + fused sup-norm residual), default calibration, Rouwenhorst",
+                   "grid_points": N, "plan": op.describe_plan().strip().split("\n")},
+        "roofline": {"bound": "hbm", "kernel": dom["name"], "achieved": achieved, "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "avg_launch_ms": avg_ms, "alg_bytes_per_launch": dom["alg_bytes"]},
+        "kernels": kernels,
+        "ideal_single_pass_frac": 16.0 * N / (dt / args.steps) / 1e9 / HBM_PEAK_GBS,
+        "last_residual": last_resid,
+    }
+    if not args.no_cpu:
+        line["cpu_baseline"] = cpu_baseline(model, shapes, params, arrays, w_host)
+        line["gpu_over_cpu"] = line["value"] / line["cpu_baseline"]["value"]
+    if not args.no_secondary:
+        sec = {}
+        m = S.SSY(); shp = (15,) * 4
+        T = S.ssy_operator(shp, m.params, S.discretize_ssy(m, shp))
+        for algo, kw in (("successive_approx", dict(tol=1e-8)),
+                         ("newton", dict(tol=1e-8, inner_rtol=1e-6, inner_atol=0.0))):
+            T.solve(np.full(shp, 800.0), algo, max_iter=64)      # warm-up (graph capture, buffers)
+            t0 = time.perf_counter()
+            x, n, info = T.solve(np.full(shp, 800.0), algo, **kw)
+            t = time.perf_counter() - t0
+            sec[f"ssy15_{algo}"] = {"iterations": n, "operator_applies": info["n_apply"], "seconds": t,
+                                    "iterations_per_s": n / t, "applies_per_s": info["n_apply"] / t,
+                                    "final_err": info["final_err"]}
+        line["secondary"] = sec
+    print(json.dumps(line), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,142 @@
+/*
+ * wc_oracle.c -- ORACLE / TEST INFRASTRUCTURE (never linked into the product).
+ *
+ * Plain C + OpenMP restatement of the factorised Koopmans operator
+ *     Tw = 1 + beta * ( K .* H0( a1 .* w^theta ) )^(1/theta)
+ * for the SSY (code/ssy/discrete/ssy_wc_ratio.py:82-149) and GCY
+ * (code/gcy/discrete/gcy_wc_ratio.py:134-236) models of the reference: the same
+ * sum the reference forms by broadcasting, evaluated axis by axis (oracle/ssy.py,
+ * oracle/gcy.py hold the numpy twin that is pinned against the reference's golden
+ * vectors; tests/test_oracle_c.py checks this file against that twin).
+ * Used as the multi-core CPU baseline of bench.py ("kind": "port").
+ *
+ * Generic form: D axes, axis g has a transition tensor Q_g[cond.., i, I] whose
+ * conditioning indices are CURRENT-state indices of other axes, given as one
+ * matrix-index stride per axis (0 = not conditioned).  Axes are contracted in the
+ * caller-supplied legal order.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define MAXD 8
+
+static void contract_axis(const double* restrict x, double* restrict y, int D, const int64_t* n,
+                          int g, const double* restrict Q, const int64_t* qs) {
+  int64_t stride[MAXD];
+  int64_t s = 1;
+  for (int a = D - 1; a >= 0; --a) { stride[a] = s; s *= n[a]; }
+  const int ng = (int)n[g];
+  const int run_axis = (g == D - 1) ? -1 : D - 1;          /* contiguous inner run */
+  const int64_t R = run_axis >= 0 ? n[run_axis] : 1;
+  /* outer = all axes except g and the run axis */
+  int oax[MAXD], no = 0;
+  int64_t ototal = 1;
+  for (int a = 0; a < D; ++a) if (a != g && a != run_axis) { oax[no++] = a; ototal *= n[a]; }
+  const int64_t sg = stride[g];
+
+#pragma omp parallel for schedule(static)
+  for (int64_t o = 0; o < ototal; ++o) {
+    int64_t rem = o, base = 0, qidx = 0;
+    for (int k = no - 1; k >= 0; --k) {
+      const int a = oax[k];
+      const int64_t c = rem % n[a];
+      rem /= n[a];
+      base += c * stride[a];
+      qidx += c * qs[a];
+    }
+    const double* Qm = Q + qidx * ng * ng;
+    if (run_axis >= 0) {
+      for (int i = 0; i < ng; ++i) {
+        double* yo = y + base + i * sg;
+        for (int64_t r = 0; r < R; ++r) yo[r] = 0.0;
+        for (int I = 0; I < ng; ++I) {
+          const double q = Qm[i * ng + I];
+          const double* xi = x + base + I * sg;
+          for (int64_t r = 0; r < R; ++r) yo[r] += q * xi[r];
+        }
+      }
+    } else {
+      for (int i = 0; i < ng; ++i) {
+        double acc = 0.0;
+        for (int I = 0; I < ng; ++I) acc += Qm[i * ng + I] * x[base + I];
+        y[base + i] = acc;
+      }
+    }
+  }
+}
+
+/*
+ * Generic operator application.
+ *   D, n[D]            grid
+ *   order[D]           legal contraction order (axis ids)
+ *   Q[D], qs[D][D]     transition tensors and conditioning strides
+ *   a1/a2/a3 + per-axis index strides   elementwise tables: x = a1[i1] w^theta,
+ *                      K = a2[i2] a3[i3], index = sum_a coord_a * stride_a
+ *   mode 0: out = T(w);  mode 1: out = dT(w)[v]
+ *   work: 2*N doubles (mode 0) or 4*N doubles (mode 1)
+ */
+int wc_oracle_apply(int D, const int64_t* n, const int* order, const double* const* Q,
+                    const int64_t* qs_flat, const double* a1, const int64_t* a1s,
+                    const double* a2, const int64_t* a2s, const double* a3, const int64_t* a3s,
+                    double theta, double beta, int mode, const double* w, const double* v,
+                    double* out, double* work) {
+  if (D < 1 || D > MAXD) return -1;
+  int64_t N = 1;
+  for (int a = 0; a < D; ++a) N *= n[a];
+  double* bufA = work;
+  double* bufB = work + N;
+  double* S = NULL;
+  const int npass = (mode == 1) ? 2 : 1;
+  for (int pass = 0; pass < npass; ++pass) {
+    /* pass 0: S = H0(a1 w^theta); pass 1 (jvp): dS = H0(a1 w^(theta-1) v) */
+#pragma omp parallel for schedule(static)
+    for (int64_t p = 0; p < N; ++p) {
+      int64_t rem = p, i1 = 0;
+      for (int a = D - 1; a >= 0; --a) { const int64_t c = rem % n[a]; rem /= n[a]; i1 += c * a1s[a]; }
+      bufA[p] = (pass == 0) ? a1[i1] * pow(w[p], theta) : a1[i1] * pow(w[p], theta - 1.0) * v[p];
+    }
+    double* src = bufA;
+    double* dst = bufB;
+    for (int k = 0; k < D; ++k) {
+      const int g = order[k];
+      contract_axis(src, dst, D, n, g, Q[g], qs_flat + (int64_t)g * D);
+      double* t = src; src = dst; dst = t;
+    }
+    if (mode == 1 && pass == 0) {            /* keep S, continue with dS in the other half */
+      S = work + 2 * N;
+      memcpy(S, src, sizeof(double) * (size_t)N);
+    } else if (mode == 1) {
+      S = work + 2 * N;
+      const double* dS = src;
+#pragma omp parallel for schedule(static)
+      for (int64_t p = 0; p < N; ++p) {
+        int64_t rem = p, i2 = 0, i3 = 0;
+        for (int a = D - 1; a >= 0; --a) { const int64_t c = rem % n[a]; rem /= n[a]; i2 += c * a2s[a]; i3 += c * a3s[a]; }
+        const double K = a2[i2] * a3[i3];
+        out[p] = beta * pow(K * S[p], 1.0 / theta - 1.0) * K * dS[p];
+      }
+    } else {
+      const double* Sv = src;
+#pragma omp parallel for schedule(static)
+      for (int64_t p = 0; p < N; ++p) {
+        int64_t rem = p, i2 = 0, i3 = 0;
+        for (int a = D - 1; a >= 0; --a) { const int64_t c = rem % n[a]; rem /= n[a]; i2 += c * a2s[a]; i3 += c * a3s[a]; }
+        out[p] = 1.0 + beta * pow(a2[i2] * a3[i3] * Sv[p], 1.0 / theta);
+      }
+    }
+  }
+  return 0;
+}
+
+int wc_oracle_num_threads(void) {
+#ifdef _OPENMP
+  return omp_get_max_threads();
+#else
+  return 1;
+#endif
+}

@@ -179,7 +179,9 @@ def test_newton_matches_sandpit_trace_and_oracle(S):
     oT, oJ = oracle_T("ssy", shapes)
     xo, no = osol.newton_solver(oT, np.full(shapes, 800.0), verbose=False, jvp=oJ)
     assert n == no
-    np.testing.assert_allclose(x, xo, rtol=0, atol=1e-4)   # both stop ~1e-5 from the fixed point
+    # both runs stop with a residual ~1e-5 (the reference's atol quirk), i.e.
+    # ~1e-5/(1-0.9988) ~ 1e-2 from the fixed point at worst, along different rounding paths
+    np.testing.assert_allclose(x, xo, rtol=0, atol=2e-3)
 
 
 @pytest.mark.parametrize("model,shapes", [("ssy", (15, 15, 15, 15)), ("gcy", (6,) * 6)])
