@@ -20,6 +20,10 @@
 // 16 columns at a time, keeps the Q fragments in registers, reads the B operand
 // from LDS and writes the result back in place (a wave reads all rows of its 16
 // columns before it writes any of them).
+//
+// Memory phase: every thread owns EPT units of VEC consecutive doubles; all of a
+// thread's global loads are issued back to back before the first is consumed, so a
+// block keeps EPT*VEC*8 B per lane in flight instead of one dependent load at a time.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -43,13 +47,14 @@ struct PassDesc {
   // tile axes, slot 0 slowest .. slot 2 fastest; unused slots have extent 1
   int m[3];
   int toff[3];
-  long long gstride[3];
+  int gstride[3];              // element strides inside the tile (tile span < 2^31)
   int L[3];                    // LDS strides (L[2] == 1)
   int ta1[3], ta2[3], ta3[3];
   // contraction steps
   int nsteps;
   int sslot[3];
   int sn[3];
+  int qlds[3];                 // LDS offset (doubles) of step s's staged Q matrix
   const double* Q[3];
   // elementwise stages
   int pro, epi;
@@ -89,11 +94,41 @@ __device__ __forceinline__ long long xcd_remap(long long b, long long n) {
   return start + k;
 }
 
+// walks the units (VEC consecutive doubles along slot 2) a thread owns: tid, tid+B, ...
+struct Walker {
+  int t0, t1, t2u;
+  int d0, d1, d2u, m1, m2u;
+  __device__ __forceinline__ void init(int tid, int B, int m1_, int m2u_) {
+    m1 = m1_; m2u = m2u_;
+    t2u = tid % m2u; int r = tid / m2u; t1 = r % m1; t0 = r / m1;
+    d2u = B % m2u; r = B / m2u; d1 = r % m1; d0 = r / m1;
+  }
+  __device__ __forceinline__ void next() {
+    t2u += d2u; int c = t2u >= m2u; t2u -= c ? m2u : 0;
+    t1 += d1 + c; c = t1 >= m1; t1 -= c ? m1 : 0;
+    t0 += d0 + c;
+  }
+};
+
+template <int VEC> struct VecT;
+template <> struct VecT<1> {
+  double v[1];
+  __device__ __forceinline__ void load(const double* p) { v[0] = *p; }
+  __device__ __forceinline__ void store(double* p) const { *p = v[0]; }
+};
+template <> struct VecT<2> {
+  double v[2];
+  __device__ __forceinline__ void load(const double* p) {
+    const double2 t = *reinterpret_cast<const double2*>(p); v[0] = t.x; v[1] = t.y; }
+  __device__ __forceinline__ void store(double* p) const {
+    double2 t; t.x = v[0]; t.y = v[1]; *reinterpret_cast<double2*>(p) = t; }
+};
+
 __device__ __forceinline__ void contract_step(double* __restrict__ lds, const PassDesc& P, const int s,
-                                              const double* __restrict__ Qm, const int lane,
-                                              const int wave, const int nwaves) {
+                                              const int lane, const int wave, const int nwaves) {
   const int slot = P.sslot[s];
   const int n = P.sn[s];
+  const double* __restrict__ Qm = lds + P.qlds[s];
   int Ls, Lu, Lv, mu, mv;
   if (slot == 0) { Ls = P.L[0]; Lu = P.L[1]; mu = P.m[1]; Lv = 1; mv = P.m[2]; }
   else if (slot == 1) { Ls = P.L[1]; Lu = P.L[0]; mu = P.m[0]; Lv = 1; mv = P.m[2]; }
@@ -148,7 +183,8 @@ __device__ __forceinline__ void contract_step(double* __restrict__ lds, const Pa
   }
 }
 
-__global__ void __launch_bounds__(512)
+template <int EPT, int VEC>
+__global__ void __launch_bounds__(512, 4)
 pass_kernel(const PassDesc P, const PassIO io) {
   extern __shared__ double lds[];
   __shared__ double red[16];
@@ -185,82 +221,154 @@ pass_kernel(const PassDesc P, const PassIO io) {
     ia1b += P.toff[j] * P.ta1[j]; ia2b += P.toff[j] * P.ta2[j]; ia3b += P.toff[j] * P.ta3[j];
   }
 
-  const int m0 = P.m[0], m1 = P.m[1], m2 = P.m[2];
-  const int tot = m0 * m1 * m2;
+  const int m2u = P.m[2] / VEC;
+  const int tot = P.m[0] * P.m[1] * m2u;          // units of VEC doubles
   const int L0 = P.L[0], L1 = P.L[1];
-  const long long g0 = P.gstride[0], g1 = P.gstride[1], g2 = P.gstride[2];
+  const int g0 = P.gstride[0], g1 = P.gstride[1], g2 = P.gstride[2];
+  const double* __restrict__ gin = io.in + gbase;
 
-  // per-thread tile coordinates of element e = tid, advanced by B each trip
-  int t2 = tid % m2;
-  int rq = tid / m2;
-  int t1 = rq % m1;
-  int t0 = rq / m1;
-  const int d2 = B % m2;
-  const int dq = B / m2;
-  const int d1 = dq % m1;
-  const int d0 = dq / m1;
-  const int s0t = t0, s1t = t1, s2t = t2;
-
-  // ---- load + prologue ----------------------------------------------------
-  for (int e = tid; e < tot; e += B) {
-    const long long gi = gbase + t0 * g0 + t1 * g1 + t2 * g2;
-    double x = io.in[gi];
-    if (P.pro == PRO_POW || P.pro == PRO_POW_LIN) {
-      const int i1 = ia1b + t0 * P.ta1[0] + t1 * P.ta1[1] + t2 * P.ta1[2];
-      const double xw = P.a1[i1] * pow_pos(x, P.theta);
-      if (P.pro == PRO_POW_LIN) io.aux_out[gi] = xw / x;     // c1 = a1 w^(theta-1)
-      x = xw;
-    } else if (P.pro == PRO_MUL) {
-      x *= io.aux_in[gi];
+  // ---- light loop (unrolled): issue all global loads of this thread, then park the
+  //      raw values in LDS.  Heavy math runs afterwards in rolled loops so that the
+  //      register arrays never coexist with pow()'s temporaries.
+  {
+    VecT<VEC> val[EPT];
+    VecT<VEC> aux[EPT];
+    Walker wk;
+    wk.init(tid, B, P.m[1], m2u);
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) {
+      if (tid + k * B < tot) {
+        const int go = wk.t0 * g0 + wk.t1 * g1 + wk.t2u * VEC * g2;
+        val[k].load(gin + go);
+        if (P.pro == PRO_MUL) aux[k].load(io.aux_in + gbase + go);
+      }
+      wk.next();
     }
-    lds[t0 * L0 + t1 * L1 + t2] = x;
-    t2 += d2; int c = t2 >= m2; t2 -= c ? m2 : 0;
-    t1 += d1 + c; c = t1 >= m1; t1 -= c ? m1 : 0;
-    t0 += d0 + c;
+    // stage the transition matrices of this block's steps
+    {
+      const int nq0 = P.nsteps > 0 ? P.sn[0] * P.sn[0] : 0;
+      const int nq1 = P.nsteps > 1 ? P.sn[1] * P.sn[1] : 0;
+      const int nq2 = P.nsteps > 2 ? P.sn[2] * P.sn[2] : 0;
+      const double* Q0 = P.Q[0] + (long long)q0 * nq0;
+      const double* Q1 = P.Q[1] + (long long)q1 * nq1;
+      const double* Q2 = P.Q[2] + (long long)q2 * nq2;
+      for (int i = tid; i < nq0; i += B) lds[P.qlds[0] + i] = Q0[i];
+      for (int i = tid; i < nq1; i += B) lds[P.qlds[1] + i] = Q1[i];
+      for (int i = tid; i < nq2; i += B) lds[P.qlds[2] + i] = Q2[i];
+    }
+    wk.init(tid, B, P.m[1], m2u);
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) {
+      if (tid + k * B < tot) {
+        if (P.pro == PRO_MUL) {
+#pragma unroll
+          for (int j = 0; j < VEC; ++j) val[k].v[j] *= aux[k].v[j];
+        }
+        val[k].store(lds + wk.t0 * L0 + wk.t1 * L1 + wk.t2u * VEC);
+      }
+      wk.next();
+    }
+  }
+
+  // ---- prologue x = a1 w^theta, in place in LDS (each thread revisits its own units)
+  if (P.pro == PRO_POW || P.pro == PRO_POW_LIN) {
+    Walker wk;
+    wk.init(tid, B, P.m[1], m2u);
+#pragma unroll 1
+    for (int u = tid; u < tot; u += B) {
+      const int t2 = wk.t2u * VEC;
+      const int lo = wk.t0 * L0 + wk.t1 * L1 + t2;
+      const int i1 = ia1b + wk.t0 * P.ta1[0] + wk.t1 * P.ta1[1] + t2 * P.ta1[2];
+      VecT<VEC> x, c1;
+      x.load(lds + lo);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        const double xw = P.a1[i1 + j * P.ta1[2]] * pow_pos(x.v[j], P.theta);
+        c1.v[j] = xw / x.v[j];                                  // c1 = a1 w^(theta-1)
+        x.v[j] = xw;
+      }
+      x.store(lds + lo);
+      if (P.pro == PRO_POW_LIN) c1.store(io.aux_out + gbase + wk.t0 * g0 + wk.t1 * g1 + t2 * g2);
+      wk.next();
+    }
   }
   __syncthreads();
 
-  // ---- contractions -------------------------------------------------------
-  if (P.nsteps > 0) {
-    contract_step(lds, P, 0, P.Q[0] + (long long)q0 * P.sn[0] * P.sn[0], lane, wave, nwaves);
-    __syncthreads();
-  }
-  if (P.nsteps > 1) {
-    contract_step(lds, P, 1, P.Q[1] + (long long)q1 * P.sn[1] * P.sn[1], lane, wave, nwaves);
-    __syncthreads();
-  }
-  if (P.nsteps > 2) {
-    contract_step(lds, P, 2, P.Q[2] + (long long)q2 * P.sn[2] * P.sn[2], lane, wave, nwaves);
-    __syncthreads();
+  // ---- contractions ----------------------------------------------------------
+  if (P.nsteps > 0) { contract_step(lds, P, 0, lane, wave, nwaves); __syncthreads(); }
+  if (P.nsteps > 1) { contract_step(lds, P, 1, lane, wave, nwaves); __syncthreads(); }
+  if (P.nsteps > 2) { contract_step(lds, P, 2, lane, wave, nwaves); __syncthreads(); }
+
+  // ---- aggregator Tw = 1 + beta (K S)^(1/theta), in place in LDS (rolled loop) ---
+  if (P.epi == EPI_CES || P.epi == EPI_CES_LIN) {
+    Walker wk;
+    wk.init(tid, B, P.m[1], m2u);
+#pragma unroll 1
+    for (int u = tid; u < tot; u += B) {
+      const int t2 = wk.t2u * VEC;
+      const int lo = wk.t0 * L0 + wk.t1 * L1 + t2;
+      const int i2 = ia2b + wk.t0 * P.ta2[0] + wk.t1 * P.ta2[1] + t2 * P.ta2[2];
+      const int i3 = ia3b + wk.t0 * P.ta3[0] + wk.t1 * P.ta3[1] + t2 * P.ta3[2];
+      VecT<VEC> y, c2;
+      y.load(lds + lo);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        const double sv = y.v[j];
+        const double ks = P.a2[i2 + j * P.ta2[2]] * P.a3[i3 + j * P.ta3[2]] * sv;
+        const double uu = pow_pos(ks, P.inv_theta);
+        c2.v[j] = P.beta * uu / sv;                             // c2 = beta K (K S)^(1/theta-1) = beta u / S
+        y.v[j] = 1.0 + P.beta * uu;
+      }
+      y.store(lds + lo);
+      if (P.epi == EPI_CES_LIN) c2.store(io.aux_out + gbase + wk.t0 * g0 + wk.t1 * g1 + t2 * g2);
+      wk.next();
+    }
   }
 
-  // ---- epilogue + store ---------------------------------------------------
-  t0 = s0t; t1 = s1t; t2 = s2t;
+  // ---- light loop (unrolled): residual / scaling and the global store ------------
+  const bool need_old = (P.epi == EPI_CES || P.epi == EPI_CES_LIN) ? (io.resid != nullptr)
+                                                                   : (P.epi == EPI_MUL && P.minus_identity);
   double rmax = 0.0;
-  for (int e = tid; e < tot; e += B) {
-    const long long gi = gbase + t0 * g0 + t1 * g1 + t2 * g2;
-    double y = lds[t0 * L0 + t1 * L1 + t2];
-    if (P.epi == EPI_CES || P.epi == EPI_CES_LIN) {
-      const int i2 = ia2b + t0 * P.ta2[0] + t1 * P.ta2[1] + t2 * P.ta2[2];
-      const int i3 = ia3b + t0 * P.ta3[0] + t1 * P.ta3[1] + t2 * P.ta3[2];
-      const double ks = P.a2[i2] * P.a3[i3] * y;
-      const double u = pow_pos(ks, P.inv_theta);
-      const double tw = 1.0 + P.beta * u;
-      if (P.epi == EPI_CES_LIN) io.aux_out[gi] = P.beta * u / y;   // c2 = beta K (K S)^(1/theta-1)
-      if (io.resid != nullptr) {
-        double r = fabs(tw - io.old[gi]);
-        if (!(r == r)) r = __longlong_as_double(0x7ff0000000000000LL);   // NaN -> +inf
-        rmax = fmax(rmax, r);
+  {
+    VecT<VEC> val[EPT];
+    VecT<VEC> aux[EPT];
+    Walker wk;
+    wk.init(tid, B, P.m[1], m2u);
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) {
+      if (tid + k * B < tot) {
+        const int go = wk.t0 * g0 + wk.t1 * g1 + wk.t2u * VEC * g2;
+        if (need_old) val[k].load(io.old + gbase + go);
+        if (P.epi == EPI_MUL) aux[k].load(io.aux_in + gbase + go);
       }
-      y = tw;
-    } else if (P.epi == EPI_MUL) {
-      y *= io.aux_in[gi];
-      if (P.minus_identity) y -= io.old[gi];
+      wk.next();
     }
-    io.out[gi] = y;
-    t2 += d2; int c = t2 >= m2; t2 -= c ? m2 : 0;
-    t1 += d1 + c; c = t1 >= m1; t1 -= c ? m1 : 0;
-    t0 += d0 + c;
+    wk.init(tid, B, P.m[1], m2u);
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) {
+      if (tid + k * B < tot) {
+        const int t2 = wk.t2u * VEC;
+        const int go = wk.t0 * g0 + wk.t1 * g1 + t2 * g2;
+        VecT<VEC> y;
+        y.load(lds + wk.t0 * L0 + wk.t1 * L1 + t2);
+        if (P.epi == EPI_MUL) {
+#pragma unroll
+          for (int j = 0; j < VEC; ++j) {
+            y.v[j] *= aux[k].v[j];
+            if (P.minus_identity) y.v[j] -= val[k].v[j];
+          }
+        } else if (need_old) {
+#pragma unroll
+          for (int j = 0; j < VEC; ++j) {
+            double r = fabs(y.v[j] - val[k].v[j]);
+            if (!(r == r)) r = __longlong_as_double(0x7ff0000000000000LL);   // NaN -> +inf
+            rmax = fmax(rmax, r);
+          }
+        }
+        y.store(io.out + gbase + go);
+      }
+      wk.next();
+    }
   }
 
   if (io.resid != nullptr && (P.epi == EPI_CES || P.epi == EPI_CES_LIN)) {
@@ -274,6 +382,22 @@ pass_kernel(const PassDesc P, const PassIO io) {
       atomicMax(io.resid, (unsigned long long)__double_as_longlong(r));
     }
   }
+}
+
+typedef void (*pass_fn)(const PassDesc, const PassIO);
+
+// EPT in {1,2,4,8,16}, VEC in {1,2}
+inline pass_fn pass_kernel_variant(int ept, int vec) {
+#define SDFS_V(E) (vec == 2 ? (pass_fn)pass_kernel<E, 2> : (pass_fn)pass_kernel<E, 1>)
+  switch (ept) {
+    case 1: return SDFS_V(1);
+    case 2: return SDFS_V(2);
+    case 4: return SDFS_V(4);
+    case 8: return SDFS_V(8);
+    case 16: return SDFS_V(16);
+    default: return nullptr;
+  }
+#undef SDFS_V
 }
 
 }  // namespace sdfs

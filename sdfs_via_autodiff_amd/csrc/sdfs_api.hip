@@ -45,6 +45,8 @@ struct AxisInfo {
 struct Pass {
   PassDesc d;
   int block = 256;
+  bool vec2 = false;        // tile runs are even and 16-B aligned: double2 accesses
+  int ept1 = 1, ept2 = 1;   // units per thread for VEC = 1 / 2
   size_t lds_bytes = 0;
   int tile_axes[3] = {-1, -1, -1};
   int step_axes[3] = {-1, -1, -1};
@@ -113,6 +115,7 @@ struct sdfs_handle {
   // graph cache for the SA chunk
   hipGraphExec_t sa_graph = nullptr;
   int sa_graph_chunk = 0;
+  double sa_graph_tol = 0;   // the gate tolerance is baked into the captured kernel arguments
 };
 
 namespace {
@@ -233,7 +236,7 @@ int build_plan(sdfs_handle* h, Plan& plan, const std::vector<int>& todo_in, std:
     for (int j = 0; j < 3; ++j) { d.m[j] = 1; d.toff[j] = 0; d.gstride[j] = 0; d.ta1[j] = d.ta2[j] = d.ta3[j] = 0; }
     for (int j = 0; j < nt; ++j) {
       const int slot = 3 - nt + j, a = tile[j];
-      d.m[slot] = h->ax[a].nloc; d.toff[slot] = h->ax[a].off; d.gstride[slot] = stride[a];
+      d.m[slot] = h->ax[a].nloc; d.toff[slot] = h->ax[a].off; d.gstride[slot] = (int)stride[a];
       d.ta1[slot] = h->ax[a].a1s; d.ta2[slot] = h->ax[a].a2s; d.ta3[slot] = h->ax[a].a3s;
       P.tile_axes[slot] = a;
     }
@@ -270,7 +273,12 @@ int build_plan(sdfs_handle* h, Plan& plan, const std::vector<int>& todo_in, std:
     int L1 = d.m[2];
     if (contracts_fast_slot && d.m[1] * d.m[0] > 1) { while ((L1 & 3) != 2) ++L1; }
     d.L[2] = 1; d.L[1] = L1; d.L[0] = L1 * d.m[1];
-    const long long lds_elems = (long long)d.L[0] * d.m[0];
+    long long lds_elems = (long long)d.L[0] * d.m[0];
+    lds_elems += lds_elems & 1;
+    for (int s = 0; s < 3; ++s) {                     // staged transition matrices behind the tile
+      d.qlds[s] = (int)lds_elems;
+      if (s < d.nsteps) lds_elems += d.sn[s] * d.sn[s];
+    }
     P.lds_bytes = (size_t)lds_elems * 8;
     if (P.lds_bytes > 150 * 1024) return fail(h, SDFS_ERR_UNSUPPORTED, "tile of %lld doubles exceeds LDS", lds_elems);
     // block size: balance column tiles over waves, keep enough lanes for the elementwise stages
@@ -290,6 +298,17 @@ int build_plan(sdfs_handle* h, Plan& plan, const std::vector<int>& todo_in, std:
     }
     int fw = env_int("SDFS_FORCE_WAVES", 0);
     P.block = 64 * (fw > 0 ? fw : std::max(w_elem, w_mfma));
+    while ((tot + P.block - 1) / P.block > 16 && P.block < 512) P.block += 64;
+    auto round_ept = [](long long e) { int r = 1; while (r < e) r <<= 1; return r; };
+    P.ept1 = round_ept((tot + P.block - 1) / P.block);
+    if (P.ept1 > 16) return fail(h, SDFS_ERR_UNSUPPORTED, "tile too large for one block");
+    // 16-byte accesses: runs along slot 2 must be even, contiguous and every base even
+    bool v2 = (d.m[2] % 2 == 0) && d.gstride[2] == 1 && (d.L[1] % 2 == 0) && (d.L[0] % 2 == 0) &&
+              (d.gstride[0] % 2 == 0 || d.m[0] == 1) && (d.gstride[1] % 2 == 0 || d.m[1] == 1) &&
+              env_int("SDFS_NO_VEC2", 0) == 0;
+    for (int k = 0; k < d.nfixed; ++k) if (d.fstride[k] % 2 != 0 && d.fext[k] > 1) v2 = false;
+    P.vec2 = v2;
+    P.ept2 = v2 ? round_ept((tot / 2 + P.block - 1) / P.block) : P.ept1;
     char lab[96];
     int o = snprintf(lab, sizeof lab, "expect[");
     for (int s = 0; s < d.nsteps; ++s) o += snprintf(lab + o, sizeof lab - o, "%s%s", s ? "," : "", h->ax[G[s]].name);
@@ -375,8 +394,12 @@ int launch_pass(sdfs_handle* h, Pass& P, int pro, int epi, const PassIO& io, int
     snprintf(nm, sizeof nm, "%s:%s", tag, P.label.c_str());
     cid = counter_id(h, nm, bytes, P.flops);
   }
+  auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+  const bool v2 = P.vec2 && al16(io.in) && al16(io.out) && al16(io.aux_in) && al16(io.aux_out) && al16(io.old);
+  pass_fn fn = pass_kernel_variant(v2 ? P.ept2 : P.ept1, v2 ? 2 : 1);
+  if (!fn) return fail(h, SDFS_ERR_UNSUPPORTED, "no kernel variant for EPT %d", v2 ? P.ept2 : P.ept1);
   ProfScope ps(h, cid);
-  hipLaunchKernelGGL(pass_kernel, dim3((unsigned)d.ntiles), dim3(P.block), P.lds_bytes, h->stream, d, io);
+  hipLaunchKernelGGL(fn, dim3((unsigned)d.ntiles), dim3(P.block), P.lds_bytes, h->stream, d, io);
   HIPCHK(h, hipGetLastError());
   return 0;
 }
@@ -502,7 +525,7 @@ int solve_sa(sdfs_handle* h, const sdfs_opts& o, double* w, int64_t* n_iter, int
     return 0;
   };
   const bool graph = o.use_graph && !h->profiling;
-  if (graph && (h->sa_graph == nullptr || h->sa_graph_chunk != chunk)) {
+  if (graph && (h->sa_graph == nullptr || h->sa_graph_chunk != chunk || h->sa_graph_tol != o.tol)) {
     if (h->sa_graph) { hipGraphExecDestroy(h->sa_graph); h->sa_graph = nullptr; }
     hipGraph_t g = nullptr;
     HIPCHK(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
@@ -513,6 +536,7 @@ int solve_sa(sdfs_handle* h, const sdfs_opts& o, double* w, int64_t* n_iter, int
     HIPCHK(h, hipGraphInstantiate(&h->sa_graph, g, nullptr, nullptr, 0));
     hipGraphDestroy(g);
     h->sa_graph_chunk = chunk;
+    h->sa_graph_tol = o.tol;
   }
 
   long long it = 0;            // completed iterations (the reference's current_iter)
@@ -848,7 +872,9 @@ int create_common(int model, int ndim, const int64_t* shapes, const double* para
   if (rc) return bail(rc);
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute((const void*)pass_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
+    for (int e = 1; e <= 16; e <<= 1)
+      for (int v = 1; v <= 2; ++v)
+        hipFuncSetAttribute((const void*)pass_kernel_variant(e, v), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
     attr_set = true;
   }
   std::vector<int> all;
@@ -1103,8 +1129,9 @@ int sdfs_describe_plan(const sdfs_handle* h, char* buf, int64_t cap) {
     const Plan& pl = h->plan[st];
     for (size_t i = 0; i < pl.passes.size(); ++i) {
       const Pass& P = pl.passes[i];
-      snprintf(line, sizeof line, "stage %d pass %zu: %s tile %dx%dx%d lds %zu B block %d tiles %lld\n", st, i,
-               P.label.c_str(), P.d.m[0], P.d.m[1], P.d.m[2], P.lds_bytes, P.block, P.d.ntiles);
+      snprintf(line, sizeof line, "stage %d pass %zu: %s tile %dx%dx%d lds %zu B block %d vec %d ept %d tiles %lld\n", st, i,
+               P.label.c_str(), P.d.m[0], P.d.m[1], P.d.m[2], P.lds_bytes, P.block, P.vec2 ? 2 : 1,
+               P.vec2 ? P.ept2 : P.ept1, P.d.ntiles);
       s += line;
     }
   }

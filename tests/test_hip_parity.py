@@ -246,3 +246,15 @@ def test_bad_arguments_raise(S):
     assert np.all(np.isnan(out))
     x, n, info = T.solve(np.full(shapes, -1.0), "successive_approx")
     assert n == 1 and info["status"] == -4
+
+
+def test_two_solves_with_different_tolerances_on_one_operator(S):
+    """The captured iteration graph bakes the gate tolerance in; it must be rebuilt when tol changes."""
+    shapes = (3, 3, 3, 3)
+    g = load_golden("sa_ssy_3x3x3x3.npz")
+    T, _, _ = make_op(S, "ssy", shapes)
+    for tol, key in ((1e-7, "1e7"), (1e-8, "1e8"), (1e-7, "1e7")):
+        x, n, info = T.solve(np.full(shapes, 800.0), "successive_approx", tol=tol)
+        assert n == int(g[f"n_{key}"])
+        np.testing.assert_allclose(x, g[f"w_{key}"], rtol=0, atol=1e-9)
+        assert 0 < info["final_err"] <= tol
