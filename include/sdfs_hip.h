@@ -151,6 +151,11 @@ int sdfs_set_profiling(sdfs_handle* h, int on);
 int sdfs_reset_counters(sdfs_handle* h);
 int sdfs_get_counters(sdfs_handle* h, sdfs_counters* out);
 
+/* Test hook: out[i] = x[i]^y through the kernels' own device power routine (the
+ * replacement for jnp's `**` at ssy_wc_ratio.py:145,148 / gcy_wc_ratio.py:232,235),
+ * so that its accuracy can be checked in isolation. */
+int sdfs_debug_pow(const double* x_host, double y, double* out_host, int64_t n, int device_id);
+
 /* Human-readable description of the kernel plan (passes, tiles, grid sizes). */
 int sdfs_describe_plan(const sdfs_handle* h, char* buf, int64_t cap);
 

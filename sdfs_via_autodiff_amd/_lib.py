@@ -70,6 +70,7 @@ SYMBOLS = {
     "sdfs_reset_counters": (C.c_int, [_P]),
     "sdfs_get_counters": (C.c_int, [_P, C.POINTER(sdfs_counters)]),
     "sdfs_describe_plan": (C.c_int, [_P, C.c_char_p, C.c_int64]),
+    "sdfs_debug_pow": (C.c_int, [_P, C.c_double, _P, C.c_int64, C.c_int]),
 }
 
 

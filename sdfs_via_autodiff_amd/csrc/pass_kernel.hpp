@@ -28,6 +28,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "pow_tables.hpp"
+
 namespace sdfs {
 
 constexpr int MAXF = 5;   // block-fixed axis slots
@@ -79,9 +81,74 @@ struct PassIO {
 
 typedef double v4d __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ double pow_pos(double x, double y) {
-  // x > 0 on this path (wealth-consumption ratios); pow() of the device libm.
-  return pow(x, y);
+// ---------------------------------------------------------------------------
+// pow_fast(x, y) for the two powers of the operator (w^theta and (K S)^(1/theta)).
+// x^y = 2^(y log2 x) with log2 x in double-double:
+//   x = 2^k z, z in [0.7055, 1.411); 64-entry table of 1/c and log2 c (tools/gen_pow_tables.py);
+//   r = fma(z, 1/c, -1), |r| <= 2^-7;  log2 x = k + log2 c + r/ln2 + r^2 P(r)  (Taylor, degree 10)
+//   e = y * log2 x (hi + lo);  2^e = 2^(j>>6) * 2^((j&63)/64) * 2^f, |f| <= 2^-7 (Taylor, degree 7)
+// Absolute error of y*log2 x stays below ~2^-58 |y|, i.e. ~1 ulp of the result for
+// |y| <= 64 (theta = -16, -36 here); tests/test_hip_parity.py checks it against long double.
+// The tables live one entry per lane in registers and are gathered with ds_bpermute
+// (no LDS memory, no bank conflicts): EVERY lane of the wave must be active at a call.
+// Inputs outside the fast range (x <= 0, NaN, Inf, subnormal, overflow/underflow) take libm pow().
+struct PowLane { double invc, lchi, lclo, e2t; };
+
+__device__ __forceinline__ PowLane pow_lane_init(int lane) {
+  PowLane T;
+  T.invc = POW_INVC[lane]; T.lchi = POW_LOGC_HI[lane]; T.lclo = POW_LOGC_LO[lane]; T.e2t = POW_EXP2T[lane];
+  return T;
+}
+
+__device__ __forceinline__ double gather64(double v, int idx) {
+  const int lo = __builtin_amdgcn_ds_bpermute(idx << 2, __double2loint(v));
+  const int hi = __builtin_amdgcn_ds_bpermute(idx << 2, __double2hiint(v));
+  return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ double pow_fast(double x, double y, const PowLane& T) {
+  // subnormal inputs: rescale by 2^64 (exact) and fix the exponent below
+  const bool tiny = x < 0x1p-1022;
+  const double xs = tiny ? x * 0x1p64 : x;
+  const unsigned long long ix = (unsigned long long)__double_as_longlong(xs);
+  const unsigned long long tmp = ix - POW_OFF;
+  const int i = (int)((tmp >> 46) & 63);
+  const double kd = (double)((long long)tmp >> 52) - (tiny ? 64.0 : 0.0);
+  const double z = __longlong_as_double((long long)(ix - (tmp & 0xfff0000000000000ULL)));
+  const double invc = gather64(T.invc, i);
+  const double lchi = gather64(T.lchi, i);
+  const double lclo = gather64(T.lclo, i);
+  const double r = fma(z, invc, -1.0);
+  // hi part: (kd + lchi) + r/ln2, errors collected in lo
+  const double t1 = kd + lchi;
+  const double t1e = lchi - (t1 - kd);                 // fast two-sum: |kd| >= |lchi| or kd == 0
+  const double p1 = r * POW_INVLN2_HI;
+  const double p1e = fma(r, POW_INVLN2_HI, -p1);
+  const double hi = t1 + p1;                           // two-sum
+  const double bb = hi - t1;
+  const double e2 = (t1 - (hi - bb)) + (p1 - bb);
+  double q = POW_L10;
+  q = fma(q, r, POW_L9); q = fma(q, r, POW_L8); q = fma(q, r, POW_L7); q = fma(q, r, POW_L6);
+  q = fma(q, r, POW_L5); q = fma(q, r, POW_L4); q = fma(q, r, POW_L3); q = fma(q, r, POW_L2);
+  const double lo = fma(r * r, q, ((t1e + e2) + p1e) + fma(r, POW_INVLN2_LO, lclo));
+  // e = y * log2(x), clamped so that the integer part stays small (over/underflow saturate in ldexp)
+  double ehi = y * hi;
+  const double elo = fma(y, hi, -ehi) + y * lo;
+  ehi = fmin(fmax(ehi, -1200.0), 1200.0);
+  const double jd = rint(ehi * 64.0);
+  const double f = fma(jd, -0.015625, ehi) + elo;
+  const int j = (int)jd;
+  const double t = gather64(T.e2t, j & 63);
+  double p = POW_E7;
+  p = fma(p, f, POW_E6); p = fma(p, f, POW_E5); p = fma(p, f, POW_E4);
+  p = fma(p, f, POW_E3); p = fma(p, f, POW_E2); p = fma(p, f, POW_E1);
+  double res = ldexp(fma(t, p * f, t), j >> 6);
+  // IEEE corner cases of pow for the inputs this path can meet (y finite, y != 0)
+  const double inf = __longlong_as_double(0x7ff0000000000000LL);
+  if (x == 0.0) res = y < 0.0 ? inf : 0.0;
+  if (x == inf) res = y < 0.0 ? 0.0 : inf;
+  if (!(x >= 0.0)) res = __longlong_as_double(0x7ff8000000000000LL);   // negative base or NaN
+  return res;
 }
 
 // XCD-aware block -> tile map: blocks b, b+8, b+16.. share an XCD (round-robin
@@ -183,9 +250,11 @@ __device__ __forceinline__ void contract_step(double* __restrict__ lds, const Pa
   }
 }
 
-template <int EPT, int VEC>
+template <int EPT, int VEC, bool JVP>
 __global__ void __launch_bounds__(512, 4)
 pass_kernel(const PassDesc P, const PassIO io) {
+  // T launches never see PRO_MUL / EPI_MUL and JVP launches never see a power: the mode is a
+  // template flag so the dead stage (and its registers) disappears from each variant.
   extern __shared__ double lds[];
   __shared__ double red[16];
 
@@ -240,7 +309,7 @@ pass_kernel(const PassDesc P, const PassIO io) {
       if (tid + k * B < tot) {
         const int go = wk.t0 * g0 + wk.t1 * g1 + wk.t2u * VEC * g2;
         val[k].load(gin + go);
-        if (P.pro == PRO_MUL) aux[k].load(io.aux_in + gbase + go);
+        if (JVP && P.pro == PRO_MUL) aux[k].load(io.aux_in + gbase + go);
       }
       wk.next();
     }
@@ -260,7 +329,7 @@ pass_kernel(const PassDesc P, const PassIO io) {
 #pragma unroll
     for (int k = 0; k < EPT; ++k) {
       if (tid + k * B < tot) {
-        if (P.pro == PRO_MUL) {
+        if (JVP && P.pro == PRO_MUL) {
 #pragma unroll
           for (int j = 0; j < VEC; ++j) val[k].v[j] *= aux[k].v[j];
         }
@@ -270,25 +339,34 @@ pass_kernel(const PassDesc P, const PassIO io) {
     }
   }
 
-  // ---- prologue x = a1 w^theta, in place in LDS (each thread revisits its own units)
-  if (P.pro == PRO_POW || P.pro == PRO_POW_LIN) {
+  // ---- prologue x = a1 w^theta, in place in LDS (each thread revisits its own units).
+  //      Uniform trip count: pow_fast needs every lane of the wave active.
+  const int iters = (tot + B - 1) / B;
+  PowLane PT;
+  if (!JVP && (P.pro == PRO_POW || P.pro == PRO_POW_LIN || P.epi == EPI_CES || P.epi == EPI_CES_LIN))
+    PT = pow_lane_init(lane);
+  if (!JVP && (P.pro == PRO_POW || P.pro == PRO_POW_LIN)) {
     Walker wk;
     wk.init(tid, B, P.m[1], m2u);
 #pragma unroll 1
-    for (int u = tid; u < tot; u += B) {
+    for (int it = 0; it < iters; ++it) {
+      const bool valid = tid + it * B < tot;
       const int t2 = wk.t2u * VEC;
-      const int lo = wk.t0 * L0 + wk.t1 * L1 + t2;
-      const int i1 = ia1b + wk.t0 * P.ta1[0] + wk.t1 * P.ta1[1] + t2 * P.ta1[2];
+      const int lo = valid ? wk.t0 * L0 + wk.t1 * L1 + t2 : 0;
+      const int i1 = valid ? ia1b + wk.t0 * P.ta1[0] + wk.t1 * P.ta1[1] + t2 * P.ta1[2] : 0;
       VecT<VEC> x, c1;
       x.load(lds + lo);
 #pragma unroll
       for (int j = 0; j < VEC; ++j) {
-        const double xw = P.a1[i1 + j * P.ta1[2]] * pow_pos(x.v[j], P.theta);
-        c1.v[j] = xw / x.v[j];                                  // c1 = a1 w^(theta-1)
+        const double xin = valid ? x.v[j] : 1.0;
+        const double xw = P.a1[valid ? i1 + j * P.ta1[2] : 0] * pow_fast(xin, P.theta, PT);
+        c1.v[j] = xw / xin;                                     // c1 = a1 w^(theta-1)
         x.v[j] = xw;
       }
-      x.store(lds + lo);
-      if (P.pro == PRO_POW_LIN) c1.store(io.aux_out + gbase + wk.t0 * g0 + wk.t1 * g1 + t2 * g2);
+      if (valid) {
+        x.store(lds + lo);
+        if (P.pro == PRO_POW_LIN) c1.store(io.aux_out + gbase + wk.t0 * g0 + wk.t1 * g1 + t2 * g2);
+      }
       wk.next();
     }
   }
@@ -299,35 +377,38 @@ pass_kernel(const PassDesc P, const PassIO io) {
   if (P.nsteps > 1) { contract_step(lds, P, 1, lane, wave, nwaves); __syncthreads(); }
   if (P.nsteps > 2) { contract_step(lds, P, 2, lane, wave, nwaves); __syncthreads(); }
 
-  // ---- aggregator Tw = 1 + beta (K S)^(1/theta), in place in LDS (rolled loop) ---
-  if (P.epi == EPI_CES || P.epi == EPI_CES_LIN) {
+  // ---- aggregator Tw = 1 + beta (K S)^(1/theta), in place in LDS (rolled, uniform) ----
+  if (!JVP && (P.epi == EPI_CES || P.epi == EPI_CES_LIN)) {
     Walker wk;
     wk.init(tid, B, P.m[1], m2u);
 #pragma unroll 1
-    for (int u = tid; u < tot; u += B) {
+    for (int it = 0; it < iters; ++it) {
+      const bool valid = tid + it * B < tot;
       const int t2 = wk.t2u * VEC;
-      const int lo = wk.t0 * L0 + wk.t1 * L1 + t2;
-      const int i2 = ia2b + wk.t0 * P.ta2[0] + wk.t1 * P.ta2[1] + t2 * P.ta2[2];
-      const int i3 = ia3b + wk.t0 * P.ta3[0] + wk.t1 * P.ta3[1] + t2 * P.ta3[2];
+      const int lo = valid ? wk.t0 * L0 + wk.t1 * L1 + t2 : 0;
+      const int i2 = valid ? ia2b + wk.t0 * P.ta2[0] + wk.t1 * P.ta2[1] + t2 * P.ta2[2] : 0;
+      const int i3 = valid ? ia3b + wk.t0 * P.ta3[0] + wk.t1 * P.ta3[1] + t2 * P.ta3[2] : 0;
       VecT<VEC> y, c2;
       y.load(lds + lo);
 #pragma unroll
       for (int j = 0; j < VEC; ++j) {
-        const double sv = y.v[j];
-        const double ks = P.a2[i2 + j * P.ta2[2]] * P.a3[i3 + j * P.ta3[2]] * sv;
-        const double uu = pow_pos(ks, P.inv_theta);
+        const double sv = valid ? y.v[j] : 1.0;
+        const double ks = P.a2[valid ? i2 + j * P.ta2[2] : 0] * P.a3[valid ? i3 + j * P.ta3[2] : 0] * sv;
+        const double uu = pow_fast(ks, P.inv_theta, PT);
         c2.v[j] = P.beta * uu / sv;                             // c2 = beta K (K S)^(1/theta-1) = beta u / S
         y.v[j] = 1.0 + P.beta * uu;
       }
-      y.store(lds + lo);
-      if (P.epi == EPI_CES_LIN) c2.store(io.aux_out + gbase + wk.t0 * g0 + wk.t1 * g1 + t2 * g2);
+      if (valid) {
+        y.store(lds + lo);
+        if (P.epi == EPI_CES_LIN) c2.store(io.aux_out + gbase + wk.t0 * g0 + wk.t1 * g1 + t2 * g2);
+      }
       wk.next();
     }
   }
 
   // ---- light loop (unrolled): residual / scaling and the global store ------------
-  const bool need_old = (P.epi == EPI_CES || P.epi == EPI_CES_LIN) ? (io.resid != nullptr)
-                                                                   : (P.epi == EPI_MUL && P.minus_identity);
+  const bool need_old = JVP ? (P.epi == EPI_MUL && P.minus_identity)
+                            : ((P.epi == EPI_CES || P.epi == EPI_CES_LIN) && io.resid != nullptr);
   double rmax = 0.0;
   {
     VecT<VEC> val[EPT];
@@ -339,7 +420,7 @@ pass_kernel(const PassDesc P, const PassIO io) {
       if (tid + k * B < tot) {
         const int go = wk.t0 * g0 + wk.t1 * g1 + wk.t2u * VEC * g2;
         if (need_old) val[k].load(io.old + gbase + go);
-        if (P.epi == EPI_MUL) aux[k].load(io.aux_in + gbase + go);
+        if (JVP && P.epi == EPI_MUL) aux[k].load(io.aux_in + gbase + go);
       }
       wk.next();
     }
@@ -351,13 +432,13 @@ pass_kernel(const PassDesc P, const PassIO io) {
         const int go = wk.t0 * g0 + wk.t1 * g1 + t2 * g2;
         VecT<VEC> y;
         y.load(lds + wk.t0 * L0 + wk.t1 * L1 + t2);
-        if (P.epi == EPI_MUL) {
+        if (JVP && P.epi == EPI_MUL) {
 #pragma unroll
           for (int j = 0; j < VEC; ++j) {
             y.v[j] *= aux[k].v[j];
             if (P.minus_identity) y.v[j] -= val[k].v[j];
           }
-        } else if (need_old) {
+        } else if (!JVP && need_old) {
 #pragma unroll
           for (int j = 0; j < VEC; ++j) {
             double r = fabs(y.v[j] - val[k].v[j]);
@@ -371,7 +452,7 @@ pass_kernel(const PassDesc P, const PassIO io) {
     }
   }
 
-  if (io.resid != nullptr && (P.epi == EPI_CES || P.epi == EPI_CES_LIN)) {
+  if (!JVP && io.resid != nullptr && (P.epi == EPI_CES || P.epi == EPI_CES_LIN)) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) rmax = fmax(rmax, __shfl_xor(rmax, o));
     if (lane == 0) red[wave] = rmax;
@@ -384,11 +465,22 @@ pass_kernel(const PassDesc P, const PassIO io) {
   }
 }
 
+// test hook: out[i] = pow_fast(x[i], y) (n padded so that whole waves run)
+__global__ void __launch_bounds__(256) debug_pow_kernel(const double* __restrict__ x, double y,
+                                                        double* __restrict__ out, long long n) {
+  const PowLane PT = pow_lane_init(threadIdx.x & 63);
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const double xv = i < n ? x[i] : 1.0;
+  const double r = pow_fast(xv, y, PT);
+  if (i < n) out[i] = r;
+}
+
 typedef void (*pass_fn)(const PassDesc, const PassIO);
 
-// EPT in {1,2,4,8,16}, VEC in {1,2}
-inline pass_fn pass_kernel_variant(int ept, int vec) {
-#define SDFS_V(E) (vec == 2 ? (pass_fn)pass_kernel<E, 2> : (pass_fn)pass_kernel<E, 1>)
+// EPT in {1,2,4,8,16}, VEC in {1,2}, JVP in {false,true}
+inline pass_fn pass_kernel_variant(int ept, int vec, bool jvp) {
+#define SDFS_V(E) (jvp ? (vec == 2 ? (pass_fn)pass_kernel<E, 2, true> : (pass_fn)pass_kernel<E, 1, true>) \
+                       : (vec == 2 ? (pass_fn)pass_kernel<E, 2, false> : (pass_fn)pass_kernel<E, 1, false>))
   switch (ept) {
     case 1: return SDFS_V(1);
     case 2: return SDFS_V(2);

@@ -396,7 +396,8 @@ int launch_pass(sdfs_handle* h, Pass& P, int pro, int epi, const PassIO& io, int
   }
   auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
   const bool v2 = P.vec2 && al16(io.in) && al16(io.out) && al16(io.aux_in) && al16(io.aux_out) && al16(io.old);
-  pass_fn fn = pass_kernel_variant(v2 ? P.ept2 : P.ept1, v2 ? 2 : 1);
+  const bool jvp = (pro == PRO_MUL || epi == EPI_MUL || (pro == PRO_NONE && epi == EPI_NONE && tag[0] == 'j'));
+  pass_fn fn = pass_kernel_variant(v2 ? P.ept2 : P.ept1, v2 ? 2 : 1, jvp);
   if (!fn) return fail(h, SDFS_ERR_UNSUPPORTED, "no kernel variant for EPT %d", v2 ? P.ept2 : P.ept1);
   ProfScope ps(h, cid);
   hipLaunchKernelGGL(fn, dim3((unsigned)d.ntiles), dim3(P.block), P.lds_bytes, h->stream, d, io);
@@ -874,7 +875,8 @@ int create_common(int model, int ndim, const int64_t* shapes, const double* para
   if (!attr_set) {
     for (int e = 1; e <= 16; e <<= 1)
       for (int v = 1; v <= 2; ++v)
-        hipFuncSetAttribute((const void*)pass_kernel_variant(e, v), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
+        for (int j = 0; j < 2; ++j)
+          hipFuncSetAttribute((const void*)pass_kernel_variant(e, v, j != 0), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
     attr_set = true;
   }
   std::vector<int> all;
@@ -1119,6 +1121,19 @@ int sdfs_get_counters(sdfs_handle* h, sdfs_counters* out) {
   if ((rc = drain_events(h))) return rc;
   *out = h->counters;
   return 0;
+}
+
+int sdfs_debug_pow(const double* x_host, double y, double* out_host, int64_t n, int device_id) {
+  if (!x_host || !out_host || n < 1) return SDFS_ERR_ARG;
+  if (hipSetDevice(device_id) != hipSuccess) return fail(nullptr, SDFS_ERR_HIP, "hipSetDevice failed");
+  double *dx = nullptr, *dy = nullptr;
+  if (hipMalloc((void**)&dx, 8 * (size_t)n) != hipSuccess || hipMalloc((void**)&dy, 8 * (size_t)n) != hipSuccess)
+    return fail(nullptr, SDFS_ERR_HIP, "hipMalloc failed");
+  hipMemcpy(dx, x_host, 8 * (size_t)n, hipMemcpyHostToDevice);
+  hipLaunchKernelGGL(debug_pow_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, dx, y, dy, (long long)n);
+  hipError_t e = hipMemcpy(out_host, dy, 8 * (size_t)n, hipMemcpyDeviceToHost);
+  hipFree(dx); hipFree(dy);
+  return e == hipSuccess ? 0 : fail(nullptr, SDFS_ERR_HIP, "debug_pow: %s", hipGetErrorString(e));
 }
 
 int sdfs_describe_plan(const sdfs_handle* h, char* buf, int64_t cap) {

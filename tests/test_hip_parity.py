@@ -258,3 +258,33 @@ def test_two_solves_with_different_tolerances_on_one_operator(S):
         assert n == int(g[f"n_{key}"])
         np.testing.assert_allclose(x, g[f"w_{key}"], rtol=0, atol=1e-9)
         assert 0 < info["final_err"] <= tol
+
+
+def test_device_pow_accuracy_vs_long_double(S):
+    """The kernels' power routine (double-double log2 + table exp2) against x87 long double powl."""
+    import ctypes
+    from sdfs_via_autodiff_amd import _lib
+    rng = np.random.default_rng(11)
+    xs = np.concatenate([
+        np.exp(rng.uniform(np.log(1e-130), np.log(1e8), 200000)),
+        rng.uniform(100.0, 1000.0, 100000),             # wealth-consumption ratios
+        1.0 + rng.uniform(-1e-3, 1e-3, 20000),          # near 1 (cancellation in the log)
+        np.array([1.0, 2.0, 0.5, 800.0, 0.7055, 1.411, 1e-300, 5e-324, 2.2250738585072014e-308, 1e300]),
+    ])
+    for y in (-16.0216, -36.03, 1 / -16.0216, 1 / -36.03, -17.0216, -37.03, 1 / -16.0216 - 1, 2.5, 64.0):
+        out = np.empty_like(xs)
+        rc = _lib.lib.sdfs_debug_pow(xs.ctypes.data, ctypes.c_double(y), out.ctypes.data, xs.size, 0)
+        assert rc == 0
+        want = np.power(xs.astype(np.longdouble), np.longdouble(y))
+        fin = np.isfinite(want.astype(np.float64)) & (want.astype(np.float64) > 1e-300)
+        rel = np.abs((out[fin].astype(np.longdouble) - want[fin]) / want[fin]).astype(np.float64)
+        assert rel.max() < 4.5e-16, (y, rel.max(), xs[fin][rel.argmax()])
+        # over/underflow saturate like IEEE pow
+        big = ~np.isfinite(want.astype(np.float64))
+        assert np.all(np.isinf(out[big]))
+        zero = want.astype(np.float64) == 0.0
+        assert np.all(out[zero] == 0.0)
+    special = np.array([0.0, -1.0, np.inf, np.nan, -0.0])
+    out = np.empty_like(special)
+    _lib.lib.sdfs_debug_pow(special.ctypes.data, ctypes.c_double(-16.0216), out.ctypes.data, special.size, 0)
+    assert out[0] == np.inf and np.isnan(out[1]) and out[2] == 0.0 and np.isnan(out[3]) and out[4] == np.inf
