@@ -166,6 +166,9 @@ struct Walker {
   int t0, t1, t2u;
   int d0, d1, d2u, m1, m2u;
   __device__ __forceinline__ void init(int tid, int B, int m1_, int m2u_) {
+    // opaque copy: every phase recomputes its (cheap) coordinates instead of keeping the
+    // previous phase's address registers alive across the MFMA/pow stages (that spilled)
+    asm volatile("" : "+v"(tid));
     m1 = m1_; m2u = m2u_;
     t2u = tid % m2u; int r = tid / m2u; t1 = r % m1; t0 = r / m1;
     d2u = B % m2u; r = B / m2u; d1 = r % m1; d0 = r / m1;
