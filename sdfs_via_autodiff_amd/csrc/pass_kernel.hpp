@@ -208,14 +208,13 @@ __device__ __forceinline__ void contract_step(double* __restrict__ lds, const Pa
   const bool mt2 = n > 16;
   const int li = lane & 15, lk = lane >> 4;
 
-  // A operand: Q[i][I], lane holds A[m = lane&15][k = lane>>4] per k-step (f64 16x16x4 map)
-  double qa[8], qb[8];
-#pragma unroll
-  for (int kk = 0; kk < 8; ++kk) {
-    const int I = 4 * kk + lk;
-    qa[kk] = (li < n && I < n) ? Qm[li * n + I] : 0.0;
-    qb[kk] = (16 + li < n && I < n) ? Qm[(16 + li) * n + I] : 0.0;
-  }
+  // A operand: Q[i][I], lane holds A[m = lane&15][k = lane>>4] per k-step (f64 16x16x4 map).
+  // Fragments are re-read from the LDS-staged matrix per k-step: keeping all 16 of them in
+  // registers cost 32 VGPRs that the next tile's prefetch needs; out-of-range rows/columns
+  // read element 0 and are masked to zero.
+  const int qrow0 = (li < n ? li : 0) * n;
+  const int qrow1 = (16 + li < n ? 16 + li : 0) * n;
+  const bool r0ok = li < n, r1ok = 16 + li < n;
 
   for (int ct = wave; ct * 16 < ncols; ct += nwaves) {
     const int col = ct * 16 + li;
@@ -228,11 +227,16 @@ __device__ __forceinline__ void contract_step(double* __restrict__ lds, const Pa
 #pragma unroll
     for (int kk = 0; kk < 8; ++kk) {
       if (kk < KT) {
-        int I = 4 * kk + lk;
-        I = I < n ? I : n - 1;              // rows >= n meet zero Q columns; keep the read in bounds
+        const int I0 = 4 * kk + lk;
+        const bool iok = I0 < n;
+        const int I = iok ? I0 : n - 1;     // rows >= n meet zero Q columns; keep the read in bounds
         const double b = lds[cbase + I * Ls];
-        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(qa[kk], b, acc0, 0, 0, 0);
-        if (mt2) acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(qb[kk], b, acc1, 0, 0, 0);
+        const double a0 = Qm[qrow0 + I];
+        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64((r0ok && iok) ? a0 : 0.0, b, acc0, 0, 0, 0);
+        if (mt2) {
+          const double a1 = Qm[qrow1 + I];
+          acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64((r1ok && iok) ? a1 : 0.0, b, acc1, 0, 0, 0);
+        }
       }
     }
     // D map of v_mfma_f64_16x16x4_f64: col = lane&15, row = (lane>>4) + 4*reg
@@ -253,11 +257,61 @@ __device__ __forceinline__ void contract_step(double* __restrict__ lds, const Pa
   }
 }
 
-template <int EPT, int VEC, bool JVP>
+// Zero-instruction barrier: redefines the offsets as far as the optimiser can tell, so address
+// arithmetic built on them is neither hoisted out of the tile loop nor kept live from one
+// phase to the next (both cost dozens of VGPRs and ended in scratch spills).
+template <int N>
+__device__ __forceinline__ void opaque(int (&a)[N]) {
+#pragma unroll
+  for (int k = 0; k < N; ++k) asm volatile("" : "+v"(a[k]));
+}
+
+// Compile-time role of a launch inside one operator application.
+enum PassMode { M_MID = 0, M_TFIRST = 1, M_TLAST = 2, M_TONLY = 3, M_JFIRST = 4, M_JLAST = 5 };
+
+struct TileCtx {
+  long long gbase;
+  int ia1b, ia2b, ia3b;
+  int q0, q1, q2;
+};
+
+__device__ __forceinline__ TileCtx decode_tile(const PassDesc& P, long long tile) {
+  TileCtx c;
+  c.gbase = 0; c.ia1b = 0; c.ia2b = 0; c.ia3b = 0; c.q0 = 0; c.q1 = 0; c.q2 = 0;
+#pragma unroll
+  for (int k = MAXF - 1; k >= 0; --k) {
+    if (k < P.nfixed) {
+      const int e = P.fext[k];
+      const int cc = (int)(tile % e);
+      tile /= e;
+      const int gc = cc + P.foff[k];
+      c.gbase += (long long)cc * P.fstride[k];
+      c.ia1b += gc * P.fa1[k]; c.ia2b += gc * P.fa2[k]; c.ia3b += gc * P.fa3[k];
+      c.q0 += gc * P.fq[0][k]; c.q1 += gc * P.fq[1][k]; c.q2 += gc * P.fq[2][k];
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    c.ia1b += P.toff[j] * P.ta1[j]; c.ia2b += P.toff[j] * P.ta2[j]; c.ia3b += P.toff[j] * P.ta3[j];
+  }
+  return c;
+}
+
+// Persistent pass kernel: the grid holds as many blocks as fit on the chip; each block
+// walks a strided sequence of tiles inside its XCD's contiguous chunk and prefetches
+// tile t+1 into registers while tile t goes through LDS (park -> pow -> MFMA -> pow -> store).
+// Every tile of a pass has the same geometry, so each thread computes the global / LDS
+// offsets of its EPT units ONCE (goff / loff) and reuses them for every tile and phase.
+template <int EPT, int VEC, int MODE>
 __global__ void __launch_bounds__(512, 4)
 pass_kernel(const PassDesc P, const PassIO io) {
-  // T launches never see PRO_MUL / EPI_MUL and JVP launches never see a power: the mode is a
-  // template flag so the dead stage (and its registers) disappears from each variant.
+  constexpr bool POWP = (MODE == M_TFIRST || MODE == M_TONLY);   // x = a1 w^theta while parking
+  constexpr bool CES = (MODE == M_TLAST || MODE == M_TONLY);     // Tw = 1 + beta (K S)^(1/theta)
+  constexpr bool MULP = (MODE == M_JFIRST);                      // x = c1 * v
+  constexpr bool MULE = (MODE == M_JLAST);                       // out = c2 * y (- v)
+  constexpr int NAUX = MULP ? EPT : 1;
+  constexpr int NOLD = (CES || MULE) ? EPT : 1;
+  constexpr int NC2 = MULE ? EPT : 1;
   extern __shared__ double lds[];
   __shared__ double red[16];
 
@@ -270,194 +324,222 @@ pass_kernel(const PassDesc P, const PassIO io) {
   const int B = blockDim.x;
   const int lane = tid & 63, wave = tid >> 6, nwaves = B >> 6;
 
-  long long tile = xcd_remap((long long)blockIdx.x, P.ntiles);
+  // tile sequence of this block: XCD label x owns one contiguous chunk of tiles; its
+  // nbx blocks sweep it together (neighbouring tiles run at the same time on one L2)
+  const long long G = gridDim.x;
+  const long long xl = blockIdx.x & 7, jl = blockIdx.x >> 3;
+  const long long nbx = (G - xl + 7) >> 3;
+  const long long q8 = P.ntiles >> 3, r8 = P.ntiles & 7;
+  const long long cstart = (xl < r8) ? xl * (q8 + 1) : r8 * (q8 + 1) + (xl - r8) * q8;
+  const long long cend = cstart + q8 + (xl < r8 ? 1 : 0);
+  long long tile = cstart + jl;
+  if (tile >= cend) return;
 
-  // decode block-fixed coordinates
-  long long gbase = 0;
-  int ia1b = 0, ia2b = 0, ia3b = 0;
-  int q0 = 0, q1 = 0, q2 = 0;
-#pragma unroll
-  for (int k = MAXF - 1; k >= 0; --k) {
-    if (k < P.nfixed) {
-      const int e = P.fext[k];
-      const int c = (int)(tile % e);
-      tile /= e;
-      const int gc = c + P.foff[k];
-      gbase += (long long)c * P.fstride[k];
-      ia1b += gc * P.fa1[k]; ia2b += gc * P.fa2[k]; ia3b += gc * P.fa3[k];
-      q0 += gc * P.fq[0][k]; q1 += gc * P.fq[1][k]; q2 += gc * P.fq[2][k];
-    }
-  }
-#pragma unroll
-  for (int j = 0; j < 3; ++j) {
-    ia1b += P.toff[j] * P.ta1[j]; ia2b += P.toff[j] * P.ta2[j]; ia3b += P.toff[j] * P.ta3[j];
-  }
-
+  const int m1 = P.m[1];
   const int m2u = P.m[2] / VEC;
-  const int tot = P.m[0] * P.m[1] * m2u;          // units of VEC doubles
+  const int tot = P.m[0] * m1 * m2u;          // units of VEC doubles
+  const int iters = (tot + B - 1) / B;
   const int L0 = P.L[0], L1 = P.L[1];
   const int g0 = P.gstride[0], g1 = P.gstride[1], g2 = P.gstride[2];
-  const double* __restrict__ gin = io.in + gbase;
 
-  // ---- light loop (unrolled): issue all global loads of this thread, then park the
-  //      raw values in LDS.  Heavy math runs afterwards in rolled loops so that the
-  //      register arrays never coexist with pow()'s temporaries.
+  // per-thread unit offsets, identical for every tile of the pass
+  int goff[EPT], loff[EPT];
   {
-    VecT<VEC> val[EPT];
-    VecT<VEC> aux[EPT];
     Walker wk;
-    wk.init(tid, B, P.m[1], m2u);
+    wk.init(tid, B, m1, m2u);
 #pragma unroll
     for (int k = 0; k < EPT; ++k) {
-      if (tid + k * B < tot) {
-        const int go = wk.t0 * g0 + wk.t1 * g1 + wk.t2u * VEC * g2;
-        val[k].load(gin + go);
-        if (JVP && P.pro == PRO_MUL) aux[k].load(io.aux_in + gbase + go);
-      }
-      wk.next();
-    }
-    // stage the transition matrices of this block's steps
-    {
-      const int nq0 = P.nsteps > 0 ? P.sn[0] * P.sn[0] : 0;
-      const int nq1 = P.nsteps > 1 ? P.sn[1] * P.sn[1] : 0;
-      const int nq2 = P.nsteps > 2 ? P.sn[2] * P.sn[2] : 0;
-      const double* Q0 = P.Q[0] + (long long)q0 * nq0;
-      const double* Q1 = P.Q[1] + (long long)q1 * nq1;
-      const double* Q2 = P.Q[2] + (long long)q2 * nq2;
-      for (int i = tid; i < nq0; i += B) lds[P.qlds[0] + i] = Q0[i];
-      for (int i = tid; i < nq1; i += B) lds[P.qlds[1] + i] = Q1[i];
-      for (int i = tid; i < nq2; i += B) lds[P.qlds[2] + i] = Q2[i];
-    }
-    wk.init(tid, B, P.m[1], m2u);
-#pragma unroll
-    for (int k = 0; k < EPT; ++k) {
-      if (tid + k * B < tot) {
-        if (JVP && P.pro == PRO_MUL) {
-#pragma unroll
-          for (int j = 0; j < VEC; ++j) val[k].v[j] *= aux[k].v[j];
-        }
-        val[k].store(lds + wk.t0 * L0 + wk.t1 * L1 + wk.t2u * VEC);
-      }
+      const bool valid = tid + k * B < tot;
+      goff[k] = valid ? wk.t0 * g0 + wk.t1 * g1 + wk.t2u * VEC * g2 : -1;
+      loff[k] = valid ? wk.t0 * L0 + wk.t1 * L1 + wk.t2u * VEC : 0;
       wk.next();
     }
   }
 
-  // ---- prologue x = a1 w^theta, in place in LDS (each thread revisits its own units).
-  //      Uniform trip count: pow_fast needs every lane of the wave active.
-  const int iters = (tot + B - 1) / B;
   PowLane PT;
-  if (!JVP && (P.pro == PRO_POW || P.pro == PRO_POW_LIN || P.epi == EPI_CES || P.epi == EPI_CES_LIN))
-    PT = pow_lane_init(lane);
-  if (!JVP && (P.pro == PRO_POW || P.pro == PRO_POW_LIN)) {
-    Walker wk;
-    wk.init(tid, B, P.m[1], m2u);
-#pragma unroll 1
-    for (int it = 0; it < iters; ++it) {
-      const bool valid = tid + it * B < tot;
-      const int t2 = wk.t2u * VEC;
-      const int lo = valid ? wk.t0 * L0 + wk.t1 * L1 + t2 : 0;
-      const int i1 = valid ? ia1b + wk.t0 * P.ta1[0] + wk.t1 * P.ta1[1] + t2 * P.ta1[2] : 0;
-      VecT<VEC> x, c1;
-      x.load(lds + lo);
-#pragma unroll
-      for (int j = 0; j < VEC; ++j) {
-        const double xin = valid ? x.v[j] : 1.0;
-        const double xw = P.a1[valid ? i1 + j * P.ta1[2] : 0] * pow_fast(xin, P.theta, PT);
-        c1.v[j] = xw / xin;                                     // c1 = a1 w^(theta-1)
-        x.v[j] = xw;
-      }
-      if (valid) {
-        x.store(lds + lo);
-        if (P.pro == PRO_POW_LIN) c1.store(io.aux_out + gbase + wk.t0 * g0 + wk.t1 * g1 + t2 * g2);
-      }
-      wk.next();
-    }
-  }
-  __syncthreads();
+  if (POWP || CES) PT = pow_lane_init(lane);
 
-  // ---- contractions ----------------------------------------------------------
-  if (P.nsteps > 0) { contract_step(lds, P, 0, lane, wave, nwaves); __syncthreads(); }
-  if (P.nsteps > 1) { contract_step(lds, P, 1, lane, wave, nwaves); __syncthreads(); }
-  if (P.nsteps > 2) { contract_step(lds, P, 2, lane, wave, nwaves); __syncthreads(); }
-
-  // ---- aggregator Tw = 1 + beta (K S)^(1/theta), in place in LDS (rolled, uniform) ----
-  if (!JVP && (P.epi == EPI_CES || P.epi == EPI_CES_LIN)) {
-    Walker wk;
-    wk.init(tid, B, P.m[1], m2u);
-#pragma unroll 1
-    for (int it = 0; it < iters; ++it) {
-      const bool valid = tid + it * B < tot;
-      const int t2 = wk.t2u * VEC;
-      const int lo = valid ? wk.t0 * L0 + wk.t1 * L1 + t2 : 0;
-      const int i2 = valid ? ia2b + wk.t0 * P.ta2[0] + wk.t1 * P.ta2[1] + t2 * P.ta2[2] : 0;
-      const int i3 = valid ? ia3b + wk.t0 * P.ta3[0] + wk.t1 * P.ta3[1] + t2 * P.ta3[2] : 0;
-      VecT<VEC> y, c2;
-      y.load(lds + lo);
+  TileCtx cur = decode_tile(P, tile);
+  VecT<VEC> val[EPT];
+  VecT<VEC> aux[NAUX];
 #pragma unroll
-      for (int j = 0; j < VEC; ++j) {
-        const double sv = valid ? y.v[j] : 1.0;
-        const double ks = P.a2[valid ? i2 + j * P.ta2[2] : 0] * P.a3[valid ? i3 + j * P.ta3[2] : 0] * sv;
-        const double uu = pow_fast(ks, P.inv_theta, PT);
-        c2.v[j] = P.beta * uu / sv;                             // c2 = beta K (K S)^(1/theta-1) = beta u / S
-        y.v[j] = 1.0 + P.beta * uu;
-      }
-      if (valid) {
-        y.store(lds + lo);
-        if (P.epi == EPI_CES_LIN) c2.store(io.aux_out + gbase + wk.t0 * g0 + wk.t1 * g1 + t2 * g2);
-      }
-      wk.next();
+  for (int k = 0; k < EPT; ++k) {
+    if (goff[k] >= 0) {
+      val[k].load(io.in + cur.gbase + goff[k]);
+      if (MULP) aux[MULP ? k : 0].load(io.aux_in + cur.gbase + goff[k]);
     }
   }
 
-  // ---- light loop (unrolled): residual / scaling and the global store ------------
-  const bool need_old = JVP ? (P.epi == EPI_MUL && P.minus_identity)
-                            : ((P.epi == EPI_CES || P.epi == EPI_CES_LIN) && io.resid != nullptr);
+  int qp0 = -1, qp1 = -1, qp2 = -1;
   double rmax = 0.0;
-  {
-    VecT<VEC> val[EPT];
-    VecT<VEC> aux[EPT];
-    Walker wk;
-    wk.init(tid, B, P.m[1], m2u);
+
+  for (;;) {
+    // Per-lane values are re-derived from an opaque copy of the thread id in every trip:
+    // otherwise LICM hoists every lane-dependent invariant of the body (MFMA operand
+    // addresses, walker state, ...) out of the tile loop and spills dozens of them.
+    int tid_o = threadIdx.x;
+    asm volatile("" : "+v"(tid_o));
+    const int tid = tid_o;
+    const int lane = tid & 63, wave = tid >> 6;
+    // ---- park the prefetched tile in LDS ------------------------------------------
+    opaque(goff); opaque(loff);
 #pragma unroll
     for (int k = 0; k < EPT; ++k) {
-      if (tid + k * B < tot) {
-        const int go = wk.t0 * g0 + wk.t1 * g1 + wk.t2u * VEC * g2;
-        if (need_old) val[k].load(io.old + gbase + go);
-        if (JVP && P.epi == EPI_MUL) aux[k].load(io.aux_in + gbase + go);
+      if (goff[k] >= 0) {
+        if (MULP) {
+#pragma unroll
+          for (int j = 0; j < VEC; ++j) val[k].v[j] *= aux[MULP ? k : 0].v[j];
+        }
+        val[k].store(lds + loff[k]);
       }
-      wk.next();
     }
-    wk.init(tid, B, P.m[1], m2u);
+    // ---- prefetch the next tile (stays in flight during all the compute below) -------
+    const long long ntile = tile + nbx;
+    const bool has_next = ntile < cend;
+    TileCtx nxt = cur;
+    if (has_next) {
+      nxt = decode_tile(P, ntile);
+      opaque(goff);
+#pragma unroll
+      for (int k = 0; k < EPT; ++k) {
+        if (goff[k] >= 0) {
+          val[k].load(io.in + nxt.gbase + goff[k]);
+          if (MULP) aux[MULP ? k : 0].load(io.aux_in + nxt.gbase + goff[k]);
+        }
+      }
+    }
+    // ---- stage the transition matrices (only when the conditioning index changed) ----
+    if (P.nsteps > 0 && cur.q0 != qp0) {
+      const int nq = P.sn[0] * P.sn[0];
+      const double* Q = P.Q[0] + (long long)cur.q0 * nq;
+      for (int i = tid; i < nq; i += B) lds[P.qlds[0] + i] = Q[i];
+      qp0 = cur.q0;
+    }
+    if (P.nsteps > 1 && cur.q1 != qp1) {
+      const int nq = P.sn[1] * P.sn[1];
+      const double* Q = P.Q[1] + (long long)cur.q1 * nq;
+      for (int i = tid; i < nq; i += B) lds[P.qlds[1] + i] = Q[i];
+      qp1 = cur.q1;
+    }
+    if (P.nsteps > 2 && cur.q2 != qp2) {
+      const int nq = P.sn[2] * P.sn[2];
+      const double* Q = P.Q[2] + (long long)cur.q2 * nq;
+      for (int i = tid; i < nq; i += B) lds[P.qlds[2] + i] = Q[i];
+      qp2 = cur.q2;
+    }
+
+    // ---- prologue x = a1 w^theta, in place in LDS (each thread revisits its own units).
+    //      Uniform trip count: pow_fast needs every lane of the wave active.
+    if (POWP) {
+      Walker wk;
+      wk.init(tid, B, m1, m2u);
+#pragma unroll 1
+      for (int it = 0; it < iters; ++it) {
+        const bool valid = tid + it * B < tot;
+        const int t2 = wk.t2u * VEC;
+        const int lo = valid ? wk.t0 * L0 + wk.t1 * L1 + t2 : 0;
+        const int i1 = valid ? cur.ia1b + wk.t0 * P.ta1[0] + wk.t1 * P.ta1[1] + t2 * P.ta1[2] : 0;
+        VecT<VEC> x, c1;
+        x.load(lds + lo);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+          const double xin = valid ? x.v[j] : 1.0;
+          const double xw = P.a1[valid ? i1 + j * P.ta1[2] : 0] * pow_fast(xin, P.theta, PT);
+          c1.v[j] = xw / xin;                                     // c1 = a1 w^(theta-1)
+          x.v[j] = xw;
+        }
+        if (valid) {
+          x.store(lds + lo);
+          if (P.pro == PRO_POW_LIN) c1.store(io.aux_out + cur.gbase + wk.t0 * g0 + wk.t1 * g1 + t2 * g2);
+        }
+        wk.next();
+      }
+    }
+    __syncthreads();
+
+    // ---- contractions ----------------------------------------------------------------
+    if (P.nsteps > 0) { contract_step(lds, P, 0, lane, wave, nwaves); __syncthreads(); }
+    if (P.nsteps > 1) { contract_step(lds, P, 1, lane, wave, nwaves); __syncthreads(); }
+    if (P.nsteps > 2) { contract_step(lds, P, 2, lane, wave, nwaves); __syncthreads(); }
+
+    // ---- final-stage operands of THIS tile: issue now, consume after the aggregator ----
+    const bool need_old = CES ? (io.resid != nullptr) : (MULE && P.minus_identity);
+    VecT<VEC> oldv[NOLD];
+    VecT<VEC> c2v[NC2];
+    if (CES || MULE) {
+      opaque(goff);
+#pragma unroll
+      for (int k = 0; k < EPT; ++k) {
+        if (goff[k] >= 0) {
+          if (need_old) oldv[(CES || MULE) ? k : 0].load(io.old + cur.gbase + goff[k]);
+          if (MULE) c2v[MULE ? k : 0].load(io.aux_in + cur.gbase + goff[k]);
+        }
+      }
+    }
+
+    // ---- aggregator Tw = 1 + beta (K S)^(1/theta), in place in LDS (rolled, uniform) ----
+    if (CES) {
+      Walker wk;
+      wk.init(tid, B, m1, m2u);
+#pragma unroll 1
+      for (int it = 0; it < iters; ++it) {
+        const bool valid = tid + it * B < tot;
+        const int t2 = wk.t2u * VEC;
+        const int lo = valid ? wk.t0 * L0 + wk.t1 * L1 + t2 : 0;
+        const int i2 = valid ? cur.ia2b + wk.t0 * P.ta2[0] + wk.t1 * P.ta2[1] + t2 * P.ta2[2] : 0;
+        const int i3 = valid ? cur.ia3b + wk.t0 * P.ta3[0] + wk.t1 * P.ta3[1] + t2 * P.ta3[2] : 0;
+        VecT<VEC> y, c2;
+        y.load(lds + lo);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+          const double sv = valid ? y.v[j] : 1.0;
+          const double ks = P.a2[valid ? i2 + j * P.ta2[2] : 0] * P.a3[valid ? i3 + j * P.ta3[2] : 0] * sv;
+          const double uu = pow_fast(ks, P.inv_theta, PT);
+          c2.v[j] = P.beta * uu / sv;                             // c2 = beta K (K S)^(1/theta-1) = beta u / S
+          y.v[j] = 1.0 + P.beta * uu;
+        }
+        if (valid) {
+          y.store(lds + lo);
+          if (P.epi == EPI_CES_LIN) c2.store(io.aux_out + cur.gbase + wk.t0 * g0 + wk.t1 * g1 + t2 * g2);
+        }
+        wk.next();
+      }
+    }
+
+    // ---- residual / scaling and the global store ---------------------------------------
+    opaque(goff); opaque(loff);
 #pragma unroll
     for (int k = 0; k < EPT; ++k) {
-      if (tid + k * B < tot) {
-        const int t2 = wk.t2u * VEC;
-        const int go = wk.t0 * g0 + wk.t1 * g1 + t2 * g2;
+      if (goff[k] >= 0) {
         VecT<VEC> y;
-        y.load(lds + wk.t0 * L0 + wk.t1 * L1 + t2);
-        if (JVP && P.epi == EPI_MUL) {
+        y.load(lds + loff[k]);
+        if (MULE) {
 #pragma unroll
           for (int j = 0; j < VEC; ++j) {
-            y.v[j] *= aux[k].v[j];
-            if (P.minus_identity) y.v[j] -= val[k].v[j];
+            y.v[j] *= c2v[MULE ? k : 0].v[j];
+            if (P.minus_identity) y.v[j] -= oldv[(CES || MULE) ? k : 0].v[j];
           }
-        } else if (!JVP && need_old) {
+        } else if (CES && need_old) {
 #pragma unroll
           for (int j = 0; j < VEC; ++j) {
-            double r = fabs(y.v[j] - val[k].v[j]);
+            double r = fabs(y.v[j] - oldv[(CES || MULE) ? k : 0].v[j]);
             if (!(r == r)) r = __longlong_as_double(0x7ff0000000000000LL);   // NaN -> +inf
             rmax = fmax(rmax, r);
           }
         }
-        y.store(io.out + gbase + go);
+        y.store(io.out + cur.gbase + goff[k]);
       }
-      wk.next();
     }
+    if (!has_next) break;
+    __syncthreads();            // every read of this tile's LDS image is done before the next park
+    cur = nxt;
+    tile = ntile;
   }
 
-  if (!JVP && io.resid != nullptr && (P.epi == EPI_CES || P.epi == EPI_CES_LIN)) {
+  if (CES && io.resid != nullptr) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) rmax = fmax(rmax, __shfl_xor(rmax, o));
+    __syncthreads();
     if (lane == 0) red[wave] = rmax;
     __syncthreads();
     if (tid == 0) {
@@ -480,10 +562,10 @@ __global__ void __launch_bounds__(256) debug_pow_kernel(const double* __restrict
 
 typedef void (*pass_fn)(const PassDesc, const PassIO);
 
-// EPT in {1,2,4,8,16}, VEC in {1,2}, JVP in {false,true}
-inline pass_fn pass_kernel_variant(int ept, int vec, bool jvp) {
-#define SDFS_V(E) (jvp ? (vec == 2 ? (pass_fn)pass_kernel<E, 2, true> : (pass_fn)pass_kernel<E, 1, true>) \
-                       : (vec == 2 ? (pass_fn)pass_kernel<E, 2, false> : (pass_fn)pass_kernel<E, 1, false>))
+// EPT in {1,2,4,8,16}, VEC in {1,2}, MODE in PassMode
+template <int MODE>
+inline pass_fn pass_kernel_variant_m(int ept, int vec) {
+#define SDFS_V(E) (vec == 2 ? (pass_fn)pass_kernel<E, 2, MODE> : (pass_fn)pass_kernel<E, 1, MODE>)
   switch (ept) {
     case 1: return SDFS_V(1);
     case 2: return SDFS_V(2);
@@ -493,6 +575,17 @@ inline pass_fn pass_kernel_variant(int ept, int vec, bool jvp) {
     default: return nullptr;
   }
 #undef SDFS_V
+}
+inline pass_fn pass_kernel_variant(int ept, int vec, int mode) {
+  switch (mode) {
+    case M_MID: return pass_kernel_variant_m<M_MID>(ept, vec);
+    case M_TFIRST: return pass_kernel_variant_m<M_TFIRST>(ept, vec);
+    case M_TLAST: return pass_kernel_variant_m<M_TLAST>(ept, vec);
+    case M_TONLY: return pass_kernel_variant_m<M_TONLY>(ept, vec);
+    case M_JFIRST: return pass_kernel_variant_m<M_JFIRST>(ept, vec);
+    case M_JLAST: return pass_kernel_variant_m<M_JLAST>(ept, vec);
+    default: return nullptr;
+  }
 }
 
 }  // namespace sdfs

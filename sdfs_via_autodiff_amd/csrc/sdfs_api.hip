@@ -71,6 +71,7 @@ struct sdfs_handle {
   hipStream_t own_stream = nullptr;
   hipStream_t stream = nullptr;
   int model = 0, ndim = 0;
+  int num_cus = 256;
   int shape[MAXD] = {1, 1, 1, 1, 1, 1};
   long long N = 0;
   double theta = 0, beta = 0;
@@ -396,11 +397,21 @@ int launch_pass(sdfs_handle* h, Pass& P, int pro, int epi, const PassIO& io, int
   }
   auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
   const bool v2 = P.vec2 && al16(io.in) && al16(io.out) && al16(io.aux_in) && al16(io.aux_out) && al16(io.old);
-  const bool jvp = (pro == PRO_MUL || epi == EPI_MUL || (pro == PRO_NONE && epi == EPI_NONE && tag[0] == 'j'));
-  pass_fn fn = pass_kernel_variant(v2 ? P.ept2 : P.ept1, v2 ? 2 : 1, jvp);
+  int mode = M_MID;
+  if (pro == PRO_POW || pro == PRO_POW_LIN) mode = (epi == EPI_CES || epi == EPI_CES_LIN) ? M_TONLY : M_TFIRST;
+  else if (epi == EPI_CES || epi == EPI_CES_LIN) mode = M_TLAST;
+  else if (pro == PRO_MUL) mode = M_JFIRST;
+  else if (epi == EPI_MUL) mode = M_JLAST;
+  if (pro == PRO_MUL && epi == EPI_MUL) return fail(h, SDFS_ERR_UNSUPPORTED, "single-pass JVP not supported");
+  pass_fn fn = pass_kernel_variant(v2 ? P.ept2 : P.ept1, v2 ? 2 : 1, mode);
   if (!fn) return fail(h, SDFS_ERR_UNSUPPORTED, "no kernel variant for EPT %d", v2 ? P.ept2 : P.ept1);
+  // persistent grid: as many blocks as the chip holds at once (LDS- and thread-limited)
+  int per_cu = (int)std::min<size_t>(8, (160 * 1024) / (P.lds_bytes + 256));
+  per_cu = std::max(1, std::min(per_cu, 1024 / P.block));
+  per_cu = env_int("SDFS_BLOCKS_PER_CU", per_cu);
+  const long long grid = std::min<long long>(d.ntiles, (long long)per_cu * h->num_cus);
   ProfScope ps(h, cid);
-  hipLaunchKernelGGL(fn, dim3((unsigned)d.ntiles), dim3(P.block), P.lds_bytes, h->stream, d, io);
+  hipLaunchKernelGGL(fn, dim3((unsigned)grid), dim3(P.block), P.lds_bytes, h->stream, d, io);
   HIPCHK(h, hipGetLastError());
   return 0;
 }
@@ -869,14 +880,18 @@ int create_common(int model, int ndim, const int64_t* shapes, const double* para
   if (hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking) != hipSuccess)
     return bail(fail(h, SDFS_ERR_HIP, "hipStreamCreate failed"));
   h->stream = h->own_stream;
+  {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0) h->num_cus = prop.multiProcessorCount;
+  }
   int rc = setup_model(h, model, ndim, shapes, params, nparams, arrays, sizes, narrays);
   if (rc) return bail(rc);
   static bool attr_set = false;
   if (!attr_set) {
     for (int e = 1; e <= 16; e <<= 1)
       for (int v = 1; v <= 2; ++v)
-        for (int j = 0; j < 2; ++j)
-          hipFuncSetAttribute((const void*)pass_kernel_variant(e, v, j != 0), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
+        for (int j = 0; j < 6; ++j)
+          hipFuncSetAttribute((const void*)pass_kernel_variant(e, v, j), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
     attr_set = true;
   }
   std::vector<int> all;
