@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsdfs_hip.so")
+LIB_PATH = os.path.join(_HERE, os.environ.get("SDFS_LIB_NAME", "libsdfs_hip.so"))   # SDFS_LIB_NAME: diagnostic builds
 
 SDFS_MODEL_SSY, SDFS_MODEL_GCY = 0, 1
 SDFS_ALGO_SA, SDFS_ALGO_NEWTON, SDFS_ALGO_ANDERSON = 0, 1, 2

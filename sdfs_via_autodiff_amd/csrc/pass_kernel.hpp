@@ -77,6 +77,7 @@ struct PassIO {
   unsigned long long* resid;        // EPI_CES: atomicMax target (bits of a non-negative double) or null
   const unsigned long long* gate;   // if non-null and *gate <= tol bits: the iteration has converged, do nothing
   double gate_tol;
+  unsigned long long* dbg;          // diagnostic builds (-DSDFS_STAMP): per-phase s_memtime stamps
 };
 
 typedef double v4d __attribute__((ext_vector_type(4)));
@@ -194,6 +195,12 @@ template <> struct VecT<2> {
     double2 t; t.x = v[0]; t.y = v[1]; *reinterpret_cast<double2*>(p) = t; }
 };
 
+// One contraction y[i, col] = sum_I Q[i, I] x[I, col] over the columns of the LDS tile.
+// Output rows are covered by n16 row tiles of v_mfma_f64_16x16x4_f64 (64 cycles, 16 rows)
+// plus n4 row tiles of v_mfma_f64_4x4x4_4b_f64 (20 cycles, 4 rows x 4 blocks of 4 columns):
+// for n = 20 that is 84 cycles per k-step instead of 128 for two 16-row tiles.  Both shapes
+// take the same B operand (lane l holds x[4kk + (l>>4)][col0 + (l&15)]).
+//   n <= 12: (0, ceil(n/4));  13..16: (1, 0);  17..24: (1, ceil((n-16)/4));  25..32: (2, 0)
 __device__ __forceinline__ void contract_step(double* __restrict__ lds, const PassDesc& P, const int s,
                                               const int lane, const int wave, const int nwaves) {
   const int slot = P.sslot[s];
@@ -205,16 +212,16 @@ __device__ __forceinline__ void contract_step(double* __restrict__ lds, const Pa
   else { Ls = 1; Lu = P.L[0]; mu = P.m[0]; Lv = P.L[1]; mv = P.m[1]; }
   const int ncols = mu * mv;
   const int KT = (n + 3) >> 2;
-  const bool mt2 = n > 16;
-  const int li = lane & 15, lk = lane >> 4;
+  const int n16 = n <= 12 ? 0 : (n <= 24 ? 1 : 2);
+  const int n4 = n <= 12 ? (n + 3) >> 2 : (n <= 16 ? 0 : (n <= 24 ? (n - 13) >> 2 : 0));
+  const int li = lane & 15, lk = lane >> 4, l4 = lane & 3;
 
-  // A operand: Q[i][I], lane holds A[m = lane&15][k = lane>>4] per k-step (f64 16x16x4 map).
-  // Fragments are re-read from the LDS-staged matrix per k-step: keeping all 16 of them in
-  // registers cost 32 VGPRs that the next tile's prefetch needs; out-of-range rows/columns
-  // read element 0 and are masked to zero.
-  const int qrow0 = (li < n ? li : 0) * n;
-  const int qrow1 = (16 + li < n ? 16 + li : 0) * n;
-  const bool r0ok = li < n, r1ok = 16 + li < n;
+  // A operand rows of this lane (clamped to row 0 and masked when out of range)
+  const bool r16a = n16 > 0 && li < n, r16b = n16 > 1 && 16 + li < n;
+  const int q16a = (r16a ? li : 0) * n, q16b = (r16b ? 16 + li : 0) * n;
+  const int rb = 16 * n16;
+  const bool r4a = n4 > 0 && rb + l4 < n, r4b = n4 > 1 && rb + 4 + l4 < n, r4c = n4 > 2 && rb + 8 + l4 < n;
+  const int q4a = (r4a ? rb + l4 : 0) * n, q4b = (r4b ? rb + 4 + l4 : 0) * n, q4c = (r4c ? rb + 8 + l4 : 0) * n;
 
   for (int ct = wave; ct * 16 < ncols; ct += nwaves) {
     const int col = ct * 16 + li;
@@ -224,6 +231,7 @@ __device__ __forceinline__ void contract_step(double* __restrict__ lds, const Pa
     const int cbase = cu * Lu + cv * Lv;
     v4d acc0 = {0.0, 0.0, 0.0, 0.0};
     v4d acc1 = {0.0, 0.0, 0.0, 0.0};
+    double d0 = 0.0, d1 = 0.0, d2 = 0.0;
 #pragma unroll
     for (int kk = 0; kk < 8; ++kk) {
       if (kk < KT) {
@@ -231,28 +239,48 @@ __device__ __forceinline__ void contract_step(double* __restrict__ lds, const Pa
         const bool iok = I0 < n;
         const int I = iok ? I0 : n - 1;     // rows >= n meet zero Q columns; keep the read in bounds
         const double b = lds[cbase + I * Ls];
-        const double a0 = Qm[qrow0 + I];
-        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64((r0ok && iok) ? a0 : 0.0, b, acc0, 0, 0, 0);
-        if (mt2) {
-          const double a1 = Qm[qrow1 + I];
-          acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64((r1ok && iok) ? a1 : 0.0, b, acc1, 0, 0, 0);
+        if (n16 > 0) {
+          const double a = Qm[q16a + I];
+          acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64((r16a && iok) ? a : 0.0, b, acc0, 0, 0, 0);
+        }
+        if (n16 > 1) {
+          const double a = Qm[q16b + I];
+          acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64((r16b && iok) ? a : 0.0, b, acc1, 0, 0, 0);
+        }
+        if (n4 > 0) {
+          const double a = Qm[q4a + I];
+          d0 = __builtin_amdgcn_mfma_f64_4x4x4f64((r4a && iok) ? a : 0.0, b, d0, 0, 0, 0);
+        }
+        if (n4 > 1) {
+          const double a = Qm[q4b + I];
+          d1 = __builtin_amdgcn_mfma_f64_4x4x4f64((r4b && iok) ? a : 0.0, b, d1, 0, 0, 0);
+        }
+        if (n4 > 2) {
+          const double a = Qm[q4c + I];
+          d2 = __builtin_amdgcn_mfma_f64_4x4x4f64((r4c && iok) ? a : 0.0, b, d2, 0, 0, 0);
         }
       }
     }
-    // D map of v_mfma_f64_16x16x4_f64: col = lane&15, row = (lane>>4) + 4*reg
     if (col < ncols) {
+      // 16x16x4 D map: col = lane&15, row = (lane>>4) + 4*reg
+      if (n16 > 0) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int i = lk + 4 * r;
-        if (i < n) lds[cbase + i * Ls] = acc0[r];
+        for (int r = 0; r < 4; ++r) {
+          const int i = lk + 4 * r;
+          if (i < n) lds[cbase + i * Ls] = acc0[r];
+        }
       }
-      if (mt2) {
+      if (n16 > 1) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int i = 16 + lk + 4 * r;
           if (i < n) lds[cbase + i * Ls] = acc1[r];
         }
       }
+      // 4x4x4_4b D map: lane = i*16 + blk*4 + j -> row = lane>>4, col = lane&15 (one value per lane)
+      if (n4 > 0 && rb + lk < n) lds[cbase + (rb + lk) * Ls] = d0;
+      if (n4 > 1 && rb + 4 + lk < n) lds[cbase + (rb + 4 + lk) * Ls] = d1;
+      if (n4 > 2 && rb + 8 + lk < n) lds[cbase + (rb + 8 + lk) * Ls] = d2;
     }
   }
 }
@@ -266,8 +294,23 @@ __device__ __forceinline__ void opaque(int (&a)[N]) {
   for (int k = 0; k < N; ++k) asm volatile("" : "+v"(a[k]));
 }
 
+#ifdef SDFS_STAMP
+#define STAMP(slot)                                                                        \
+  do {                                                                                     \
+    __builtin_amdgcn_sched_barrier(0);                                                     \
+    unsigned long long t_;                                                                 \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");             \
+    __builtin_amdgcn_sched_barrier(0);                                                     \
+    if (io.dbg != nullptr && threadIdx.x == 0 && blockIdx.x < 64 && trip < 2)              \
+      io.dbg[(blockIdx.x * 2 + trip) * 16 + (slot)] = t_;                                   \
+  } while (0)
+#else
+#define STAMP(slot) do {} while (0)
+#endif
+
 // Compile-time role of a launch inside one operator application.
-enum PassMode { M_MID = 0, M_TFIRST = 1, M_TLAST = 2, M_TONLY = 3, M_JFIRST = 4, M_JLAST = 5 };
+enum PassMode { M_MID = 0, M_TFIRST = 1, M_TLAST = 2, M_TONLY = 3, M_JFIRST = 4, M_JLAST = 5,
+                M_TFIRST_LIN = 6, M_TLAST_LIN = 7, M_NMODES = 8 };
 
 struct TileCtx {
   long long gbase;
@@ -297,20 +340,25 @@ __device__ __forceinline__ TileCtx decode_tile(const PassDesc& P, long long tile
   return c;
 }
 
-// Persistent pass kernel: the grid holds as many blocks as fit on the chip; each block
-// walks a strided sequence of tiles inside its XCD's contiguous chunk and prefetches
-// tile t+1 into registers while tile t goes through LDS (park -> pow -> MFMA -> pow -> store).
-// Every tile of a pass has the same geometry, so each thread computes the global / LDS
-// offsets of its EPT units ONCE (goff / loff) and reuses them for every tile and phase.
+// One workgroup per tile.  Phases (each thread revisits the same EPT units of VEC doubles):
+//   load   : all global loads of the thread issued back to back (tile, c1 for the JVP, and the
+//            transition matrices of the block's steps), then parked in LDS
+//   pow    : x = a1 w^theta in place in LDS (first pass of T)
+//   MFMA   : up to three contractions in place in LDS
+//   pow    : Tw = 1 + beta (K S)^(1/theta) in place in LDS (last pass of T)
+//   store  : residual / JVP scaling and the global store
+// Two 512-thread workgroups share a CU (LDS-limited), so one block's memory phases overlap the
+// other's MFMA / pow phases.  MODE is the compile-time role of the launch.
 template <int EPT, int VEC, int MODE>
 __global__ void __launch_bounds__(512, 4)
 pass_kernel(const PassDesc P, const PassIO io) {
-  constexpr bool POWP = (MODE == M_TFIRST || MODE == M_TONLY);   // x = a1 w^theta while parking
-  constexpr bool CES = (MODE == M_TLAST || MODE == M_TONLY);     // Tw = 1 + beta (K S)^(1/theta)
+  constexpr bool POWP = (MODE == M_TFIRST || MODE == M_TONLY || MODE == M_TFIRST_LIN);   // x = a1 w^theta
+  constexpr bool CES = (MODE == M_TLAST || MODE == M_TONLY || MODE == M_TLAST_LIN);      // Tw = 1 + beta (K S)^(1/theta)
+  constexpr bool LINP = (MODE == M_TFIRST_LIN);                  // also write c1 = a1 w^(theta-1)
+  constexpr bool LINE = (MODE == M_TLAST_LIN);                   // also write c2 = beta u / S
   constexpr bool MULP = (MODE == M_JFIRST);                      // x = c1 * v
   constexpr bool MULE = (MODE == M_JLAST);                       // out = c2 * y (- v)
   constexpr int NAUX = MULP ? EPT : 1;
-  constexpr int NOLD = (CES || MULE) ? EPT : 1;
   constexpr int NC2 = MULE ? EPT : 1;
   extern __shared__ double lds[];
   __shared__ double red[16];
@@ -323,17 +371,10 @@ pass_kernel(const PassDesc P, const PassIO io) {
   const int tid = threadIdx.x;
   const int B = blockDim.x;
   const int lane = tid & 63, wave = tid >> 6, nwaves = B >> 6;
+  const int trip = 0;
+  (void)trip;
 
-  // tile sequence of this block: XCD label x owns one contiguous chunk of tiles; its
-  // nbx blocks sweep it together (neighbouring tiles run at the same time on one L2)
-  const long long G = gridDim.x;
-  const long long xl = blockIdx.x & 7, jl = blockIdx.x >> 3;
-  const long long nbx = (G - xl + 7) >> 3;
-  const long long q8 = P.ntiles >> 3, r8 = P.ntiles & 7;
-  const long long cstart = (xl < r8) ? xl * (q8 + 1) : r8 * (q8 + 1) + (xl - r8) * q8;
-  const long long cend = cstart + q8 + (xl < r8 ? 1 : 0);
-  long long tile = cstart + jl;
-  if (tile >= cend) return;
+  const TileCtx cur = decode_tile(P, xcd_remap((long long)blockIdx.x, P.ntiles));
 
   const int m1 = P.m[1];
   const int m2u = P.m[2] / VEC;
@@ -342,204 +383,187 @@ pass_kernel(const PassDesc P, const PassIO io) {
   const int L0 = P.L[0], L1 = P.L[1];
   const int g0 = P.gstride[0], g1 = P.gstride[1], g2 = P.gstride[2];
 
-  // per-thread unit offsets, identical for every tile of the pass
-  int goff[EPT], loff[EPT];
+  STAMP(0);
+  // ---- load phase ------------------------------------------------------------------
   {
+    // transition matrices first (they come from L2; vmcnt retires in order)
+    const int nq0 = P.nsteps > 0 ? P.sn[0] * P.sn[0] : 0;
+    const int nq1 = P.nsteps > 1 ? P.sn[1] * P.sn[1] : 0;
+    const int nq2 = P.nsteps > 2 ? P.sn[2] * P.sn[2] : 0;
+    const double* Q0 = P.Q[0] + (long long)cur.q0 * nq0;
+    const double* Q1 = P.Q[1] + (long long)cur.q1 * nq1;
+    const double* Q2 = P.Q[2] + (long long)cur.q2 * nq2;
+    double qv0[2], qv1[2], qv2[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const int i = tid + r * B;
+      qv0[r] = i < nq0 ? Q0[i] : 0.0;
+      qv1[r] = i < nq1 ? Q1[i] : 0.0;
+      qv2[r] = i < nq2 ? Q2[i] : 0.0;
+    }
+    VecT<VEC> val[EPT];
+    VecT<VEC> aux[NAUX];
     Walker wk;
     wk.init(tid, B, m1, m2u);
 #pragma unroll
     for (int k = 0; k < EPT; ++k) {
-      const bool valid = tid + k * B < tot;
-      goff[k] = valid ? wk.t0 * g0 + wk.t1 * g1 + wk.t2u * VEC * g2 : -1;
-      loff[k] = valid ? wk.t0 * L0 + wk.t1 * L1 + wk.t2u * VEC : 0;
+      if (tid + k * B < tot) {
+        const int go = wk.t0 * g0 + wk.t1 * g1 + wk.t2u * VEC * g2;
+        val[k].load(io.in + cur.gbase + go);
+        if (MULP) aux[MULP ? k : 0].load(io.aux_in + cur.gbase + go);
+      }
       wk.next();
     }
-  }
-
-  PowLane PT;
-  if (POWP || CES) PT = pow_lane_init(lane);
-
-  TileCtx cur = decode_tile(P, tile);
-  VecT<VEC> val[EPT];
-  VecT<VEC> aux[NAUX];
 #pragma unroll
-  for (int k = 0; k < EPT; ++k) {
-    if (goff[k] >= 0) {
-      val[k].load(io.in + cur.gbase + goff[k]);
-      if (MULP) aux[MULP ? k : 0].load(io.aux_in + cur.gbase + goff[k]);
+    for (int r = 0; r < 2; ++r) {
+      const int i = tid + r * B;
+      if (i < nq0) lds[P.qlds[0] + i] = qv0[r];
+      if (i < nq1) lds[P.qlds[1] + i] = qv1[r];
+      if (i < nq2) lds[P.qlds[2] + i] = qv2[r];
     }
-  }
-
-  int qp0 = -1, qp1 = -1, qp2 = -1;
-  double rmax = 0.0;
-
-  for (;;) {
-    // Per-lane values are re-derived from an opaque copy of the thread id in every trip:
-    // otherwise LICM hoists every lane-dependent invariant of the body (MFMA operand
-    // addresses, walker state, ...) out of the tile loop and spills dozens of them.
-    int tid_o = threadIdx.x;
-    asm volatile("" : "+v"(tid_o));
-    const int tid = tid_o;
-    const int lane = tid & 63, wave = tid >> 6;
-    // ---- park the prefetched tile in LDS ------------------------------------------
-    opaque(goff); opaque(loff);
+    // matrices larger than 2*B entries (n = 32 with small blocks): plain loop for the rest
+    for (int i = tid + 2 * B; i < nq0; i += B) lds[P.qlds[0] + i] = Q0[i];
+    for (int i = tid + 2 * B; i < nq1; i += B) lds[P.qlds[1] + i] = Q1[i];
+    for (int i = tid + 2 * B; i < nq2; i += B) lds[P.qlds[2] + i] = Q2[i];
+    STAMP(1);
+    wk.init(tid, B, m1, m2u);
 #pragma unroll
     for (int k = 0; k < EPT; ++k) {
-      if (goff[k] >= 0) {
+      if (tid + k * B < tot) {
         if (MULP) {
 #pragma unroll
           for (int j = 0; j < VEC; ++j) val[k].v[j] *= aux[MULP ? k : 0].v[j];
         }
-        val[k].store(lds + loff[k]);
+        val[k].store(lds + wk.t0 * L0 + wk.t1 * L1 + wk.t2u * VEC);
       }
+      wk.next();
     }
-    // ---- prefetch the next tile (stays in flight during all the compute below) -------
-    const long long ntile = tile + nbx;
-    const bool has_next = ntile < cend;
-    TileCtx nxt = cur;
-    if (has_next) {
-      nxt = decode_tile(P, ntile);
-      opaque(goff);
-#pragma unroll
-      for (int k = 0; k < EPT; ++k) {
-        if (goff[k] >= 0) {
-          val[k].load(io.in + nxt.gbase + goff[k]);
-          if (MULP) aux[MULP ? k : 0].load(io.aux_in + nxt.gbase + goff[k]);
-        }
-      }
-    }
-    // ---- stage the transition matrices (only when the conditioning index changed) ----
-    if (P.nsteps > 0 && cur.q0 != qp0) {
-      const int nq = P.sn[0] * P.sn[0];
-      const double* Q = P.Q[0] + (long long)cur.q0 * nq;
-      for (int i = tid; i < nq; i += B) lds[P.qlds[0] + i] = Q[i];
-      qp0 = cur.q0;
-    }
-    if (P.nsteps > 1 && cur.q1 != qp1) {
-      const int nq = P.sn[1] * P.sn[1];
-      const double* Q = P.Q[1] + (long long)cur.q1 * nq;
-      for (int i = tid; i < nq; i += B) lds[P.qlds[1] + i] = Q[i];
-      qp1 = cur.q1;
-    }
-    if (P.nsteps > 2 && cur.q2 != qp2) {
-      const int nq = P.sn[2] * P.sn[2];
-      const double* Q = P.Q[2] + (long long)cur.q2 * nq;
-      for (int i = tid; i < nq; i += B) lds[P.qlds[2] + i] = Q[i];
-      qp2 = cur.q2;
-    }
+  }
+  STAMP(2);
 
-    // ---- prologue x = a1 w^theta, in place in LDS (each thread revisits its own units).
-    //      Uniform trip count: pow_fast needs every lane of the wave active.
-    if (POWP) {
-      Walker wk;
-      wk.init(tid, B, m1, m2u);
+  PowLane PT;
+  if (POWP || CES) PT = pow_lane_init(lane);
+
+  // ---- prologue x = a1 w^theta, in place in LDS (each thread revisits its own units).
+  //      Uniform trip count: pow_fast needs every lane of the wave active.
+  if (POWP) {
+    Walker wk;
+    wk.init(tid, B, m1, m2u);
 #pragma unroll 1
-      for (int it = 0; it < iters; ++it) {
-        const bool valid = tid + it * B < tot;
-        const int t2 = wk.t2u * VEC;
-        const int lo = valid ? wk.t0 * L0 + wk.t1 * L1 + t2 : 0;
-        const int i1 = valid ? cur.ia1b + wk.t0 * P.ta1[0] + wk.t1 * P.ta1[1] + t2 * P.ta1[2] : 0;
-        VecT<VEC> x, c1;
-        x.load(lds + lo);
+    for (int it = 0; it < iters; ++it) {
+      const bool valid = tid + it * B < tot;
+      const int t2 = wk.t2u * VEC;
+      const int lo = valid ? wk.t0 * L0 + wk.t1 * L1 + t2 : 0;
+      const int i1 = valid ? cur.ia1b + wk.t0 * P.ta1[0] + wk.t1 * P.ta1[1] + t2 * P.ta1[2] : 0;
+      VecT<VEC> x, c1;
+      x.load(lds + lo);
 #pragma unroll
-        for (int j = 0; j < VEC; ++j) {
-          const double xin = valid ? x.v[j] : 1.0;
-          const double xw = P.a1[valid ? i1 + j * P.ta1[2] : 0] * pow_fast(xin, P.theta, PT);
-          c1.v[j] = xw / xin;                                     // c1 = a1 w^(theta-1)
-          x.v[j] = xw;
-        }
-        if (valid) {
-          x.store(lds + lo);
-          if (P.pro == PRO_POW_LIN) c1.store(io.aux_out + cur.gbase + wk.t0 * g0 + wk.t1 * g1 + t2 * g2);
-        }
-        wk.next();
+      for (int j = 0; j < VEC; ++j) {
+        const double xin = valid ? x.v[j] : 1.0;
+        const double xw = P.a1[valid ? i1 + j * P.ta1[2] : 0] * pow_fast(xin, P.theta, PT);
+        if (LINP) c1.v[j] = xw / xin;                           // c1 = a1 w^(theta-1)
+        x.v[j] = xw;
       }
+      if (valid) {
+        x.store(lds + lo);
+        if (LINP) c1.store(io.aux_out + cur.gbase + wk.t0 * g0 + wk.t1 * g1 + t2 * g2);
+      }
+      wk.next();
     }
-    __syncthreads();
+  }
+  STAMP(3);
+  __syncthreads();
+  STAMP(4);
 
-    // ---- contractions ----------------------------------------------------------------
-    if (P.nsteps > 0) { contract_step(lds, P, 0, lane, wave, nwaves); __syncthreads(); }
-    if (P.nsteps > 1) { contract_step(lds, P, 1, lane, wave, nwaves); __syncthreads(); }
-    if (P.nsteps > 2) { contract_step(lds, P, 2, lane, wave, nwaves); __syncthreads(); }
+  // ---- contractions ------------------------------------------------------------------
+  if (P.nsteps > 0) { contract_step(lds, P, 0, lane, wave, nwaves); STAMP(5); __syncthreads(); }
+  STAMP(6);
+  if (P.nsteps > 1) { contract_step(lds, P, 1, lane, wave, nwaves); STAMP(7); __syncthreads(); }
+  STAMP(8);
+  if (P.nsteps > 2) { contract_step(lds, P, 2, lane, wave, nwaves); STAMP(9); __syncthreads(); }
+  STAMP(10);
 
-    // ---- final-stage operands of THIS tile: issue now, consume after the aggregator ----
-    const bool need_old = CES ? (io.resid != nullptr) : (MULE && P.minus_identity);
-    VecT<VEC> oldv[NOLD];
+  // ---- aggregator Tw = 1 + beta (K S)^(1/theta), in place in LDS (rolled, uniform) ------
+  if (CES) {
+    Walker wk;
+    wk.init(tid, B, m1, m2u);
+#pragma unroll 1
+    for (int it = 0; it < iters; ++it) {
+      const bool valid = tid + it * B < tot;
+      const int t2 = wk.t2u * VEC;
+      const int lo = valid ? wk.t0 * L0 + wk.t1 * L1 + t2 : 0;
+      const int i2 = valid ? cur.ia2b + wk.t0 * P.ta2[0] + wk.t1 * P.ta2[1] + t2 * P.ta2[2] : 0;
+      const int i3 = valid ? cur.ia3b + wk.t0 * P.ta3[0] + wk.t1 * P.ta3[1] + t2 * P.ta3[2] : 0;
+      VecT<VEC> y, c2;
+      y.load(lds + lo);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        const double sv = valid ? y.v[j] : 1.0;
+        const double ks = P.a2[valid ? i2 + j * P.ta2[2] : 0] * P.a3[valid ? i3 + j * P.ta3[2] : 0] * sv;
+        const double uu = pow_fast(ks, P.inv_theta, PT);
+        if (LINE) c2.v[j] = P.beta * uu / sv;                   // c2 = beta K (K S)^(1/theta-1) = beta u / S
+        y.v[j] = 1.0 + P.beta * uu;
+      }
+      if (valid) {
+        y.store(lds + lo);
+        if (LINE) c2.store(io.aux_out + cur.gbase + wk.t0 * g0 + wk.t1 * g1 + t2 * g2);
+      }
+      wk.next();
+    }
+  }
+  STAMP(11);
+
+  // ---- residual / scaling and the global store -------------------------------------------
+  const bool need_old = CES ? (io.resid != nullptr) : (MULE && P.minus_identity);
+  double rmax = 0.0;
+  {
+    VecT<VEC> oldv[EPT];
     VecT<VEC> c2v[NC2];
+    Walker wk;
     if (CES || MULE) {
-      opaque(goff);
+      wk.init(tid, B, m1, m2u);
 #pragma unroll
       for (int k = 0; k < EPT; ++k) {
-        if (goff[k] >= 0) {
-          if (need_old) oldv[(CES || MULE) ? k : 0].load(io.old + cur.gbase + goff[k]);
-          if (MULE) c2v[MULE ? k : 0].load(io.aux_in + cur.gbase + goff[k]);
-        }
-      }
-    }
-
-    // ---- aggregator Tw = 1 + beta (K S)^(1/theta), in place in LDS (rolled, uniform) ----
-    if (CES) {
-      Walker wk;
-      wk.init(tid, B, m1, m2u);
-#pragma unroll 1
-      for (int it = 0; it < iters; ++it) {
-        const bool valid = tid + it * B < tot;
-        const int t2 = wk.t2u * VEC;
-        const int lo = valid ? wk.t0 * L0 + wk.t1 * L1 + t2 : 0;
-        const int i2 = valid ? cur.ia2b + wk.t0 * P.ta2[0] + wk.t1 * P.ta2[1] + t2 * P.ta2[2] : 0;
-        const int i3 = valid ? cur.ia3b + wk.t0 * P.ta3[0] + wk.t1 * P.ta3[1] + t2 * P.ta3[2] : 0;
-        VecT<VEC> y, c2;
-        y.load(lds + lo);
-#pragma unroll
-        for (int j = 0; j < VEC; ++j) {
-          const double sv = valid ? y.v[j] : 1.0;
-          const double ks = P.a2[valid ? i2 + j * P.ta2[2] : 0] * P.a3[valid ? i3 + j * P.ta3[2] : 0] * sv;
-          const double uu = pow_fast(ks, P.inv_theta, PT);
-          c2.v[j] = P.beta * uu / sv;                             // c2 = beta K (K S)^(1/theta-1) = beta u / S
-          y.v[j] = 1.0 + P.beta * uu;
-        }
-        if (valid) {
-          y.store(lds + lo);
-          if (P.epi == EPI_CES_LIN) c2.store(io.aux_out + cur.gbase + wk.t0 * g0 + wk.t1 * g1 + t2 * g2);
+        if (tid + k * B < tot) {
+          const int go = wk.t0 * g0 + wk.t1 * g1 + wk.t2u * VEC * g2;
+          if (need_old) oldv[k].load(io.old + cur.gbase + go);
+          if (MULE) c2v[MULE ? k : 0].load(io.aux_in + cur.gbase + go);
         }
         wk.next();
       }
     }
-
-    // ---- residual / scaling and the global store ---------------------------------------
-    opaque(goff); opaque(loff);
+    wk.init(tid, B, m1, m2u);
 #pragma unroll
     for (int k = 0; k < EPT; ++k) {
-      if (goff[k] >= 0) {
+      if (tid + k * B < tot) {
+        const int t2 = wk.t2u * VEC;
+        const int go = wk.t0 * g0 + wk.t1 * g1 + t2 * g2;
         VecT<VEC> y;
-        y.load(lds + loff[k]);
+        y.load(lds + wk.t0 * L0 + wk.t1 * L1 + t2);
         if (MULE) {
 #pragma unroll
           for (int j = 0; j < VEC; ++j) {
             y.v[j] *= c2v[MULE ? k : 0].v[j];
-            if (P.minus_identity) y.v[j] -= oldv[(CES || MULE) ? k : 0].v[j];
+            if (P.minus_identity) y.v[j] -= oldv[k].v[j];
           }
         } else if (CES && need_old) {
 #pragma unroll
           for (int j = 0; j < VEC; ++j) {
-            double r = fabs(y.v[j] - oldv[(CES || MULE) ? k : 0].v[j]);
+            double r = fabs(y.v[j] - oldv[k].v[j]);
             if (!(r == r)) r = __longlong_as_double(0x7ff0000000000000LL);   // NaN -> +inf
             rmax = fmax(rmax, r);
           }
         }
-        y.store(io.out + cur.gbase + goff[k]);
+        y.store(io.out + cur.gbase + go);
       }
+      wk.next();
     }
-    if (!has_next) break;
-    __syncthreads();            // every read of this tile's LDS image is done before the next park
-    cur = nxt;
-    tile = ntile;
   }
+  STAMP(12);
 
   if (CES && io.resid != nullptr) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) rmax = fmax(rmax, __shfl_xor(rmax, o));
-    __syncthreads();
     if (lane == 0) red[wave] = rmax;
     __syncthreads();
     if (tid == 0) {
@@ -584,6 +608,8 @@ inline pass_fn pass_kernel_variant(int ept, int vec, int mode) {
     case M_TONLY: return pass_kernel_variant_m<M_TONLY>(ept, vec);
     case M_JFIRST: return pass_kernel_variant_m<M_JFIRST>(ept, vec);
     case M_JLAST: return pass_kernel_variant_m<M_JLAST>(ept, vec);
+    case M_TFIRST_LIN: return pass_kernel_variant_m<M_TFIRST_LIN>(ept, vec);
+    case M_TLAST_LIN: return pass_kernel_variant_m<M_TLAST_LIN>(ept, vec);
     default: return nullptr;
   }
 }

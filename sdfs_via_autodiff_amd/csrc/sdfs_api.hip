@@ -299,9 +299,10 @@ int build_plan(sdfs_handle* h, Plan& plan, const std::vector<int>& todo_in, std:
     }
     int fw = env_int("SDFS_FORCE_WAVES", 0);
     P.block = 64 * (fw > 0 ? fw : std::max(w_elem, w_mfma));
-    while ((tot + P.block - 1) / P.block > 16 && P.block < 512) P.block += 64;
     auto round_ept = [](long long e) { int r = 1; while (r < e) r <<= 1; return r; };
-    P.ept1 = round_ept((tot + P.block - 1) / P.block);
+    auto units_per_thread = [&](long long units) { return round_ept((units + P.block - 1) / P.block); };
+    while (units_per_thread(tot) > 16 && P.block < 512) P.block += 64;
+    P.ept1 = units_per_thread(tot);
     if (P.ept1 > 16) return fail(h, SDFS_ERR_UNSUPPORTED, "tile too large for one block");
     // 16-byte accesses: runs along slot 2 must be even, contiguous and every base even
     bool v2 = (d.m[2] % 2 == 0) && d.gstride[2] == 1 && (d.L[1] % 2 == 0) && (d.L[0] % 2 == 0) &&
@@ -309,7 +310,7 @@ int build_plan(sdfs_handle* h, Plan& plan, const std::vector<int>& todo_in, std:
               env_int("SDFS_NO_VEC2", 0) == 0;
     for (int k = 0; k < d.nfixed; ++k) if (d.fstride[k] % 2 != 0 && d.fext[k] > 1) v2 = false;
     P.vec2 = v2;
-    P.ept2 = v2 ? round_ept((tot / 2 + P.block - 1) / P.block) : P.ept1;
+    P.ept2 = v2 ? units_per_thread(tot / 2) : P.ept1;
     char lab[96];
     int o = snprintf(lab, sizeof lab, "expect[");
     for (int s = 0; s < d.nsteps; ++s) o += snprintf(lab + o, sizeof lab - o, "%s%s", s ? "," : "", h->ax[G[s]].name);
@@ -397,19 +398,49 @@ int launch_pass(sdfs_handle* h, Pass& P, int pro, int epi, const PassIO& io, int
   }
   auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
   const bool v2 = P.vec2 && al16(io.in) && al16(io.out) && al16(io.aux_in) && al16(io.aux_out) && al16(io.old);
+  if (!v2 && (long long)P.ept1 * P.block < (long long)d.m[0] * d.m[1] * d.m[2])
+    return fail(h, SDFS_ERR_ARG, "grid pointers must be 16-byte aligned for this tile shape");
   int mode = M_MID;
-  if (pro == PRO_POW || pro == PRO_POW_LIN) mode = (epi == EPI_CES || epi == EPI_CES_LIN) ? M_TONLY : M_TFIRST;
-  else if (epi == EPI_CES || epi == EPI_CES_LIN) mode = M_TLAST;
+  if (pro == PRO_POW || pro == PRO_POW_LIN) {
+    if (epi == EPI_CES) mode = M_TONLY;
+    else if (epi == EPI_CES_LIN) return fail(h, SDFS_ERR_UNSUPPORTED, "single-pass linearise not supported");
+    else mode = (pro == PRO_POW_LIN) ? M_TFIRST_LIN : M_TFIRST;
+  } else if (epi == EPI_CES || epi == EPI_CES_LIN) mode = (epi == EPI_CES_LIN) ? M_TLAST_LIN : M_TLAST;
   else if (pro == PRO_MUL) mode = M_JFIRST;
   else if (epi == EPI_MUL) mode = M_JLAST;
   if (pro == PRO_MUL && epi == EPI_MUL) return fail(h, SDFS_ERR_UNSUPPORTED, "single-pass JVP not supported");
   pass_fn fn = pass_kernel_variant(v2 ? P.ept2 : P.ept1, v2 ? 2 : 1, mode);
   if (!fn) return fail(h, SDFS_ERR_UNSUPPORTED, "no kernel variant for EPT %d", v2 ? P.ept2 : P.ept1);
-  // persistent grid: as many blocks as the chip holds at once (LDS- and thread-limited)
-  int per_cu = (int)std::min<size_t>(8, (160 * 1024) / (P.lds_bytes + 256));
-  per_cu = std::max(1, std::min(per_cu, 1024 / P.block));
-  per_cu = env_int("SDFS_BLOCKS_PER_CU", per_cu);
-  const long long grid = std::min<long long>(d.ntiles, (long long)per_cu * h->num_cus);
+  const long long grid = d.ntiles;
+#ifdef SDFS_STAMP
+  PassIO io2 = io;
+  static unsigned long long* dbg_dev = nullptr;
+  if (!dbg_dev) hipMalloc((void**)&dbg_dev, 64 * 2 * 16 * 8);
+  hipMemsetAsync(dbg_dev, 0, 64 * 2 * 16 * 8, h->stream);
+  io2.dbg = dbg_dev;
+  hipLaunchKernelGGL(fn, dim3((unsigned)grid), dim3(P.block), P.lds_bytes, h->stream, d, io2);
+  {
+    static int dumps = 0;
+    if (dumps < 12) {
+      std::vector<unsigned long long> hb(64 * 2 * 16);
+      hipStreamSynchronize(h->stream);
+      hipMemcpy(hb.data(), dbg_dev, hb.size() * 8, hipMemcpyDeviceToHost);
+      if (dumps >= 6) {
+        fprintf(stderr, "STAMP %s mode %d\n", P.label.c_str(), mode);
+        for (int b = 0; b < 64; b += 9) for (int t = 0; t < 2; ++t) {
+          fprintf(stderr, "  blk %2d trip %d:", b, t);
+          for (int k = 1; k < 14; ++k) {
+            unsigned long long a = hb[(b * 2 + t) * 16 + k - 1], c = hb[(b * 2 + t) * 16 + k];
+            fprintf(stderr, " %6lld", (a && c) ? (long long)(c - a) : -1LL);
+          }
+          fprintf(stderr, "\n");
+        }
+      }
+      ++dumps;
+    }
+  }
+  return 0;
+#endif
   ProfScope ps(h, cid);
   hipLaunchKernelGGL(fn, dim3((unsigned)grid), dim3(P.block), P.lds_bytes, h->stream, d, io);
   HIPCHK(h, hipGetLastError());
@@ -890,7 +921,7 @@ int create_common(int model, int ndim, const int64_t* shapes, const double* para
   if (!attr_set) {
     for (int e = 1; e <= 16; e <<= 1)
       for (int v = 1; v <= 2; ++v)
-        for (int j = 0; j < 6; ++j)
+        for (int j = 0; j < M_NMODES; ++j)
           hipFuncSetAttribute((const void*)pass_kernel_variant(e, v, j), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
     attr_set = true;
   }
