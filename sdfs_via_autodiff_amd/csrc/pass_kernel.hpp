@@ -196,11 +196,89 @@ template <> struct VecT<2> {
 };
 
 // One contraction y[i, col] = sum_I Q[i, I] x[I, col] over the columns of the LDS tile.
-// Output rows are covered by n16 row tiles of v_mfma_f64_16x16x4_f64 (64 cycles, 16 rows)
-// plus n4 row tiles of v_mfma_f64_4x4x4_4b_f64 (20 cycles, 4 rows x 4 blocks of 4 columns):
+// Output rows are covered by N16 row tiles of v_mfma_f64_16x16x4_f64 (64 cycles, 16 rows)
+// plus N4 row tiles of v_mfma_f64_4x4x4_4b_f64 (20 cycles, 4 rows x 4 blocks of 4 columns):
 // for n = 20 that is 84 cycles per k-step instead of 128 for two 16-row tiles.  Both shapes
 // take the same B operand (lane l holds x[4kk + (l>>4)][col0 + (l&15)]).
 //   n <= 12: (0, ceil(n/4));  13..16: (1, 0);  17..24: (1, ceil((n-16)/4));  25..32: (2, 0)
+// Everything that does not depend on the column tile is hoisted: the masked Q fragments sit
+// in registers, the row offsets of the B reads are precomputed (clamped in range), and the
+// column -> LDS offset map advances incrementally (no division in the loop).  The loop body
+// is then one address add + one ds_read_b64 per k-step next to the MFMAs.
+template <int N16, int N4>
+__device__ __forceinline__ void contract_cols(double* __restrict__ lds, const double* __restrict__ Qm,
+                                              const int n, const int KT, const int Ls, const int Lu,
+                                              const int Lv, const int mv, const int ncols,
+                                              const int lane, const int wave, const int nwaves) {
+  constexpr int A16 = N16 > 0 ? N16 : 1, A4 = N4 > 0 ? N4 : 1;
+  const int li = lane & 15, lk = lane >> 4, l4 = lane & 3;
+  constexpr int rb = 16 * N16;
+  double a16[A16][8], a4[A4][8];
+  int roff[8];
+#pragma unroll
+  for (int kk = 0; kk < 8; ++kk) {
+    const int I0 = 4 * kk + lk;
+    const bool iok = I0 < n;
+    const int I = iok ? I0 : n - 1;          // rows >= n meet zero Q columns; keep the read in bounds
+    roff[kk] = I * Ls;
+#pragma unroll
+    for (int t = 0; t < N16; ++t) {
+      const int row = 16 * t + li;
+      a16[t][kk] = (kk < KT && iok && row < n) ? Qm[row * n + I] : 0.0;
+    }
+#pragma unroll
+    for (int t = 0; t < N4; ++t) {
+      const int row = rb + 4 * t + l4;
+      a4[t][kk] = (kk < KT && iok && row < n) ? Qm[row * n + I] : 0.0;
+    }
+  }
+  // column walk: col = ct*16 + li, advancing by 16*nwaves per trip
+  int col = wave * 16 + li;
+  int cu = col / mv, cv = col - cu * mv;
+  const int adv = 16 * nwaves;
+  const int du = adv / mv, dv = adv - du * mv;
+
+  for (int ct = wave; ct * 16 < ncols; ct += nwaves) {
+    const bool colok = col < ncols;
+    const int cbase = colok ? cu * Lu + cv * Lv : (ncols - 1) / mv * Lu + ((ncols - 1) % mv) * Lv;
+    v4d acc[A16];
+    double d[A4];
+#pragma unroll
+    for (int t = 0; t < A16; ++t) acc[t] = (v4d){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int t = 0; t < A4; ++t) d[t] = 0.0;
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) {
+      if (kk < KT) {
+        const double b = lds[cbase + roff[kk]];
+#pragma unroll
+        for (int t = 0; t < N16; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a16[t][kk], b, acc[t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < N4; ++t) d[t] = __builtin_amdgcn_mfma_f64_4x4x4f64(a4[t][kk], b, d[t], 0, 0, 0);
+      }
+    }
+    if (colok) {
+      // 16x16x4 D map: col = lane&15, row = (lane>>4) + 4*reg
+#pragma unroll
+      for (int t = 0; t < N16; ++t) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int i = 16 * t + lk + 4 * r;
+          if (i < n) lds[cbase + i * Ls] = acc[t][r];
+        }
+      }
+      // 4x4x4_4b D map: lane = i*16 + blk*4 + j -> row = lane>>4, col = lane&15 (one value per lane)
+#pragma unroll
+      for (int t = 0; t < N4; ++t) {
+        const int i = rb + 4 * t + lk;
+        if (i < n) lds[cbase + i * Ls] = d[t];
+      }
+    }
+    col += adv;
+    cv += dv; const int c = cv >= mv; cv -= c ? mv : 0; cu += du + c;
+  }
+}
+
 __device__ __forceinline__ void contract_step(double* __restrict__ lds, const PassDesc& P, const int s,
                                               const int lane, const int wave, const int nwaves) {
   const int slot = P.sslot[s];
@@ -212,77 +290,15 @@ __device__ __forceinline__ void contract_step(double* __restrict__ lds, const Pa
   else { Ls = 1; Lu = P.L[0]; mu = P.m[0]; Lv = P.L[1]; mv = P.m[1]; }
   const int ncols = mu * mv;
   const int KT = (n + 3) >> 2;
-  const int n16 = n <= 12 ? 0 : (n <= 24 ? 1 : 2);
-  const int n4 = n <= 12 ? (n + 3) >> 2 : (n <= 16 ? 0 : (n <= 24 ? (n - 13) >> 2 : 0));
-  const int li = lane & 15, lk = lane >> 4, l4 = lane & 3;
-
-  // A operand rows of this lane (clamped to row 0 and masked when out of range)
-  const bool r16a = n16 > 0 && li < n, r16b = n16 > 1 && 16 + li < n;
-  const int q16a = (r16a ? li : 0) * n, q16b = (r16b ? 16 + li : 0) * n;
-  const int rb = 16 * n16;
-  const bool r4a = n4 > 0 && rb + l4 < n, r4b = n4 > 1 && rb + 4 + l4 < n, r4c = n4 > 2 && rb + 8 + l4 < n;
-  const int q4a = (r4a ? rb + l4 : 0) * n, q4b = (r4b ? rb + 4 + l4 : 0) * n, q4c = (r4c ? rb + 8 + l4 : 0) * n;
-
-  for (int ct = wave; ct * 16 < ncols; ct += nwaves) {
-    const int col = ct * 16 + li;
-    const int colc = col < ncols ? col : ncols - 1;
-    const int cu = colc / mv;
-    const int cv = colc - cu * mv;
-    const int cbase = cu * Lu + cv * Lv;
-    v4d acc0 = {0.0, 0.0, 0.0, 0.0};
-    v4d acc1 = {0.0, 0.0, 0.0, 0.0};
-    double d0 = 0.0, d1 = 0.0, d2 = 0.0;
-#pragma unroll
-    for (int kk = 0; kk < 8; ++kk) {
-      if (kk < KT) {
-        const int I0 = 4 * kk + lk;
-        const bool iok = I0 < n;
-        const int I = iok ? I0 : n - 1;     // rows >= n meet zero Q columns; keep the read in bounds
-        const double b = lds[cbase + I * Ls];
-        if (n16 > 0) {
-          const double a = Qm[q16a + I];
-          acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64((r16a && iok) ? a : 0.0, b, acc0, 0, 0, 0);
-        }
-        if (n16 > 1) {
-          const double a = Qm[q16b + I];
-          acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64((r16b && iok) ? a : 0.0, b, acc1, 0, 0, 0);
-        }
-        if (n4 > 0) {
-          const double a = Qm[q4a + I];
-          d0 = __builtin_amdgcn_mfma_f64_4x4x4f64((r4a && iok) ? a : 0.0, b, d0, 0, 0, 0);
-        }
-        if (n4 > 1) {
-          const double a = Qm[q4b + I];
-          d1 = __builtin_amdgcn_mfma_f64_4x4x4f64((r4b && iok) ? a : 0.0, b, d1, 0, 0, 0);
-        }
-        if (n4 > 2) {
-          const double a = Qm[q4c + I];
-          d2 = __builtin_amdgcn_mfma_f64_4x4x4f64((r4c && iok) ? a : 0.0, b, d2, 0, 0, 0);
-        }
-      }
-    }
-    if (col < ncols) {
-      // 16x16x4 D map: col = lane&15, row = (lane>>4) + 4*reg
-      if (n16 > 0) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int i = lk + 4 * r;
-          if (i < n) lds[cbase + i * Ls] = acc0[r];
-        }
-      }
-      if (n16 > 1) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int i = 16 + lk + 4 * r;
-          if (i < n) lds[cbase + i * Ls] = acc1[r];
-        }
-      }
-      // 4x4x4_4b D map: lane = i*16 + blk*4 + j -> row = lane>>4, col = lane&15 (one value per lane)
-      if (n4 > 0 && rb + lk < n) lds[cbase + (rb + lk) * Ls] = d0;
-      if (n4 > 1 && rb + 4 + lk < n) lds[cbase + (rb + 4 + lk) * Ls] = d1;
-      if (n4 > 2 && rb + 8 + lk < n) lds[cbase + (rb + 8 + lk) * Ls] = d2;
-    }
-  }
+#define SDFS_CC(A, B4) contract_cols<A, B4>(lds, Qm, n, KT, Ls, Lu, Lv, mv, ncols, lane, wave, nwaves)
+  if (n <= 4) SDFS_CC(0, 1);
+  else if (n <= 8) SDFS_CC(0, 2);
+  else if (n <= 12) SDFS_CC(0, 3);
+  else if (n <= 16) SDFS_CC(1, 0);
+  else if (n <= 20) SDFS_CC(1, 1);
+  else if (n <= 24) SDFS_CC(1, 2);
+  else SDFS_CC(2, 0);
+#undef SDFS_CC
 }
 
 // Zero-instruction barrier: redefines the offsets as far as the optimiser can tell, so address
