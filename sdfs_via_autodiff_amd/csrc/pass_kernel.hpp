@@ -66,6 +66,9 @@ struct PassDesc {
   const double* a2;
   const double* a3;
   long long ntiles;
+  int ablate;                  // diagnostics only (SDFS_ABLATE): 1 = skip the powers, 2 = skip the contractions
+  int stagger;                 // start delay (units of ~1k cycles) for the second resident block of each CU
+  int stagger_lo, stagger_hi;  // block-id range that is delayed
 };
 
 struct PassIO {
@@ -390,6 +393,14 @@ pass_kernel(const PassDesc P, const PassIO io) {
   const int trip = 0;
   (void)trip;
 
+  // Two blocks share a CU.  Launched together they march in lockstep (both load, both pow, both
+  // MFMA) and nothing overlaps; delaying the second resident block by about half a tile period
+  // puts one block's memory phases under the other's compute, and the offset then persists
+  // because replacements start when their predecessor ends.
+  if (P.stagger > 0 && (int)blockIdx.x >= P.stagger_lo && (int)blockIdx.x < P.stagger_hi) {
+    for (int i = 0; i < P.stagger; ++i) __builtin_amdgcn_s_sleep(16);
+  }
+
   const TileCtx cur = decode_tile(P, xcd_remap((long long)blockIdx.x, P.ntiles));
 
   const int m1 = P.m[1];
@@ -462,7 +473,7 @@ pass_kernel(const PassDesc P, const PassIO io) {
 
   // ---- prologue x = a1 w^theta, in place in LDS (each thread revisits its own units).
   //      Uniform trip count: pow_fast needs every lane of the wave active.
-  if (POWP) {
+  if (POWP && !(P.ablate & 1)) {
     Walker wk;
     wk.init(tid, B, m1, m2u);
 #pragma unroll 1
@@ -492,15 +503,15 @@ pass_kernel(const PassDesc P, const PassIO io) {
   STAMP(4);
 
   // ---- contractions ------------------------------------------------------------------
-  if (P.nsteps > 0) { contract_step(lds, P, 0, lane, wave, nwaves); STAMP(5); __syncthreads(); }
+  if (P.nsteps > 0 && !(P.ablate & 2)) { contract_step(lds, P, 0, lane, wave, nwaves); STAMP(5); __syncthreads(); }
   STAMP(6);
-  if (P.nsteps > 1) { contract_step(lds, P, 1, lane, wave, nwaves); STAMP(7); __syncthreads(); }
+  if (P.nsteps > 1 && !(P.ablate & 2)) { contract_step(lds, P, 1, lane, wave, nwaves); STAMP(7); __syncthreads(); }
   STAMP(8);
-  if (P.nsteps > 2) { contract_step(lds, P, 2, lane, wave, nwaves); STAMP(9); __syncthreads(); }
+  if (P.nsteps > 2 && !(P.ablate & 2)) { contract_step(lds, P, 2, lane, wave, nwaves); STAMP(9); __syncthreads(); }
   STAMP(10);
 
   // ---- aggregator Tw = 1 + beta (K S)^(1/theta), in place in LDS (rolled, uniform) ------
-  if (CES) {
+  if (CES && !(P.ablate & 1)) {
     Walker wk;
     wk.init(tid, B, m1, m2u);
 #pragma unroll 1

@@ -272,7 +272,7 @@ int build_plan(sdfs_handle* h, Plan& plan, const std::vector<int>& todo_in, std:
     // LDS strides: pad the fastest stride to == 2 (mod 4) doubles when it is the
     // K dimension of an MFMA step (16 columns x 2 rows then hit 32 distinct b64 banks)
     int L1 = d.m[2];
-    if (contracts_fast_slot && d.m[1] * d.m[0] > 1) { while ((L1 & 3) != 2) ++L1; }
+    if (contracts_fast_slot && d.m[1] * d.m[0] > 1 && env_int("SDFS_NO_PAD", 0) == 0) { while ((L1 & 3) != 2) ++L1; }
     d.L[2] = 1; d.L[1] = L1; d.L[0] = L1 * d.m[1];
     long long lds_elems = (long long)d.L[0] * d.m[0];
     lds_elems += lds_elems & 1;
@@ -390,6 +390,10 @@ int launch_pass(sdfs_handle* h, Pass& P, int pro, int epi, const PassIO& io, int
   d.pro = pro; d.epi = epi; d.minus_identity = minus_identity;
   d.theta = h->theta; d.inv_theta = 1.0 / h->theta; d.beta = h->beta;
   d.a1 = h->a1; d.a2 = h->a2; d.a3 = h->a3;
+  d.ablate = env_int("SDFS_ABLATE", 0);
+  d.stagger = env_int("SDFS_STAGGER", 0);
+  d.stagger_lo = env_int("SDFS_STAGGER_LO", h->num_cus);
+  d.stagger_hi = env_int("SDFS_STAGGER_HI", 2 * h->num_cus);
   int cid = -1;
   if (h->profiling) {
     char nm[48];
@@ -1190,9 +1194,12 @@ int sdfs_describe_plan(const sdfs_handle* h, char* buf, int64_t cap) {
     const Plan& pl = h->plan[st];
     for (size_t i = 0; i < pl.passes.size(); ++i) {
       const Pass& P = pl.passes[i];
-      snprintf(line, sizeof line, "stage %d pass %zu: %s tile %dx%dx%d lds %zu B block %d vec %d ept %d tiles %lld\n", st, i,
+      int occ = -1;
+      pass_fn fn = pass_kernel_variant(P.vec2 ? P.ept2 : P.ept1, P.vec2 ? 2 : 1, M_MID);
+      if (fn) hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)fn, P.block, P.lds_bytes);
+      snprintf(line, sizeof line, "stage %d pass %zu: %s tile %dx%dx%d lds %zu B block %d vec %d ept %d tiles %lld blocks/CU %d\n", st, i,
                P.label.c_str(), P.d.m[0], P.d.m[1], P.d.m[2], P.lds_bytes, P.block, P.vec2 ? 2 : 1,
-               P.vec2 ? P.ept2 : P.ept1, P.d.ntiles);
+               P.vec2 ? P.ept2 : P.ept1, P.d.ntiles, occ);
       s += line;
     }
   }
