@@ -247,6 +247,7 @@ def bicgstab_sharded(op, b, tol=1e-5, atol=0.0, maxiter=None, stats=None):
     """BiCGSTAB for (dT(w) - I) x = b on sharded vectors, JAX stopping rule, x0 = 0."""
     n_global = int(np.prod(op.shapes))
     maxiter = 10 * n_global if maxiter is None else maxiter
+    maxiter = min(maxiter, 100000)
     mv = lambda u: op.jvp(u) - u
     (bb,) = op.dots([(b, b)])
     atol2 = max(tol * tol * bb, atol * atol)

@@ -1,82 +1,23 @@
 """
-world_size-2 gloo tests (CPU) of the multi-GPU layer: the sharding schedule
+world_size-2 gloo tests of the multi-GPU layer: the sharding schedule
 (stage 0 -> re-shard -> stage 1 -> re-shard), uneven blocks, the all-reduced residual and
-the distributed Newton-Krylov loop.  The local stages are computed by a numpy ORACLE
-backend here (the HIP stages need a GPU; tests/test_hip_parity.py::test_sharded_* cover
-them), so what is checked is the host logic of sdfs_via_autodiff_amd/distributed.py.
+the distributed Newton-Krylov / successive-approximation loops.
+
+CPU tests: the local stages are computed by a numpy ORACLE backend (tests/sharded_worker.py),
+so what is checked is the host logic of sdfs_via_autodiff_amd/distributed.py.
+GPU test (-m gpu): two ranks on one MI355X run the real HIP stage kernels through sharded
+C-ABI handles (exchanges staged through gloo).
+Workers run under torch.distributed.run in a subprocess with a hard timeout.
 """
+import json
 import os
 import socket
+import subprocess
 import sys
 
-import numpy as np
 import pytest
-import torch
-import torch.distributed as dist
-import torch.multiprocessing as mp
 
 from conftest import REPO
-
-LETTERS = "abcdef"
-
-
-class OracleStages:
-    """numpy twin of HipStages (same interface): stage 0 contracts every axis but A on the
-    rank's A-block, stage 1 contracts A on the rank's B-block and applies the aggregator."""
-
-    def __init__(self, model, shapes, params, arrays, axis_a, a_lo, a_len, axis_b, b_lo, b_len):
-        from oracle.c_oracle import COperator   # reuse its table/stride bookkeeping (numpy only here)
-        meta = COperator.__new__(COperator)
-        COperator.__init__(meta, model, shapes, params, arrays)
-        self.D = len(shapes)
-        self.shapes = tuple(shapes)
-        self.theta, self.beta = meta.theta, meta.beta
-        self.Q = [np.asarray(q) for q in meta.Q]
-        self.qs = meta.qs
-        self.order = [int(g) for g in meta.order]
-        self.A, self.B = axis_a, axis_b
-        self.a_sl, self.b_sl = slice(a_lo, a_lo + a_len), slice(b_lo, b_lo + b_len)
-        # dense per-point tables on the full grid, sliced per stage (tiny test grids only)
-        idx = np.indices(self.shapes)
-        self.a1_full = meta.a1.ravel()[sum(idx[a] * meta.a1s[a] for a in range(self.D))]
-        self.K_full = (meta.a2.ravel()[sum(idx[a] * meta.a2s[a] for a in range(self.D))]
-                       * meta.a3.ravel()[sum(idx[a] * meta.a3s[a] for a in range(self.D))])
-        self.c1 = self.c2 = None
-
-    def _contract(self, x, g):
-        """y[.., i_g, ..] = sum_I Q_g[cond.., i_g, I] x[.., I, ..] with cond = current indices."""
-        cond = [c for c in range(self.D) if self.qs[g, c] != 0]
-        cond.sort(key=lambda c: -self.qs[g, c])                    # slowest conditioning axis first
-        q = self.Q[g].reshape([self.shapes[c] for c in cond] + [self.shapes[g]] * 2)
-        sub_x = LETTERS[:self.D].replace(LETTERS[g], "Z")
-        sub_q = "".join(LETTERS[c] for c in cond) + LETTERS[g] + "Z"
-        return np.einsum(f"{sub_q},{sub_x}->{LETTERS[:self.D]}", q, x)
-
-    def run(self, stage, mode, x, old=None):
-        x = x.numpy()
-        sl0 = [slice(None)] * self.D; sl0[self.A] = self.a_sl
-        sl1 = [slice(None)] * self.D; sl1[self.B] = self.b_sl
-        if stage == 0:
-            a1 = self.a1_full[tuple(sl0)]
-            if mode == 1:
-                y = self.c1 * x
-            else:
-                y = a1 * x ** self.theta
-                if mode == 2:
-                    self.c1 = a1 * x ** (self.theta - 1)
-            for g in self.order:
-                if g != self.A:
-                    y = self._contract(y, g)
-            return torch.from_numpy(np.ascontiguousarray(y))
-        S = self._contract(x, self.A)
-        K = self.K_full[tuple(sl1)]
-        if mode == 1:
-            out = self.c2 * S
-        else:
-            out = 1 + self.beta * (K * S) ** (1 / self.theta)
-            if mode == 2:
-                self.c2 = self.beta * (K * S) ** (1 / self.theta - 1) * K
-        return torch.from_numpy(np.ascontiguousarray(out))
 
 
 def _free_port():
@@ -84,82 +25,21 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, model, shapes, q, use_hip=False):
-    try:
-        sys.path.insert(0, REPO); sys.path.insert(0, os.path.join(REPO, "tests"))
-        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-        dist.init_process_group("gloo", rank=rank, world_size=world)
-        from sdfs_via_autodiff_amd import distributed as D
-        from oracle import models, ssy, gcy, solvers as osol
-        if model == "ssy":
-            p = models.ssy_params(); arr = ssy.discretize_ssy(p, shapes)
-            T, J = (lambda w: ssy.T_ssy_factorised(w, shapes, p, arr)), (lambda w, v: ssy.jvp_ssy(w, v, shapes, p, arr))
-        else:
-            p = models.gcy_params(); arr = gcy.discretize_gcy(p, shapes)
-            T, J = (lambda w: gcy.T_gcy_factorised(w, shapes, p, arr)), (lambda w, v: gcy.jvp_gcy(w, v, shapes, p, arr))
-        arr = list(arr)
-        rng = np.random.default_rng(7)
-        for i in ((7,) if model == "ssy" else (1, 3)):               # make conditional tensors differ per slice
-            qq = rng.random(arr[i].shape) + 0.05
-            arr[i] = qq / qq.sum(axis=-1, keepdims=True)
-        if use_hip:
-            torch.cuda.set_device(0)
-        op = D.ShardedKoopmans(model, shapes, p, arr, backend_factory=None if use_hip else OracleStages)
-        dev = "cuda" if use_hip else "cpu"
-        w = 400 + 500 * np.random.default_rng(0).random(shapes)
-        v = np.random.default_rng(1).standard_normal(shapes)
-        w_loc = op.scatter_from_full(torch.from_numpy(w)).to(dev)
-        v_loc = op.scatter_from_full(torch.from_numpy(v)).to(dev)
-        out = {}
-        Tw = op.gather_full(op.apply_T(w_loc)).cpu().numpy()
-        out["T"] = float(np.max(np.abs(Tw - T(w)) / np.abs(T(w))))
-        Tl = op.gather_full(op.linearize(w_loc)).cpu().numpy()
-        out["Tlin"] = float(np.max(np.abs(Tl - T(w)) / np.abs(T(w))))
-        jv = op.gather_full(op.jvp(v_loc)).cpu().numpy()
-        ref = J(w, v)
-        out["jvp"] = float(np.max(np.abs(jv - ref)) / np.max(np.abs(ref)))
-        out["resid"] = abs(op.sup_norm_diff(op.apply_T(w_loc), w_loc) - np.max(np.abs(T(w) - w)))
-        out["sizes"] = (op.a_sizes, op.b_sizes)
-        # distributed Newton (tight inner tolerance) vs the oracle's polished fixed point
-        x_loc, n = D.newton_sharded(op, op.scatter_from_full(torch.full(shapes, 800.0, dtype=torch.float64)).to(dev),
-                                    tol=1e-10, inner_rtol=1e-9, inner_atol=0.0)
-        x = op.gather_full(x_loc).cpu().numpy()
-        xs = osol.newton_polish(T, J, x.copy())
-        out["newton_err"] = float(np.max(np.abs(x - xs)))
-        out["newton_iters"] = n
-        # distributed SA: same iteration count as the single-process oracle loop
-        errs = []
-        xa_loc, na = D.successive_approx_sharded(op, op.scatter_from_full(torch.full(shapes, 800.0, dtype=torch.float64)).to(dev),
-                                                 tol=1e-3, errors=errs)
-        xo, no = osol.successive_approx(T, np.full(shapes, 800.0), tol=1e-3, verbose=False)
-        out["sa_iters"] = (na, no)
-        out["sa_err"] = float(np.max(np.abs(op.gather_full(xa_loc).cpu().numpy() - xo)))
-        if rank == 0:
-            q.put(out)
-        dist.destroy_process_group()
-    except Exception as e:      # surface the failure in the parent
-        import traceback
-        q.put({"error": f"rank {rank}: {e}\n{traceback.format_exc()}"})
-        raise
-
-
-def run_world2(model, shapes, use_hip):
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, model, shapes, q, use_hip)) for r in range(2)]
-    for p_ in procs:
-        p_.start()
-    out = q.get(timeout=300)
-    for p_ in procs:
-        p_.join(timeout=60)
+def run_world2(model, shapes, backend, timeout=240):
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(REPO, "tests", "sharded_worker.py"), model, ",".join(map(str, shapes)), backend]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, cwd=REPO)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("RESULT ")]
+    assert lines, f"no result (rc {r.returncode})\n{r.stdout[-2000:]}\n{r.stderr[-3000:]}"
+    out = json.loads(lines[-1][7:])
     assert "error" not in out, out.get("error")
     return out
 
 
 @pytest.mark.parametrize("model,shapes", [("ssy", (3, 5, 4, 3)), ("gcy", (2, 3, 2, 3, 2, 5))])
 def test_sharded_operator_world2_gloo(model, shapes):
-    out = run_world2(model, shapes, use_hip=False)
+    out = run_world2(model, shapes, "oracle")
     assert out["T"] < 1e-13 and out["Tlin"] < 1e-13 and out["jvp"] < 1e-12, out
     assert out["resid"] < 1e-9
     a_sizes, b_sizes = out["sizes"]
@@ -180,7 +60,8 @@ def test_block_sizes():
 def test_sharded_hip_stages_world2(model, shapes):
     """Two ranks on one GPU (gloo for the exchanges): the real HIP stage kernels with
     sharded handles, offsets into the scale tables and uneven blocks."""
-    out = run_world2(model, shapes, use_hip=True)
+    out = run_world2(model, shapes, "hip", timeout=150)
+    assert "newton_err" in out, out
     assert out["T"] < 1e-12 and out["Tlin"] < 1e-12 and out["jvp"] < 1e-11, out
     assert out["resid"] < 1e-8
     assert out["newton_err"] < 1e-8 and out["newton_iters"] < 20, out
