@@ -78,10 +78,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus != world and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE {world}")
+    # SDFS_BENCH_BACKEND=gloo rehearses the N > 1 path on a single GPU (all ranks on one device,
+    # exchanges staged through the host); the real run uses RCCL ("nccl"), one rank per GPU.
+    backend = os.environ.get("SDFS_BENCH_BACKEND", "nccl")
+    local_rank = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     import sdfs_via_autodiff_amd as S
     model, shapes = WORKLOADS[args.workload]

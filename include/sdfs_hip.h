@@ -105,7 +105,10 @@ const char* sdfs_last_error(const sdfs_handle* h);   /* h may be NULL: last crea
 int sdfs_default_opts(sdfs_opts* o);
 
 int64_t sdfs_grid_size(const sdfs_handle* h);        /* N = prod(shapes) */
-int sdfs_set_stream(sdfs_handle* h, void* hip_stream); /* NULL -> the handle's own stream */
+/* Launch on the caller's HIP stream (hip_stream == NULL is the device's default stream, which is
+ * what torch.cuda.current_stream().cuda_stream returns for torch's default stream); use_own != 0
+ * switches back to the handle's private non-blocking stream. */
+int sdfs_set_stream(sdfs_handle* h, void* hip_stream, int use_own);
 int sdfs_synchronize(sdfs_handle* h);
 
 /* Tw = T(w).  Replaces one call of T_ssy / T_gcy.  Host buffers of N doubles. */

@@ -54,7 +54,7 @@ SYMBOLS = {
     "sdfs_last_error": (C.c_char_p, [_P]),
     "sdfs_default_opts": (C.c_int, [C.POINTER(sdfs_opts)]),
     "sdfs_grid_size": (C.c_int64, [_P]),
-    "sdfs_set_stream": (C.c_int, [_P, _P]),
+    "sdfs_set_stream": (C.c_int, [_P, _P, C.c_int]),
     "sdfs_synchronize": (C.c_int, [_P]),
     "sdfs_apply_T": (C.c_int, [_P, _P, _P]),
     "sdfs_apply_T_dev": (C.c_int, [_P, _P, _P, _P]),

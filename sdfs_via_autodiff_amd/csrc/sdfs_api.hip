@@ -1025,9 +1025,9 @@ int sdfs_default_opts(sdfs_opts* o) {
 
 int64_t sdfs_grid_size(const sdfs_handle* h) { return h ? h->N : -1; }
 
-int sdfs_set_stream(sdfs_handle* h, void* s) {
+int sdfs_set_stream(sdfs_handle* h, void* s, int use_own) {
   int rc = check(h); if (rc) return rc;
-  hipStream_t ns = s ? (hipStream_t)s : h->own_stream;
+  hipStream_t ns = use_own ? h->own_stream : (hipStream_t)s;     // s == NULL is the device's default stream
   if (ns != h->stream && h->sa_graph) { hipGraphExecDestroy(h->sa_graph); h->sa_graph = nullptr; }
   h->stream = ns;
   return 0;

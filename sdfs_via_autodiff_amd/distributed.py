@@ -69,7 +69,7 @@ class HipStages:
         self._h = h
         self.shape0 = list(self.shapes); self.shape0[axis_a] = a_len
         self.shape1 = list(self.shapes); self.shape1[axis_b] = b_len
-        check(lib.sdfs_set_stream(self._h, torch.cuda.current_stream(self.device).cuda_stream), self._h)
+        check(lib.sdfs_set_stream(self._h, torch.cuda.current_stream(self.device).cuda_stream, 0), self._h)
 
     def run(self, stage, mode, x, old=None):
         out = torch.empty(self.shape0 if stage == 0 else self.shape1, dtype=torch.float64, device=self.device)
@@ -140,16 +140,22 @@ class ShardedKoopmans:
     def gather_full(self, w_loc):
         parts = [torch.empty([*self.shapes[:self.axis_a], s, *self.shapes[self.axis_a + 1:]],
                              dtype=w_loc.dtype, device=w_loc.device) for s in self.a_sizes]
-        dist.all_gather(parts, w_loc.contiguous(), group=self.group) if len(set(self.a_sizes)) == 1 else \
+        if len(set(self.a_sizes)) == 1 and (self._use_a2a or not w_loc.is_cuda):
+            dist.all_gather(parts, w_loc.contiguous(), group=self.group)
+        else:
             self._all_gather_uneven(parts, w_loc)
         return torch.cat(parts, dim=self.axis_a)
 
     def _all_gather_uneven(self, parts, w_loc):
+        host = w_loc.is_cuda and not self._use_a2a
         for src in range(self.world):
             if src == self.rank:
                 parts[src].copy_(w_loc)
-            dist.broadcast(parts[src], src=dist.get_global_rank(self.group, src) if self.group else src,
+            buf = parts[src].cpu() if host else parts[src]
+            dist.broadcast(buf, src=dist.get_global_rank(self.group, src) if self.group else src,
                            group=self.group)
+            if host:
+                parts[src].copy_(buf)
 
     def _reshard(self, x, src_axis, src_sizes, dst_axis, dst_sizes, dst_off):
         """x is sharded on src_axis (this rank's block) with dst_axis full; return the grid sharded
@@ -209,13 +215,20 @@ class ShardedKoopmans:
         return self._apply(MODE_JVP, v_loc)
 
     # -- reductions -------------------------------------------------------------------
-    def allreduce_max(self, t):
-        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+    def _allreduce(self, t, op):
+        if t.is_cuda and not self._use_a2a:        # gloo rehearsal with device tensors: reduce on the host
+            h = t.cpu()
+            dist.all_reduce(h, op=op, group=self.group)
+            t.copy_(h)
+        else:
+            dist.all_reduce(t, op=op, group=self.group)
         return t
 
+    def allreduce_max(self, t):
+        return self._allreduce(t, dist.ReduceOp.MAX)
+
     def allreduce_sum(self, t):
-        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
-        return t
+        return self._allreduce(t, dist.ReduceOp.SUM)
 
     def sup_norm_diff(self, a, b):
         m = (a - b).abs().max().reshape(1)

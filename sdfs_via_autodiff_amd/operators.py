@@ -106,8 +106,10 @@ class KoopmansOperator:
     def synchronize(self):
         check(lib.sdfs_synchronize(self._h), self._h)
 
-    def set_stream(self, stream_ptr):
-        check(lib.sdfs_set_stream(self._h, stream_ptr), self._h)
+    def set_stream(self, stream_ptr, use_own=False):
+        """Launch on a caller-owned HIP stream (0 / None = the default stream, e.g.
+        ``torch.cuda.current_stream().cuda_stream``); ``use_own=True`` restores the private stream."""
+        check(lib.sdfs_set_stream(self._h, stream_ptr, int(use_own)), self._h)
 
     # -- device-resident solve --------------------------------------------------
     def solve(self, x_init, algorithm="successive_approx", record_errors=False, **kw):

@@ -79,6 +79,9 @@ class OracleStages:
 
 
 def main():
+    import faulthandler
+    faulthandler.enable()
+    faulthandler.dump_traceback_later(int(os.environ.get("SHARDED_WORKER_WATCHDOG", "110")), exit=True)
     model = sys.argv[1]
     shapes = tuple(int(x) for x in sys.argv[2].split(","))
     use_hip = sys.argv[3] == "hip"
@@ -140,8 +143,8 @@ def body(rank, model, shapes, use_hip):
         # distributed SA: same iteration count as the single-process oracle loop
         errs = []
         xa_loc, na = D.successive_approx_sharded(op, op.scatter_from_full(torch.full(shapes, 800.0, dtype=torch.float64)).to(dev),
-                                                 tol=1e-3, errors=errs)
-        xo, no = osol.successive_approx(T, np.full(shapes, 800.0), tol=1e-3, verbose=False)
+                                                 tol=1e-3, max_iter=120, errors=errs)
+        xo, no = osol.successive_approx(T, np.full(shapes, 800.0), tol=1e-3, max_iter=120, verbose=False)
         out["sa_iters"] = (na, no)
         out["sa_err"] = float(np.max(np.abs(op.gather_full(xa_loc).cpu().numpy() - xo)))
         return out
