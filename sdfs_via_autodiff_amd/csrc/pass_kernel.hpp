@@ -110,6 +110,18 @@ __device__ __forceinline__ double gather64(double v, int idx) {
   return __hiloint2double(hi, lo);
 }
 
+// d = a * b + c with the constant c held in an SGPR pair.  gfx950 VOP3 takes no literal, so a plain
+// fma(q, r, CONST) costs two v_mov_b32 per Horner step to build the constant in VGPRs (a third of
+// pow's VALU instructions); the scalar move that feeds the SGPR pair issues on the SALU instead.
+__device__ __forceinline__ double fma_sc(double a, double b, double c) {
+  double d;
+  asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "s"(c));
+  return d;
+}
+
+// HIPREC = true : log2 x carried as hi + lo (needed when |y| is large: w^theta, theta = -16 .. -36)
+// HIPREC = false: plain double log2 x (enough for |y| < 1: the (K S)^(1/theta) of the aggregator)
+template <bool HIPREC>
 __device__ __forceinline__ double pow_fast(double x, double y, const PowLane& T) {
   // subnormal inputs: rescale by 2^64 (exact) and fix the exponent below
   const bool tiny = x < 0x1p-1022;
@@ -117,41 +129,53 @@ __device__ __forceinline__ double pow_fast(double x, double y, const PowLane& T)
   const unsigned long long ix = (unsigned long long)__double_as_longlong(xs);
   const unsigned long long tmp = ix - POW_OFF;
   const int i = (int)((tmp >> 46) & 63);
-  const double kd = (double)((long long)tmp >> 52) - (tiny ? 64.0 : 0.0);
+  const double kd = (double)((int)((long long)tmp >> 52) - (tiny ? 64 : 0));
   const double z = __longlong_as_double((long long)(ix - (tmp & 0xfff0000000000000ULL)));
   const double invc = gather64(T.invc, i);
   const double lchi = gather64(T.lchi, i);
-  const double lclo = gather64(T.lclo, i);
   const double r = fma(z, invc, -1.0);
-  // hi part: (kd + lchi) + r/ln2, errors collected in lo
-  const double t1 = kd + lchi;
-  const double t1e = lchi - (t1 - kd);                 // fast two-sum: |kd| >= |lchi| or kd == 0
-  const double p1 = r * POW_INVLN2_HI;
-  const double p1e = fma(r, POW_INVLN2_HI, -p1);
-  const double hi = t1 + p1;                           // two-sum
-  const double bb = hi - t1;
-  const double e2 = (t1 - (hi - bb)) + (p1 - bb);
-  double q = POW_L10;
-  q = fma(q, r, POW_L9); q = fma(q, r, POW_L8); q = fma(q, r, POW_L7); q = fma(q, r, POW_L6);
-  q = fma(q, r, POW_L5); q = fma(q, r, POW_L4); q = fma(q, r, POW_L3); q = fma(q, r, POW_L2);
-  const double lo = fma(r * r, q, ((t1e + e2) + p1e) + fma(r, POW_INVLN2_LO, lclo));
-  // e = y * log2(x), clamped so that the integer part stays small (over/underflow saturate in ldexp)
-  double ehi = y * hi;
-  const double elo = fma(y, hi, -ehi) + y * lo;
+  const double t1 = kd + lchi;                         // exact: lchi is a multiple of 2^-40, |kd| < 2^12
+  double q = fma_sc(r, POW_L10, POW_L9);
+  q = fma_sc(q, r, POW_L8); q = fma_sc(q, r, POW_L7); q = fma_sc(q, r, POW_L6);
+  q = fma_sc(q, r, POW_L5); q = fma_sc(q, r, POW_L4); q = fma_sc(q, r, POW_L3); q = fma_sc(q, r, POW_L2);
+  const double lclo = gather64(T.lclo, i);
+  double ehi, elo;
+  if (HIPREC) {
+    const double p1 = r * POW_INVLN2_HI;
+    const double p1e = fma(r, POW_INVLN2_HI, -p1);
+    const double hi = t1 + p1;                         // two-sum
+    const double bb = hi - t1;
+    const double e2 = (t1 - (hi - bb)) + (p1 - bb);
+    const double lo = fma(r * r, q, (e2 + p1e) + fma(r, POW_INVLN2_LO, lclo));
+    ehi = y * hi;
+    elo = fma(y, hi, -ehi) + y * lo;
+  } else {
+    // |y| < 1: the product and table errors of the hi + lo form are below 2^-60 |y| and dropped;
+    // what is kept is the rounding of the final sum (|log2 x| can be ~300 here) and of y * hi
+    const double sm = fma(r * r, q, fma(r, POW_INVLN2_HI, lclo));
+    const double hi = t1 + sm;
+    const double e2 = sm - (hi - t1);                  // fast two-sum (|t1| >= |sm| whenever it matters)
+    ehi = y * hi;
+    elo = fma(y, hi, -ehi) + y * e2;
+  }
+  // clamp so that the integer part stays small (over/underflow then saturate in ldexp)
   ehi = fmin(fmax(ehi, -1200.0), 1200.0);
   const double jd = rint(ehi * 64.0);
   const double f = fma(jd, -0.015625, ehi) + elo;
   const int j = (int)jd;
   const double t = gather64(T.e2t, j & 63);
-  double p = POW_E7;
-  p = fma(p, f, POW_E6); p = fma(p, f, POW_E5); p = fma(p, f, POW_E4);
-  p = fma(p, f, POW_E3); p = fma(p, f, POW_E2); p = fma(p, f, POW_E1);
+  double p = fma_sc(f, POW_E7, POW_E6);
+  p = fma_sc(p, f, POW_E5); p = fma_sc(p, f, POW_E4);
+  p = fma_sc(p, f, POW_E3); p = fma_sc(p, f, POW_E2); p = fma_sc(p, f, POW_E1);
   double res = ldexp(fma(t, p * f, t), j >> 6);
-  // IEEE corner cases of pow for the inputs this path can meet (y finite, y != 0)
+  // IEEE corner cases of pow for the inputs this path can meet (y finite, y != 0): rare, kept
+  // out of the straight-line code
   const double inf = __longlong_as_double(0x7ff0000000000000LL);
-  if (x == 0.0) res = y < 0.0 ? inf : 0.0;
-  if (x == inf) res = y < 0.0 ? 0.0 : inf;
-  if (!(x >= 0.0)) res = __longlong_as_double(0x7ff8000000000000LL);   // negative base or NaN
+  if (__builtin_expect(!(x > 0.0 && x < inf), 0)) {
+    if (x == 0.0) res = y < 0.0 ? inf : 0.0;
+    else if (x == inf) res = y < 0.0 ? 0.0 : inf;
+    else res = __longlong_as_double(0x7ff8000000000000LL);   // negative base or NaN
+  }
   return res;
 }
 
@@ -487,7 +511,7 @@ pass_kernel(const PassDesc P, const PassIO io) {
 #pragma unroll
       for (int j = 0; j < VEC; ++j) {
         const double xin = valid ? x.v[j] : 1.0;
-        const double xw = P.a1[valid ? i1 + j * P.ta1[2] : 0] * pow_fast(xin, P.theta, PT);
+        const double xw = P.a1[valid ? i1 + j * P.ta1[2] : 0] * pow_fast<true>(xin, P.theta, PT);
         if (LINP) c1.v[j] = xw / xin;                           // c1 = a1 w^(theta-1)
         x.v[j] = xw;
       }
@@ -527,7 +551,7 @@ pass_kernel(const PassDesc P, const PassIO io) {
       for (int j = 0; j < VEC; ++j) {
         const double sv = valid ? y.v[j] : 1.0;
         const double ks = P.a2[valid ? i2 + j * P.ta2[2] : 0] * P.a3[valid ? i3 + j * P.ta3[2] : 0] * sv;
-        const double uu = pow_fast(ks, P.inv_theta, PT);
+        const double uu = pow_fast<false>(ks, P.inv_theta, PT);
         if (LINE) c2.v[j] = P.beta * uu / sv;                   // c2 = beta K (K S)^(1/theta-1) = beta u / S
         y.v[j] = 1.0 + P.beta * uu;
       }
@@ -607,7 +631,7 @@ __global__ void __launch_bounds__(256) debug_pow_kernel(const double* __restrict
   const PowLane PT = pow_lane_init(threadIdx.x & 63);
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const double xv = i < n ? x[i] : 1.0;
-  const double r = pow_fast(xv, y, PT);
+  const double r = fabs(y) < 1.0 ? pow_fast<false>(xv, y, PT) : pow_fast<true>(xv, y, PT);
   if (i < n) out[i] = r;
 }
 
