@@ -131,6 +131,14 @@ def main():
     dom = max(counters, key=lambda c: c["total_ms"])
     avg_ms = dom["total_ms"] / max(dom["launches"], 1)
     achieved = dom["alg_bytes"] / (avg_ms * 1e-3) / 1e9
+    # HBM bytes per launch from the committed rocprofv3 PMC passes of this same command
+    # (profiles/: (2*FETCH_SIZE + WRITE_SIZE)*1024, gfx950 correction of MI355X_MICROARCH.md)
+    traffic = None
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", f"round1_{args.workload}_pmc.json")))
+        traffic = pmc["passes"][str(counters.index(dom))].get("hbm_traffic_bytes")
+    except (OSError, KeyError, ValueError):
+        pass
     kernels = [{"name": c["name"], "launches": c["launches"],
                 "avg_ms": c["total_ms"] / max(c["launches"], 1),
                 "alg_GB": c["alg_bytes"] / 1e9,
@@ -149,7 +157,7 @@ def main():
                                f"step (T apply + fused sup-norm residual), default calibration, Rouwenhorst",
                    "grid_points": N, "plan": op.describe_plan().strip().split("\n")},
         "roofline": {"bound": "hbm", "kernel": dom["name"], "achieved": achieved, "peak": HBM_PEAK_GBS,
-                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "avg_launch_ms": avg_ms, "alg_bytes_per_launch": dom["alg_bytes"]},
         "kernels": kernels,
         "ideal_single_pass_frac": 16.0 * N / (dt / args.steps) / 1e9 / HBM_PEAK_GBS,
