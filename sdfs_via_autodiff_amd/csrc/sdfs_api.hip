@@ -413,6 +413,7 @@ int launch_pass(sdfs_handle* h, Pass& P, int pro, int epi, const PassIO& io, int
   else if (pro == PRO_MUL) mode = M_JFIRST;
   else if (epi == EPI_MUL) mode = M_JLAST;
   if (pro == PRO_MUL && epi == EPI_MUL) return fail(h, SDFS_ERR_UNSUPPORTED, "single-pass JVP not supported");
+  const int block = P.block;
   pass_fn fn = pass_kernel_variant(v2 ? P.ept2 : P.ept1, v2 ? 2 : 1, mode);
   if (!fn) return fail(h, SDFS_ERR_UNSUPPORTED, "no kernel variant for EPT %d", v2 ? P.ept2 : P.ept1);
   const long long grid = d.ntiles;
@@ -422,7 +423,7 @@ int launch_pass(sdfs_handle* h, Pass& P, int pro, int epi, const PassIO& io, int
   if (!dbg_dev) hipMalloc((void**)&dbg_dev, 64 * 2 * 16 * 8);
   hipMemsetAsync(dbg_dev, 0, 64 * 2 * 16 * 8, h->stream);
   io2.dbg = dbg_dev;
-  hipLaunchKernelGGL(fn, dim3((unsigned)grid), dim3(P.block), P.lds_bytes, h->stream, d, io2);
+  hipLaunchKernelGGL(fn, dim3((unsigned)grid), dim3(block), P.lds_bytes, h->stream, d, io2);
   {
     static int dumps = 0;
     if (dumps < 12) {
@@ -446,7 +447,7 @@ int launch_pass(sdfs_handle* h, Pass& P, int pro, int epi, const PassIO& io, int
   return 0;
 #endif
   ProfScope ps(h, cid);
-  hipLaunchKernelGGL(fn, dim3((unsigned)grid), dim3(P.block), P.lds_bytes, h->stream, d, io);
+  hipLaunchKernelGGL(fn, dim3((unsigned)grid), dim3(block), P.lds_bytes, h->stream, d, io);
   HIPCHK(h, hipGetLastError());
   return 0;
 }
