@@ -18,10 +18,12 @@ from .operators import (KoopmansOperator, ssy_operator, gcy_operator, T_ssy, T_g
 from .solvers import (successive_approx, newton_solver, anderson_solver,
                       fixed_point_via_gradient_decent, solvers, solver,
                       default_tolerance, default_max_iter)
+from .loglinear import wc_loglinear_factory, loglinear_guess
 from ._lib import SdfsError, LIB_PATH
 
 __all__ = ["SSY", "GCY", "rouwenhorst", "discretize_ssy", "discretize_gcy",
            "KoopmansOperator", "ssy_operator", "gcy_operator", "T_ssy", "T_gcy",
            "successive_approx", "newton_solver", "anderson_solver",
            "fixed_point_via_gradient_decent", "solvers", "solver",
-           "default_tolerance", "default_max_iter", "SdfsError", "LIB_PATH"]
+           "default_tolerance", "default_max_iter", "wc_loglinear_factory", "loglinear_guess",
+           "SdfsError", "LIB_PATH"]

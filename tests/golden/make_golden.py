@@ -172,6 +172,19 @@ def main():
         xs = SOL.solver(T, np.ones(shapes) * 800.0, algorithm="successive_approx", verbose=False)
     np.savez_compressed(os.path.join(HERE, "solver_front_ssy_2x3x4x5.npz"), w=np.asarray(xs))
 
+    # --- log-linear approximation (ssy_model.py:88-156, gcy_model.py:80-159), reference functions ---
+    rng = np.random.default_rng(3)
+    import ssy_model as SM
+    import gcy_model as GM
+    f_ssy = SM.wc_loglinear_factory(ssy)
+    xs = rng.standard_normal((40, 4)) * np.array([0.002, 0.3, 0.3, 0.003])
+    f_gcy = GM.wc_loglinear_factory(gcy)
+    xg = rng.standard_normal((40, 6)) * np.array([0.002, 0.3, 0.3, 0.5, 0.003, 0.003])
+    np.savez_compressed(os.path.join(HERE, "loglinear.npz"),
+                        x_ssy=xs, q_ssy=np.array([f_ssy(x) for x in xs]),
+                        x_gcy=xg, q_gcy=np.array([f_gcy(x) for x in xg]))
+    print("loglinear ok", f_ssy(xs[0]), f_gcy(xg[0]))
+
     # --- recorded notebook output (sandpit.ipynb:41-44), typed in as data ---
     np.savez(os.path.join(HERE, "sandpit_trace.npz"),
              shapes=np.array((10, 10, 10, 10)),

@@ -146,3 +146,32 @@ def test_max_iter_warning(capsys):
     x, n = S.successive_approx(lambda x: x + 1.0, np.zeros(2), max_iter=5, verbose=False)
     assert n == 5
     assert "Warning: Hit maximum iteration number 5" in capsys.readouterr().out
+
+
+def test_loglinear_matches_reference():
+    """wc_loglinear_factory against values from the reference's own functions (tests/golden/loglinear.npz)."""
+    import sdfs_via_autodiff_amd as S
+    g = load_golden("loglinear.npz")
+    f = S.wc_loglinear_factory(S.SSY())
+    np.testing.assert_allclose([f(x) for x in g["x_ssy"]], g["q_ssy"], rtol=1e-12)
+    np.testing.assert_allclose(f(tuple(g["x_ssy"].T)), g["q_ssy"], rtol=1e-12)      # array form
+    f = S.wc_loglinear_factory(S.GCY())
+    np.testing.assert_allclose([f(x) for x in g["x_gcy"]], g["q_gcy"], rtol=1e-12)
+    with pytest.raises(TypeError):
+        S.wc_loglinear_factory(object())
+
+
+def test_loglinear_guess_shapes_and_values():
+    import sdfs_via_autodiff_amd as S
+    m = S.SSY(); shapes = (3, 4, 5, 6); arr = S.discretize_ssy(m, shapes)
+    w0 = S.loglinear_guess(m, shapes, arr)
+    f = S.wc_loglinear_factory(m)
+    assert w0.shape == shapes
+    l, k, i, j = 2, 1, 3, 4
+    assert abs(w0[l, k, i, j] - (np.exp(f((arr[0][l], arr[2][k], arr[4][i], arr[6][i, j]))) + 1)) < 1e-9
+    m = S.GCY(); shapes = (2, 3, 4, 2, 3, 2); arr = S.discretize_gcy(m, shapes)
+    w0 = S.loglinear_guess(m, shapes, arr)
+    f = S.wc_loglinear_factory(m)
+    a, b, c, d, e, ff = 1, 2, 3, 0, 1, 1
+    x = (arr[13][ff], arr[7][d], arr[4][c], arr[10][e], arr[0][b, c, e, a], arr[2][e, b])
+    assert w0.shape == shapes and abs(w0[a, b, c, d, e, ff] - (np.exp(f(x)) + 1)) < 1e-9
