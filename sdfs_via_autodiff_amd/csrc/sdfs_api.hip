@@ -938,11 +938,13 @@ int create_common(int model, int ndim, const int64_t* shapes, const double* para
   } else {
     if (axis_a >= ndim || axis_b < 0 || axis_b >= ndim || axis_a == axis_b)
       return bail(fail(h, SDFS_ERR_ARG, "bad shard axes %d / %d", axis_a, axis_b));
+    // no transition tensor may be conditioned on A or B, and A's own tensor (contracted in stage 1,
+    // where only B is incomplete) must not be conditioned on B
     for (int g = 0; g < ndim; ++g)
-      if (h->ax[g].qs[axis_a] != 0 || h->ax[g].qs[axis_b] != 0 )
+      if (h->ax[g].qs[axis_a] != 0 || h->ax[g].qs[axis_b] != 0)
         return bail(fail(h, SDFS_ERR_ARG, "shard axes must not condition any transition matrix"));
     for (int c = 0; c < ndim; ++c)
-      if (h->ax[axis_a].qs[c] != 0) return bail(fail(h, SDFS_ERR_ARG, "shard axis A must be unconditional"));
+      if (h->ax[axis_b].qs[c] != 0) return bail(fail(h, SDFS_ERR_ARG, "shard axis B must be unconditional"));
     if (a_lo < 0 || a_len < 1 || a_lo + a_len > h->shape[axis_a] || b_lo < 0 || b_len < 1 || b_lo + b_len > h->shape[axis_b])
       return bail(fail(h, SDFS_ERR_ARG, "shard block out of range"));
     h->sharded = true; h->axis_a = axis_a; h->axis_b = axis_b;

@@ -50,7 +50,7 @@ class OracleStages:
         sub_q = "".join(LETTERS[c] for c in cond) + LETTERS[g] + "Z"
         return np.einsum(f"{sub_q},{sub_x}->{LETTERS[:self.D]}", q, x)
 
-    def run(self, stage, mode, x, old=None):
+    def run(self, stage, mode, x, old=None, resid=None):
         x = x.numpy()
         sl0 = [slice(None)] * self.D; sl0[self.A] = self.a_sl
         sl1 = [slice(None)] * self.D; sl1[self.B] = self.b_sl
@@ -74,6 +74,8 @@ class OracleStages:
             out = 1 + self.beta * (K * S) ** (1 / self.theta)
             if mode == 2:
                 self.c2 = self.beta * (K * S) ** (1 / self.theta - 1) * K
+        if resid is not None and old is not None:
+            resid[0] = float(np.max(np.abs(out - old.numpy())))
         return torch.from_numpy(np.ascontiguousarray(out))
 
 
