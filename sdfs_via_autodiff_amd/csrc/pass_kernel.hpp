@@ -67,8 +67,6 @@ struct PassDesc {
   const double* a3;
   long long ntiles;
   int ablate;                  // diagnostics only (SDFS_ABLATE): 1 = skip the powers, 2 = skip the contractions
-  int stagger;                 // start delay (units of ~1k cycles) for the second resident block of each CU
-  int stagger_lo, stagger_hi;  // block-id range that is delayed
 };
 
 struct PassIO {
@@ -416,14 +414,6 @@ pass_kernel(const PassDesc P, const PassIO io) {
   const int lane = tid & 63, wave = tid >> 6, nwaves = B >> 6;
   const int trip = 0;
   (void)trip;
-
-  // Two blocks share a CU.  Launched together they march in lockstep (both load, both pow, both
-  // MFMA) and nothing overlaps; delaying the second resident block by about half a tile period
-  // puts one block's memory phases under the other's compute, and the offset then persists
-  // because replacements start when their predecessor ends.
-  if (P.stagger > 0 && (int)blockIdx.x >= P.stagger_lo && (int)blockIdx.x < P.stagger_hi) {
-    for (int i = 0; i < P.stagger; ++i) __builtin_amdgcn_s_sleep(16);
-  }
 
   const TileCtx cur = decode_tile(P, xcd_remap((long long)blockIdx.x, P.ntiles));
 

@@ -391,9 +391,6 @@ int launch_pass(sdfs_handle* h, Pass& P, int pro, int epi, const PassIO& io, int
   d.theta = h->theta; d.inv_theta = 1.0 / h->theta; d.beta = h->beta;
   d.a1 = h->a1; d.a2 = h->a2; d.a3 = h->a3;
   d.ablate = env_int("SDFS_ABLATE", 0);
-  d.stagger = env_int("SDFS_STAGGER", 0);
-  d.stagger_lo = env_int("SDFS_STAGGER_LO", h->num_cus);
-  d.stagger_hi = env_int("SDFS_STAGGER_HI", 2 * h->num_cus);
   int cid = -1;
   if (h->profiling) {
     char nm[48];

@@ -1,6 +1,6 @@
 #!/bin/bash
 # prints kernel name, VGPRs, scratch, occupancy for every kernel in the library
-hipcc --offload-arch=gfx950 -O3 -std=c++17 -Wno-unused-value -shared -fPIC -Rpass-analysis=kernel-resource-usage -o /tmp/_ru.so /root/repo/sdfs_via_autodiff_amd/csrc/sdfs_api.hip 2>&1 | python3 -c "
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -Wno-unused-value -shared -fPIC -Rpass-analysis=kernel-resource-usage -o /tmp/_ru.so $(dirname "$0")/../sdfs_via_autodiff_amd/csrc/sdfs_api.hip 2>&1 | python3 -c "
 import sys,re
 name=None
 for l in sys.stdin:
