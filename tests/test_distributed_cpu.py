@@ -25,8 +25,8 @@ def _free_port():
     return p
 
 
-def run_world2(model, shapes, backend, timeout=240):
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+def run_world2(model, shapes, backend, timeout=240, world=2):
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
            os.path.join(REPO, "tests", "sharded_worker.py"), model, ",".join(map(str, shapes)), backend]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, cwd=REPO)
@@ -48,6 +48,14 @@ def test_sharded_operator_world2_gloo(model, shapes):
     assert out["sa_iters"][0] == out["sa_iters"][1] and out["sa_err"] < 1e-9, out
 
 
+def test_sharded_operator_world4_uneven_blocks():
+    """20-over-8 style uneven blocks in miniature: 5 and 6 states over 4 ranks."""
+    out = run_world2("gcy", (5, 2, 2, 6, 2, 3), "oracle", world=4)
+    assert out["T"] < 1e-13 and out["Tlin"] < 1e-13 and out["jvp"] < 1e-12, out
+    assert out["sizes"] == [[2, 1, 1, 1], [2, 2, 1, 1]]
+    assert out["newton_err"] < 1e-8 and out["sa_iters"][0] == out["sa_iters"][1]
+
+
 def test_block_sizes():
     from sdfs_via_autodiff_amd.distributed import block_sizes, block_offsets
     assert block_sizes(20, 8) == [3, 3, 3, 3, 2, 2, 2, 2]
@@ -66,3 +74,11 @@ def test_sharded_hip_stages_world2(model, shapes):
     assert out["resid"] < 1e-8
     assert out["newton_err"] < 1e-8 and out["newton_iters"] < 20, out
     assert out["sa_iters"][0] == out["sa_iters"][1] and out["sa_err"] < 1e-8, out
+
+
+@pytest.mark.gpu
+def test_sharded_hip_stages_world4_uneven():
+    out = run_world2("gcy", (5, 3, 2, 6, 3, 4), "hip", timeout=200, world=4)
+    assert out["T"] < 1e-12 and out["Tlin"] < 1e-12 and out["jvp"] < 1e-11, out
+    assert out["sizes"] == [[2, 1, 1, 1], [2, 2, 1, 1]]
+    assert out["newton_err"] < 1e-8, out
