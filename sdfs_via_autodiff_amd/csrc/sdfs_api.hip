@@ -207,7 +207,10 @@ int build_plan(sdfs_handle* h, Plan& plan, const std::vector<int>& todo_in, std:
       }
     }
     if (G.empty()) return fail(h, SDFS_ERR_ARG, "planner: no contractible axis (sharded axis still pending?)");
-    // filler axes: amortise a conditional Q over more columns / keep >= 16 columns per step
+    // filler axes: amortise a conditional Q over more columns / keep >= 16 columns per step.
+    // A filler is a pure batch axis, so it may enter the tile in CHUNKS (chunk = a divisor of its
+    // extent): smaller tiles -> more resident blocks per CU where only the batch axis is shrunk.
+    int chunk_axis = -1, chunk = 0;
     while ((int)tile.size() < 3) {
       int pick = -1;
       for (int a = D - 1; a >= 0; --a) {
@@ -225,6 +228,11 @@ int build_plan(sdfs_handle* h, Plan& plan, const std::vector<int>& todo_in, std:
       const bool want = (mincols < 16) || (nloc / e >= 512);
       if (e > budget || !want) break;
       tile = nt;
+      const int fc = env_int("SDFS_FILLER_CHUNK", 0);
+      if (fc > 0 && chunk_axis < 0 && h->ax[pick].nloc % fc == 0 && fc < h->ax[pick].nloc &&
+          tile_elems(tile) / h->ax[pick].nloc * fc / h->ax[G.back()].nloc >= 64) {
+        chunk_axis = pick; chunk = fc;
+      }
     }
     std::sort(tile.begin(), tile.end());                    // slow -> fast
     // steps: fastest axis first
@@ -237,13 +245,22 @@ int build_plan(sdfs_handle* h, Plan& plan, const std::vector<int>& todo_in, std:
     for (int j = 0; j < 3; ++j) { d.m[j] = 1; d.toff[j] = 0; d.gstride[j] = 0; d.ta1[j] = d.ta2[j] = d.ta3[j] = 0; }
     for (int j = 0; j < nt; ++j) {
       const int slot = 3 - nt + j, a = tile[j];
-      d.m[slot] = h->ax[a].nloc; d.toff[slot] = h->ax[a].off; d.gstride[slot] = (int)stride[a];
+      d.m[slot] = (a == chunk_axis) ? chunk : h->ax[a].nloc; d.toff[slot] = h->ax[a].off; d.gstride[slot] = (int)stride[a];
       d.ta1[slot] = h->ax[a].a1s; d.ta2[slot] = h->ax[a].a2s; d.ta3[slot] = h->ax[a].a3s;
       P.tile_axes[slot] = a;
     }
     d.nfixed = 0;
     long long ntiles = 1;
     for (int a = 0; a < D; ++a) {
+      if (a == chunk_axis) {               // the chunk number is one more block-fixed coordinate
+        if (d.nfixed >= MAXF) return fail(h, SDFS_ERR_UNSUPPORTED, "too many fixed axes");
+        const int k = d.nfixed++;
+        d.fext[k] = h->ax[a].nloc / chunk; d.foff[k] = 0; d.fstride[k] = stride[a] * chunk;
+        d.fa1[k] = h->ax[a].a1s * chunk; d.fa2[k] = h->ax[a].a2s * chunk; d.fa3[k] = h->ax[a].a3s * chunk;
+        for (int s = 0; s < (int)G.size(); ++s) d.fq[s][k] = 0;
+        ntiles *= d.fext[k];
+        continue;
+      }
       if (in(tile, a)) continue;
       if (d.nfixed >= MAXF) return fail(h, SDFS_ERR_UNSUPPORTED, "too many fixed axes");
       const int k = d.nfixed++;
@@ -264,7 +281,7 @@ int build_plan(sdfs_handle* h, Plan& plan, const std::vector<int>& todo_in, std:
       d.sslot[s] = slot; d.sn[s] = h->ax[g].n; d.Q[s] = h->ax[g].Q;
       P.step_axes[s] = g;
       if (slot == 2) contracts_fast_slot = true;
-      const long long cols = tile_elems(tile) / h->ax[g].nloc;
+      const long long cols = (long long)d.m[0] * d.m[1] * d.m[2] / h->ax[g].nloc;
       maxct = std::max(maxct, (cols + 15) / 16);
       P.q_bytes += 8.0 * (double)h->ax[g].qcount * h->ax[g].n * h->ax[g].n;
       P.flops += 2.0 * (double)nloc * h->ax[g].n;
@@ -283,7 +300,7 @@ int build_plan(sdfs_handle* h, Plan& plan, const std::vector<int>& todo_in, std:
     P.lds_bytes = (size_t)lds_elems * 8;
     if (P.lds_bytes > 150 * 1024) return fail(h, SDFS_ERR_UNSUPPORTED, "tile of %lld doubles exceeds LDS", lds_elems);
     // block size: balance column tiles over waves, keep enough lanes for the elementwise stages
-    const long long tot = tile_elems(tile);
+    const long long tot = (long long)d.m[0] * d.m[1] * d.m[2];
     int w_elem = (int)std::min<long long>(8, std::max<long long>(1, (tot + 127) / 128));
     int w_mfma = (int)std::min<long long>(maxct, 8);
     if (maxct > 4) {
