@@ -75,6 +75,14 @@ SYMBOLS = {
 
 
 def _load():
+    # PyTorch-ROCm ships its own copy of the HIP runtime.  If libsdfs_hip.so pulled in /opt/rocm's
+    # copy first, a later torch.cuda initialisation in the same process finds "No HIP GPUs"; loading
+    # torch first makes both share one runtime (torch is what the callers use for device memory and
+    # torch.distributed anyway).
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     if not os.path.exists(LIB_PATH):
         raise SdfsError(
             f"{LIB_PATH} not found: build it first (python -c 'import __graft_entry__ as g; g.build()'). "

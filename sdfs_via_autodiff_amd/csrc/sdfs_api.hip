@@ -936,13 +936,14 @@ int create_common(int model, int ndim, const int64_t* shapes, const double* para
   }
   int rc = setup_model(h, model, ndim, shapes, params, nparams, arrays, sizes, narrays);
   if (rc) return bail(rc);
-  static bool attr_set = false;
-  if (!attr_set) {
+  // dynamic LDS above 64 KB has to be allowed per kernel variant (and per device)
+  static unsigned long long attr_done = 0;
+  if (device_id < 64 && !(attr_done & (1ULL << device_id))) {
     for (int e = 1; e <= 16; e <<= 1)
       for (int v = 1; v <= 2; ++v)
         for (int j = 0; j < M_NMODES; ++j)
           hipFuncSetAttribute((const void*)pass_kernel_variant(e, v, j), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
-    attr_set = true;
+    attr_done |= 1ULL << device_id;
   }
   std::vector<int> all;
   for (int a = 0; a < ndim; ++a) all.push_back(a);

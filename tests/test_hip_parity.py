@@ -290,3 +290,35 @@ def test_device_pow_accuracy_vs_long_double(S):
     out = np.empty_like(special)
     _lib.lib.sdfs_debug_pow(special.ctypes.data, ctypes.c_double(-16.0216), out.ctypes.data, special.size, 0)
     assert out[0] == np.inf and np.isnan(out[1]) and out[2] == 0.0 and np.isnan(out[3]) and out[4] == np.inf
+
+
+def test_in_place_apply_and_two_handles(S):
+    """Device-pointer entry points: out may alias the input; handles are independent."""
+    import torch
+    shapes = (6, 5, 4, 7)
+    T1, _, _ = make_op(S, "ssy", shapes)
+    T2, _, _ = make_op(S, "gcy", (3, 4, 2, 3, 2, 4))
+    w = wbench(shapes)
+    want = T1(w)
+    buf = torch.from_numpy(w).cuda()
+    res = torch.zeros(1, dtype=torch.float64, device="cuda")
+    T1.set_stream(torch.cuda.current_stream().cuda_stream)
+    T1.apply_dev(buf.data_ptr(), buf.data_ptr(), res.data_ptr())      # in place
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(buf.cpu().numpy(), want, rtol=1e-14)
+    assert abs(float(res.item()) - np.max(np.abs(want - w))) < 1e-9
+    w2 = wbench((3, 4, 2, 3, 2, 4), seed=3)
+    oT, _ = oracle_T("gcy", (3, 4, 2, 3, 2, 4))
+    np.testing.assert_allclose(T2(w2), oT(w2), rtol=APPLY_RTOL)
+    np.testing.assert_allclose(T1(w), want, rtol=1e-14)               # T1 unaffected by T2's use
+
+
+def test_loglinear_warm_start_reaches_same_fixed_point(S):
+    shapes = (6, 6, 6, 6)
+    m = S.SSY(); arr = S.discretize_ssy(m, shapes)
+    T = S.ssy_operator(shapes, m.params, arr)
+    w0 = S.loglinear_guess(m, shapes, arr)
+    xa, na, _ = T.solve(w0, "newton", tol=1e-10, inner_rtol=1e-8, inner_atol=0.0)
+    xb, nb, _ = T.solve(np.full(shapes, 800.0), "newton", tol=1e-10, inner_rtol=1e-8, inner_atol=0.0)
+    np.testing.assert_allclose(xa, xb, rtol=0, atol=1e-8)
+    assert na <= nb + 1
