@@ -8,8 +8,9 @@
 // which is how the reference's  sum_{next states} H * w^theta
 // (code/ssy/discrete/ssy_wc_ratio.py:143-145, code/gcy/discrete/gcy_wc_ratio.py:230-232)
 // factorises (every H is a product of per-axis transition matrices).
-// The first pass applies the prologue  x = a1 * w^theta  while loading, the last
-// pass applies the Epstein-Zin aggregator  Tw = 1 + beta (K * S)^(1/theta)
+// The scale factors a1 (next-state), a2, a3 (current-state) of the reference are folded into the
+// transition tensors on the host (sdfs_create), so the first pass applies just  x = w^theta  while
+// loading and the last pass the Epstein-Zin aggregator  Tw = 1 + beta S^(1/theta)
 // (ssy_wc_ratio.py:148, gcy_wc_ratio.py:235) and the sup-norm residual of
 // code/solvers.py:36 while storing.
 //
@@ -45,13 +46,11 @@ struct PassDesc {
   int foff[MAXF];              // global index of local index 0 (sharded runs)
   long long fstride[MAXF];     // element stride in the (local) grid
   int fq[3][MAXF];             // matrix-index stride of step s's Q tensor
-  int fa1[MAXF], fa2[MAXF], fa3[MAXF];
   // tile axes, slot 0 slowest .. slot 2 fastest; unused slots have extent 1
   int m[3];
   int toff[3];
   int gstride[3];              // element strides inside the tile (tile span < 2^31)
   int L[3];                    // LDS strides (L[2] == 1)
-  int ta1[3], ta2[3], ta3[3];
   // contraction steps
   int nsteps;
   int sslot[3];
@@ -62,9 +61,6 @@ struct PassDesc {
   int pro, epi;
   int minus_identity;          // EPI_MUL: subtract old[idx]
   double theta, inv_theta, beta;
-  const double* a1;
-  const double* a2;
-  const double* a3;
   long long ntiles;
   int ablate;                  // diagnostics only (SDFS_ABLATE): 1 = skip the powers, 2 = skip the contractions
 };
@@ -355,13 +351,12 @@ enum PassMode { M_MID = 0, M_TFIRST = 1, M_TLAST = 2, M_TONLY = 3, M_JFIRST = 4,
 
 struct TileCtx {
   long long gbase;
-  int ia1b, ia2b, ia3b;
   int q0, q1, q2;
 };
 
 __device__ __forceinline__ TileCtx decode_tile(const PassDesc& P, long long tile) {
   TileCtx c;
-  c.gbase = 0; c.ia1b = 0; c.ia2b = 0; c.ia3b = 0; c.q0 = 0; c.q1 = 0; c.q2 = 0;
+  c.gbase = 0; c.q0 = 0; c.q1 = 0; c.q2 = 0;
 #pragma unroll
   for (int k = MAXF - 1; k >= 0; --k) {
     if (k < P.nfixed) {
@@ -370,13 +365,8 @@ __device__ __forceinline__ TileCtx decode_tile(const PassDesc& P, long long tile
       tile /= e;
       const int gc = cc + P.foff[k];
       c.gbase += (long long)cc * P.fstride[k];
-      c.ia1b += gc * P.fa1[k]; c.ia2b += gc * P.fa2[k]; c.ia3b += gc * P.fa3[k];
       c.q0 += gc * P.fq[0][k]; c.q1 += gc * P.fq[1][k]; c.q2 += gc * P.fq[2][k];
     }
-  }
-#pragma unroll
-  for (int j = 0; j < 3; ++j) {
-    c.ia1b += P.toff[j] * P.ta1[j]; c.ia2b += P.toff[j] * P.ta2[j]; c.ia3b += P.toff[j] * P.ta3[j];
   }
   return c;
 }
@@ -384,9 +374,9 @@ __device__ __forceinline__ TileCtx decode_tile(const PassDesc& P, long long tile
 // One workgroup per tile.  Phases (each thread revisits the same EPT units of VEC doubles):
 //   load   : all global loads of the thread issued back to back (tile, c1 for the JVP, and the
 //            transition matrices of the block's steps), then parked in LDS
-//   pow    : x = a1 w^theta in place in LDS (first pass of T)
+//   pow    : x = w^theta in place in LDS (first pass of T)
 //   MFMA   : up to three contractions in place in LDS
-//   pow    : Tw = 1 + beta (K S)^(1/theta) in place in LDS (last pass of T)
+//   pow    : Tw = 1 + beta S^(1/theta) in place in LDS (last pass of T)
 //   store  : residual / JVP scaling and the global store
 // Two 512-thread workgroups share a CU (LDS-limited), so one block's memory phases overlap the
 // other's MFMA / pow phases.  MODE is the compile-time role of the launch.
@@ -495,13 +485,12 @@ pass_kernel(const PassDesc P, const PassIO io) {
       const bool valid = tid + it * B < tot;
       const int t2 = wk.t2u * VEC;
       const int lo = valid ? wk.t0 * L0 + wk.t1 * L1 + t2 : 0;
-      const int i1 = valid ? cur.ia1b + wk.t0 * P.ta1[0] + wk.t1 * P.ta1[1] + t2 * P.ta1[2] : 0;
       VecT<VEC> x, c1;
       x.load(lds + lo);
 #pragma unroll
       for (int j = 0; j < VEC; ++j) {
         const double xin = valid ? x.v[j] : 1.0;
-        const double xw = P.a1[valid ? i1 + j * P.ta1[2] : 0] * pow_fast<true>(xin, P.theta, PT);
+        const double xw = pow_fast<true>(xin, P.theta, PT);
         if (LINP) c1.v[j] = xw / xin;                           // c1 = a1 w^(theta-1)
         x.v[j] = xw;
       }
@@ -533,15 +522,12 @@ pass_kernel(const PassDesc P, const PassIO io) {
       const bool valid = tid + it * B < tot;
       const int t2 = wk.t2u * VEC;
       const int lo = valid ? wk.t0 * L0 + wk.t1 * L1 + t2 : 0;
-      const int i2 = valid ? cur.ia2b + wk.t0 * P.ta2[0] + wk.t1 * P.ta2[1] + t2 * P.ta2[2] : 0;
-      const int i3 = valid ? cur.ia3b + wk.t0 * P.ta3[0] + wk.t1 * P.ta3[1] + t2 * P.ta3[2] : 0;
       VecT<VEC> y, c2;
       y.load(lds + lo);
 #pragma unroll
       for (int j = 0; j < VEC; ++j) {
         const double sv = valid ? y.v[j] : 1.0;
-        const double ks = P.a2[valid ? i2 + j * P.ta2[2] : 0] * P.a3[valid ? i3 + j * P.ta3[2] : 0] * sv;
-        const double uu = pow_fast<false>(ks, P.inv_theta, PT);
+        const double uu = pow_fast<false>(sv, P.inv_theta, PT);
         if (LINE) c2.v[j] = P.beta * uu / sv;                   // c2 = beta K (K S)^(1/theta-1) = beta u / S
         y.v[j] = 1.0 + P.beta * uu;
       }

@@ -38,7 +38,6 @@ struct AxisInfo {
   const double* Q = nullptr;   // device transition tensor [.., n, n]
   int qs[MAXD] = {0, 0, 0, 0, 0, 0};  // matrix-index stride per conditioning axis
   long long qcount = 0;        // number of n x n matrices in Q
-  int a1s = 0, a2s = 0, a3s = 0;
   char name[8] = "";
 };
 
@@ -79,7 +78,6 @@ struct sdfs_handle {
 
   // device copies of the model tensors
   std::vector<double*> dev_allocs;
-  double *a1 = nullptr, *a2 = nullptr, *a3 = nullptr;
   AxisInfo ax[MAXD];
 
   // plans: [0] full grid (or stage 0 of a sharded run), [1] stage 1 of a sharded run
@@ -242,11 +240,10 @@ int build_plan(sdfs_handle* h, Plan& plan, const std::vector<int>& todo_in, std:
     memset(&P.d, 0, sizeof P.d);
     PassDesc& d = P.d;
     const int nt = (int)tile.size();
-    for (int j = 0; j < 3; ++j) { d.m[j] = 1; d.toff[j] = 0; d.gstride[j] = 0; d.ta1[j] = d.ta2[j] = d.ta3[j] = 0; }
+    for (int j = 0; j < 3; ++j) { d.m[j] = 1; d.toff[j] = 0; d.gstride[j] = 0; }
     for (int j = 0; j < nt; ++j) {
       const int slot = 3 - nt + j, a = tile[j];
       d.m[slot] = (a == chunk_axis) ? chunk : h->ax[a].nloc; d.toff[slot] = h->ax[a].off; d.gstride[slot] = (int)stride[a];
-      d.ta1[slot] = h->ax[a].a1s; d.ta2[slot] = h->ax[a].a2s; d.ta3[slot] = h->ax[a].a3s;
       P.tile_axes[slot] = a;
     }
     d.nfixed = 0;
@@ -256,7 +253,6 @@ int build_plan(sdfs_handle* h, Plan& plan, const std::vector<int>& todo_in, std:
         if (d.nfixed >= MAXF) return fail(h, SDFS_ERR_UNSUPPORTED, "too many fixed axes");
         const int k = d.nfixed++;
         d.fext[k] = h->ax[a].nloc / chunk; d.foff[k] = 0; d.fstride[k] = stride[a] * chunk;
-        d.fa1[k] = h->ax[a].a1s * chunk; d.fa2[k] = h->ax[a].a2s * chunk; d.fa3[k] = h->ax[a].a3s * chunk;
         for (int s = 0; s < (int)G.size(); ++s) d.fq[s][k] = 0;
         ntiles *= d.fext[k];
         continue;
@@ -265,7 +261,6 @@ int build_plan(sdfs_handle* h, Plan& plan, const std::vector<int>& todo_in, std:
       if (d.nfixed >= MAXF) return fail(h, SDFS_ERR_UNSUPPORTED, "too many fixed axes");
       const int k = d.nfixed++;
       d.fext[k] = h->ax[a].nloc; d.foff[k] = h->ax[a].off; d.fstride[k] = stride[a];
-      d.fa1[k] = h->ax[a].a1s; d.fa2[k] = h->ax[a].a2s; d.fa3[k] = h->ax[a].a3s;
       for (int s = 0; s < (int)G.size(); ++s) d.fq[s][k] = h->ax[G[s]].qs[a];
       ntiles *= h->ax[a].nloc;
     }
@@ -406,7 +401,6 @@ int launch_pass(sdfs_handle* h, Pass& P, int pro, int epi, const PassIO& io, int
   PassDesc d = P.d;
   d.pro = pro; d.epi = epi; d.minus_identity = minus_identity;
   d.theta = h->theta; d.inv_theta = 1.0 / h->theta; d.beta = h->beta;
-  d.a1 = h->a1; d.a2 = h->a2; d.a3 = h->a3;
   d.ablate = env_int("SDFS_ABLATE", 0);
   int cid = -1;
   if (h->profiling) {
@@ -857,16 +851,20 @@ int setup_model(sdfs_handle* h, int model, int ndim, const int64_t* shapes, cons
     for (size_t i = 0; i < a3.size(); ++i) a3[i] = std::exp((1 - gamma) * (mu_c + arrays[6][i])); // :124
     const int qi[4] = {1, 3, 5, 7};
     const char* nm[4] = {"h_lam", "h_c", "h_z", "z"};
+    // The scale tables are folded into the transition tensors once, here, so the kernels' pow loops
+    // need no lookups:  Ql[l,L]*a1[L] (next state),  a2[k]*Qc[k,K]  and  a3[i,j]*zQ[i,j,J] (current state).
+    std::vector<double> qf[4];
+    for (int a = 0; a < 4; ++a) qf[a].assign(arrays[qi[a]], arrays[qi[a]] + sizes[qi[a]]);
+    for (int l = 0; l < nl; ++l) for (int L = 0; L < nl; ++L) qf[0][(size_t)l * nl + L] *= a1[L];
+    for (int k = 0; k < nc; ++k) for (int K = 0; K < nc; ++K) qf[1][(size_t)k * nc + K] *= a2[k];
+    for (size_t r = 0; r < a3.size(); ++r) for (int J = 0; J < nj; ++J) qf[3][r * nj + J] *= a3[r];
     for (int a = 0; a < 4; ++a) {
       double* q = nullptr;
-      if ((rc = upload(h, &q, arrays[qi[a]], (size_t)sizes[qi[a]]))) return rc;
+      if ((rc = upload(h, &q, qf[a].data(), qf[a].size()))) return rc;
       h->ax[a].Q = q; h->ax[a].qcount = sizes[qi[a]] / ((long long)h->shape[a] * h->shape[a]);
       strncpy(h->ax[a].name, nm[a], sizeof h->ax[a].name - 1);
     }
     h->ax[3].qs[2] = 1;                 // z_Q[i, j, J] conditioned on the current h_z index
-    h->ax[0].a1s = 1;                   // a1[l]
-    h->ax[1].a2s = 1;                   // a2[k]
-    h->ax[2].a3s = nj; h->ax[3].a3s = 1;  // a3[i, j]
   } else if (model == SDFS_MODEL_GCY) {
     if (ndim != 6 || nparams != 18 || narrays != 15) return fail(h, SDFS_ERR_ARG, "GCY needs ndim 6, 18 params, 15 arrays");
     // params: beta, psi, gamma, rho_lam, s_lam, mu_c, ...  (gcy_model.py:72-75)
@@ -886,9 +884,16 @@ int setup_model(sdfs_handle* h, int model, int ndim, const int64_t* shapes, cons
     for (size_t i = 0; i < a3.size(); ++i) a3[i] = std::exp((1 - gamma) * (mu_c + arrays[0][i]));   // :186, layout [b,c,e,a]
     const int qi[6] = {1, 3, 5, 8, 11, 14};
     const char* nm[6] = {"z", "z_pi", "h_z", "h_c", "h_zpi", "h_lam"};
+    // scale tables folded into the transition tensors (see SSY above):
+    // Qhl[f,F]*a1[F],  a2[d]*Qhc[d,D],  a3[b,c,e,a]*zQ[b,c,e,a,A]
+    std::vector<double> qf[6];
+    for (int a = 0; a < 6; ++a) qf[a].assign(arrays[qi[a]], arrays[qi[a]] + sizes[qi[a]]);
+    for (int f = 0; f < nf; ++f) for (int F = 0; F < nf; ++F) qf[5][(size_t)f * nf + F] *= a1[F];
+    for (int d = 0; d < nd; ++d) for (int D = 0; D < nd; ++D) qf[3][(size_t)d * nd + D] *= a2[d];
+    for (size_t r = 0; r < a3.size(); ++r) for (int A = 0; A < na; ++A) qf[0][r * na + A] *= a3[r];
     for (int a = 0; a < 6; ++a) {
       double* q = nullptr;
-      if ((rc = upload(h, &q, arrays[qi[a]], (size_t)sizes[qi[a]]))) return rc;
+      if ((rc = upload(h, &q, qf[a].data(), qf[a].size()))) return rc;
       h->ax[a].Q = q; h->ax[a].qcount = sizes[qi[a]] / ((long long)h->shape[a] * h->shape[a]);
       strncpy(h->ax[a].name, nm[a], sizeof h->ax[a].name - 1);
     }
@@ -896,17 +901,11 @@ int setup_model(sdfs_handle* h, int model, int ndim, const int64_t* shapes, cons
     h->ax[0].qs[1] = (int)(nc * ne); h->ax[0].qs[2] = (int)ne; h->ax[0].qs[4] = 1;
     // z_pi_Q[e, b, B]: conditioned on current h_zpi
     h->ax[1].qs[4] = 1;
-    h->ax[5].a1s = 1;                   // a1[f]
-    h->ax[3].a2s = 1;                   // a2[d]
-    h->ax[0].a3s = 1; h->ax[4].a3s = (int)na; h->ax[2].a3s = (int)(ne * na); h->ax[1].a3s = (int)(nc * ne * na);  // a3[b,c,e,a]
   } else {
     return fail(h, SDFS_ERR_ARG, "unknown model %d", model);
   }
   if (!(h->theta == h->theta) || h->theta == 0.0 || !std::isfinite(h->theta))
     return fail(h, SDFS_ERR_ARG, "theta = (1-gamma)/(1-1/psi) is not finite / zero");
-  if ((rc = upload(h, &h->a1, a1.data(), a1.size())) || (rc = upload(h, &h->a2, a2.data(), a2.size())) ||
-      (rc = upload(h, &h->a3, a3.data(), a3.size())))
-    return rc;
   return 0;
 }
 
