@@ -75,6 +75,7 @@ struct PassIO {
   const unsigned long long* gate;   // if non-null and *gate <= tol bits: the iteration has converged, do nothing
   double gate_tol;
   unsigned long long* dbg;          // diagnostic builds (-DSDFS_STAMP): per-phase s_memtime stamps
+  unsigned* cu_token;               // optional per-CU compute tokens (4096 words, zeroed), or null
 };
 
 typedef double v4d __attribute__((ext_vector_type(4)));
@@ -116,7 +117,8 @@ __device__ __forceinline__ double fma_sc(double a, double b, double c) {
 // HIPREC = true : log2 x carried as hi + lo (needed when |y| is large: w^theta, theta = -16 .. -36)
 // HIPREC = false: plain double log2 x (enough for |y| < 1: the (K S)^(1/theta) of the aggregator)
 template <bool HIPREC>
-__device__ __forceinline__ double pow_fast(double x, double y, const PowLane& T) {
+__device__ __forceinline__ double pow_core(double x, double y, const PowLane& T) {
+#pragma clang fp contract(off)
   // subnormal inputs: rescale by 2^64 (exact) and fix the exponent below
   const bool tiny = x < 0x1p-1022;
   const double xs = tiny ? x * 0x1p64 : x;
@@ -161,17 +163,119 @@ __device__ __forceinline__ double pow_fast(double x, double y, const PowLane& T)
   double p = fma_sc(f, POW_E7, POW_E6);
   p = fma_sc(p, f, POW_E5); p = fma_sc(p, f, POW_E4);
   p = fma_sc(p, f, POW_E3); p = fma_sc(p, f, POW_E2); p = fma_sc(p, f, POW_E1);
-  double res = ldexp(fma(t, p * f, t), j >> 6);
-  // IEEE corner cases of pow for the inputs this path can meet (y finite, y != 0): rare, kept
-  // out of the straight-line code
+  return ldexp(fma(t, p * f, t), j >> 6);
+}
+
+// IEEE corner cases of pow for the inputs this path can meet (y finite, y != 0): rare, kept out
+// of the straight-line code so that the chains of neighbouring elements interleave
+__device__ __forceinline__ bool pow_special(double x) {
+  return !(x > 0.0 && x < __longlong_as_double(0x7ff0000000000000LL));
+}
+__device__ __forceinline__ double pow_fix(double x, double y, double res) {
   const double inf = __longlong_as_double(0x7ff0000000000000LL);
-  if (__builtin_expect(!(x > 0.0 && x < inf), 0)) {
+  if (pow_special(x)) {
     if (x == 0.0) res = y < 0.0 ? inf : 0.0;
     else if (x == inf) res = y < 0.0 ? 0.0 : inf;
     else res = __longlong_as_double(0x7ff8000000000000LL);   // negative base or NaN
   }
   return res;
 }
+
+// N independent powers -- the form the kernels use.  Written step by step across the N elements
+// (structure-of-arrays) so that the dependent chains and table gathers of neighbouring elements
+// interleave in one basic block.  The straight-line code assumes a positive normal x and a result
+// well inside the normal range; anything else (x <= 0, subnormal, Inf, NaN, |y log2 x| >= 1020)
+// sends the whole wave through pow_core / pow_fix once more (wave-uniform branch: the gathers need
+// every lane active).  Compared with pow_core the fast path
+//   * takes index, exponent and mantissa from the high word only (POW_OFF has a zero low word),
+//   * gets the rounding error of hi = fma(r, 1/ln2, t1) from d = t1 - hi (exact: t1 is a multiple
+//     of 2^-40, |r/ln2| <= 0.0113 < |t1|/2 whenever t1 != 0) and e = fma(r, 1/ln2, d),
+//   * stops the log2 Taylor series at r^8 (r^7 when |y| < 1) and the exp2 series at f^6
+//     (|r|, |f| <= 2^-7: the first dropped terms are below 2^-65 resp. 2^-58.5 and 2^-65),
+//   * rounds y log2 x to a multiple of 1/64 with the 1.5 * 2^46 shift and scales by 2^(j >> 6)
+//     with an integer add on the exponent field.
+#define SDFS_FORJ _Pragma("unroll") for (int j = 0; j < N; ++j)
+__device__ __forceinline__ double gather64b(double v, int byte_idx) {
+  const int lo = __builtin_amdgcn_ds_bpermute(byte_idx, __double2loint(v));
+  const int hi = __builtin_amdgcn_ds_bpermute(byte_idx, __double2hiint(v));
+  return __hiloint2double(hi, lo);
+}
+template <bool HIPREC, int N>
+__device__ __forceinline__ void pow_fast_n(const double (&x)[N], double y, const PowLane& T, double (&res)[N]) {
+  // every product below that must round on its own is written as a separate statement: the compiler
+  // may not fuse it into a neighbouring add (y * hi fused into ehi - kk counts its rounding twice)
+#pragma clang fp contract(off)
+  constexpr int OFFH = (int)(POW_OFF >> 32);
+  constexpr double SHIFT = 0x1.8p46;
+  int i4[N], ji[N];
+  double kd[N], z[N], invc[N], lchi[N], lclo[N], r[N], t1[N], q[N], ehi[N], elo[N], f[N], t[N], p[N];
+  bool rare = false;
+  SDFS_FORJ {
+    const int hx = __double2hiint(x[j]);
+    const int tmph = hx - OFFH;
+    rare |= (unsigned)(hx - 0x00100000) >= 0x7fe00000u;
+    i4[j] = (tmph >> 12) & 0xfc;
+    kd[j] = (double)(tmph >> 20);
+    z[j] = __hiloint2double(hx - (tmph & (int)0xfff00000), __double2loint(x[j]));
+  }
+  SDFS_FORJ invc[j] = gather64b(T.invc, i4[j]);
+  SDFS_FORJ lchi[j] = gather64b(T.lchi, i4[j]);
+  SDFS_FORJ lclo[j] = gather64b(T.lclo, i4[j]);
+  SDFS_FORJ r[j] = fma(z[j], invc[j], -1.0);
+  SDFS_FORJ t1[j] = kd[j] + lchi[j];                 // exact: lchi is a multiple of 2^-40, |kd| < 2^11
+  if (HIPREC) {
+    SDFS_FORJ q[j] = fma_sc(r[j], POW_L8, POW_L7);
+    SDFS_FORJ q[j] = fma_sc(q[j], r[j], POW_L6);
+  } else {
+    SDFS_FORJ q[j] = fma_sc(r[j], POW_L7, POW_L6);
+  }
+  SDFS_FORJ q[j] = fma_sc(q[j], r[j], POW_L5);
+  SDFS_FORJ q[j] = fma_sc(q[j], r[j], POW_L4);
+  SDFS_FORJ q[j] = fma_sc(q[j], r[j], POW_L3);
+  SDFS_FORJ q[j] = fma_sc(q[j], r[j], POW_L2);
+  if (HIPREC) {
+    double hi[N], d[N], e[N], lo[N];
+    SDFS_FORJ hi[j] = fma(r[j], POW_INVLN2_HI, t1[j]);
+    SDFS_FORJ d[j] = t1[j] - hi[j];
+    SDFS_FORJ e[j] = fma(r[j], POW_INVLN2_HI, d[j]);
+    SDFS_FORJ lo[j] = fma(r[j] * r[j], q[j], e[j] + fma(r[j], POW_INVLN2_LO, lclo[j]));
+    SDFS_FORJ ehi[j] = y * hi[j];
+    SDFS_FORJ elo[j] = fma(y, lo[j], fma(y, hi[j], -ehi[j]));
+  } else {
+    double sm[N], hi[N], e2[N];
+    SDFS_FORJ sm[j] = fma(r[j] * r[j], q[j], fma(r[j], POW_INVLN2_HI, lclo[j]));
+    SDFS_FORJ hi[j] = t1[j] + sm[j];
+    SDFS_FORJ e2[j] = sm[j] - (hi[j] - t1[j]);       // fast two-sum (|t1| >= |sm| whenever it matters)
+    SDFS_FORJ ehi[j] = y * hi[j];
+    SDFS_FORJ elo[j] = fma(y, e2[j], fma(y, hi[j], -ehi[j]));
+  }
+  SDFS_FORJ rare |= !(fabs(ehi[j]) < 1020.0);
+  SDFS_FORJ {
+    double kk = ehi[j] + SHIFT;                      // low mantissa bits: round(64 ehi)
+    ji[j] = __double2loint(kk);
+    kk -= SHIFT;
+    f[j] = (ehi[j] - kk) + elo[j];
+  }
+  SDFS_FORJ t[j] = gather64b(T.e2t, (ji[j] & 63) << 2);
+  SDFS_FORJ p[j] = fma_sc(f[j], POW_E6, POW_E5);
+  SDFS_FORJ p[j] = fma_sc(p[j], f[j], POW_E4);
+  SDFS_FORJ p[j] = fma_sc(p[j], f[j], POW_E3);
+  SDFS_FORJ p[j] = fma_sc(p[j], f[j], POW_E2);
+  SDFS_FORJ p[j] = fma_sc(p[j], f[j], POW_E1);
+  SDFS_FORJ {
+    const double v = fma(t[j], p[j] * f[j], t[j]);
+    res[j] = __hiloint2double(__double2hiint(v) + ((ji[j] >> 6) << 20), __double2loint(v));
+  }
+  if (__builtin_expect(__builtin_amdgcn_ballot_w64(rare) != 0ULL, 0)) {
+    SDFS_FORJ {
+      const double c = pow_fix(x[j], y, pow_core<HIPREC>(x[j], y, T));
+      const int hx = __double2hiint(x[j]);
+      const bool rj = (unsigned)(hx - 0x00100000) >= 0x7fe00000u || !(fabs(ehi[j]) < 1020.0);
+      res[j] = rj ? c : res[j];
+    }
+  }
+}
+#undef SDFS_FORJ
 
 // XCD-aware block -> tile map: blocks b, b+8, b+16.. share an XCD (round-robin
 // dispatch), so give each XCD one contiguous chunk of tiles: neighbouring tiles
@@ -228,16 +332,19 @@ template <> struct VecT<2> {
 // is then one address add + one ds_read_b64 per k-step next to the MFMAs.
 template <int N16, int N4>
 __device__ __forceinline__ void contract_cols(double* __restrict__ lds, const double* __restrict__ Qm,
-                                              const int n, const int KT, const int Ls, const int Lu,
+                                              const int n, const int Ls, const int Lu,
                                               const int Lv, const int mv, const int ncols,
                                               const int lane, const int wave, const int nwaves) {
   constexpr int A16 = N16 > 0 ? N16 : 1, A4 = N4 > 0 ? N4 : 1;
   const int li = lane & 15, lk = lane >> 4, l4 = lane & 3;
   constexpr int rb = 16 * N16;
-  double a16[A16][8], a4[A4][8];
-  int roff[8];
+  // k-steps are a compile-time count per shape (the Q fragments of steps past n are zero), so the
+  // trip below is one basic block: every B read is issued before the first MFMA waits on one
+  constexpr int KT = N16 == 2 ? 8 : 4 * N16 + N4;
+  double a16[A16][KT], a4[A4][KT];
+  int roff[KT];
 #pragma unroll
-  for (int kk = 0; kk < 8; ++kk) {
+  for (int kk = 0; kk < KT; ++kk) {
     const int I0 = 4 * kk + lk;
     const bool iok = I0 < n;
     const int I = iok ? I0 : n - 1;          // rows >= n meet zero Q columns; keep the read in bounds
@@ -245,12 +352,12 @@ __device__ __forceinline__ void contract_cols(double* __restrict__ lds, const do
 #pragma unroll
     for (int t = 0; t < N16; ++t) {
       const int row = 16 * t + li;
-      a16[t][kk] = (kk < KT && iok && row < n) ? Qm[row * n + I] : 0.0;
+      a16[t][kk] = (iok && row < n) ? Qm[row * n + I] : 0.0;
     }
 #pragma unroll
     for (int t = 0; t < N4; ++t) {
       const int row = rb + 4 * t + l4;
-      a4[t][kk] = (kk < KT && iok && row < n) ? Qm[row * n + I] : 0.0;
+      a4[t][kk] = (iok && row < n) ? Qm[row * n + I] : 0.0;
     }
   }
   // column walk: col = ct*16 + li, advancing by 16*nwaves per trip
@@ -268,15 +375,15 @@ __device__ __forceinline__ void contract_cols(double* __restrict__ lds, const do
     for (int t = 0; t < A16; ++t) acc[t] = (v4d){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
     for (int t = 0; t < A4; ++t) d[t] = 0.0;
+    double b[KT];
 #pragma unroll
-    for (int kk = 0; kk < 8; ++kk) {
-      if (kk < KT) {
-        const double b = lds[cbase + roff[kk]];
+    for (int kk = 0; kk < KT; ++kk) b[kk] = lds[cbase + roff[kk]];
 #pragma unroll
-        for (int t = 0; t < N16; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a16[t][kk], b, acc[t], 0, 0, 0);
+    for (int kk = 0; kk < KT; ++kk) {
 #pragma unroll
-        for (int t = 0; t < N4; ++t) d[t] = __builtin_amdgcn_mfma_f64_4x4x4f64(a4[t][kk], b, d[t], 0, 0, 0);
-      }
+      for (int t = 0; t < N16; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a16[t][kk], b[kk], acc[t], 0, 0, 0);
+#pragma unroll
+      for (int t = 0; t < N4; ++t) d[t] = __builtin_amdgcn_mfma_f64_4x4x4f64(a4[t][kk], b[kk], d[t], 0, 0, 0);
     }
     if (colok) {
       // 16x16x4 D map: col = lane&15, row = (lane>>4) + 4*reg
@@ -310,8 +417,7 @@ __device__ __forceinline__ void contract_step(double* __restrict__ lds, const Pa
   else if (slot == 1) { Ls = P.L[1]; Lu = P.L[0]; mu = P.m[0]; Lv = 1; mv = P.m[2]; }
   else { Ls = 1; Lu = P.L[0]; mu = P.m[0]; Lv = P.L[1]; mv = P.m[1]; }
   const int ncols = mu * mv;
-  const int KT = (n + 3) >> 2;
-#define SDFS_CC(A, B4) contract_cols<A, B4>(lds, Qm, n, KT, Ls, Lu, Lv, mv, ncols, lane, wave, nwaves)
+#define SDFS_CC(A, B4) contract_cols<A, B4>(lds, Qm, n, Ls, Lu, Lv, mv, ncols, lane, wave, nwaves)
   if (n <= 4) SDFS_CC(0, 1);
   else if (n <= 8) SDFS_CC(0, 2);
   else if (n <= 12) SDFS_CC(0, 3);
@@ -344,6 +450,28 @@ __device__ __forceinline__ void opaque(int (&a)[N]) {
 #else
 #define STAMP(slot) do {} while (0)
 #endif
+
+// Per-CU compute token.  fp64 MFMA and fp64 VALU share one datapath on gfx950 (tools/probes/
+// coissue_probe.hip: their times add), so two co-resident workgroups that compute at the same time
+// only slow each other down while the memory pipes idle.  With the token a workgroup computes alone
+// and its neighbour's loads / stores run underneath.  The slot is the physical CU (XCC id + SE/SH/CU
+// bits of HW_ID); the spin is bounded, so a stale token can delay a block but never hang it.
+__device__ __forceinline__ unsigned cu_token_slot() {
+  unsigned hw, xcc;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+  return ((xcc & 15u) << 8) | ((hw >> 8) & 0xffu);
+}
+__device__ __forceinline__ bool cu_token_acquire(unsigned* tok) {
+  for (int spin = 0; spin < 20000; ++spin) {
+    unsigned expect = 0u;
+    // relaxed: the token orders no data, and acquire/release at agent scope would flush the XCD's L2
+    if (__hip_atomic_compare_exchange_strong(tok, &expect, 1u, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                             __HIP_MEMORY_SCOPE_AGENT)) return true;
+    __builtin_amdgcn_s_sleep(16);
+  }
+  return false;
+}
 
 // Compile-time role of a launch inside one operator application.
 enum PassMode { M_MID = 0, M_TFIRST = 1, M_TLAST = 2, M_TONLY = 3, M_JFIRST = 4, M_JLAST = 5,
@@ -472,6 +600,15 @@ pass_kernel(const PassDesc P, const PassIO io) {
   }
   STAMP(2);
 
+  // compute token: taken only once every load of the block has landed in LDS
+  unsigned* tok = nullptr;
+  bool have_tok = false;
+  if (io.cu_token != nullptr) {
+    __syncthreads();
+    if (tid == 0) { tok = io.cu_token + cu_token_slot(); have_tok = cu_token_acquire(tok); }
+    __syncthreads();
+  }
+
   PowLane PT;
   if (POWP || CES) PT = pow_lane_init(lane);
 
@@ -487,12 +624,14 @@ pass_kernel(const PassDesc P, const PassIO io) {
       const int lo = valid ? wk.t0 * L0 + wk.t1 * L1 + t2 : 0;
       VecT<VEC> x, c1;
       x.load(lds + lo);
+      double xin[VEC], xw[VEC];
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) xin[j] = valid ? x.v[j] : 1.0;
+      pow_fast_n<true, VEC>(xin, P.theta, PT, xw);
 #pragma unroll
       for (int j = 0; j < VEC; ++j) {
-        const double xin = valid ? x.v[j] : 1.0;
-        const double xw = pow_fast<true>(xin, P.theta, PT);
-        if (LINP) c1.v[j] = xw / xin;                           // c1 = a1 w^(theta-1)
-        x.v[j] = xw;
+        if (LINP) c1.v[j] = xw[j] / xin[j];                     // c1 = a1 w^(theta-1)
+        x.v[j] = xw[j];
       }
       if (valid) {
         x.store(lds + lo);
@@ -524,12 +663,14 @@ pass_kernel(const PassDesc P, const PassIO io) {
       const int lo = valid ? wk.t0 * L0 + wk.t1 * L1 + t2 : 0;
       VecT<VEC> y, c2;
       y.load(lds + lo);
+      double sv[VEC], uu[VEC];
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) sv[j] = valid ? y.v[j] : 1.0;
+      pow_fast_n<false, VEC>(sv, P.inv_theta, PT, uu);
 #pragma unroll
       for (int j = 0; j < VEC; ++j) {
-        const double sv = valid ? y.v[j] : 1.0;
-        const double uu = pow_fast<false>(sv, P.inv_theta, PT);
-        if (LINE) c2.v[j] = P.beta * uu / sv;                   // c2 = beta K (K S)^(1/theta-1) = beta u / S
-        y.v[j] = 1.0 + P.beta * uu;
+        if (LINE) c2.v[j] = P.beta * uu[j] / sv[j];             // c2 = beta K (K S)^(1/theta-1) = beta u / S
+        y.v[j] = 1.0 + P.beta * uu[j];
       }
       if (valid) {
         y.store(lds + lo);
@@ -539,6 +680,10 @@ pass_kernel(const PassDesc P, const PassIO io) {
     }
   }
   STAMP(11);
+  if (io.cu_token != nullptr) {
+    if (CES) __syncthreads();
+    if (have_tok) __hip_atomic_store(tok, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
 
   // ---- residual / scaling and the global store -------------------------------------------
   const bool need_old = CES ? (io.resid != nullptr) : (MULE && P.minus_identity);
@@ -607,8 +752,10 @@ __global__ void __launch_bounds__(256) debug_pow_kernel(const double* __restrict
   const PowLane PT = pow_lane_init(threadIdx.x & 63);
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const double xv = i < n ? x[i] : 1.0;
-  const double r = fabs(y) < 1.0 ? pow_fast<false>(xv, y, PT) : pow_fast<true>(xv, y, PT);
-  if (i < n) out[i] = r;
+  const double xin[1] = {xv};
+  double r[1];
+  if (fabs(y) < 1.0) pow_fast_n<false, 1>(xin, y, PT, r); else pow_fast_n<true, 1>(xin, y, PT, r);
+  if (i < n) out[i] = r[0];
 }
 
 typedef void (*pass_fn)(const PassDesc, const PassIO);
