@@ -75,7 +75,6 @@ struct PassIO {
   const unsigned long long* gate;   // if non-null and *gate <= tol bits: the iteration has converged, do nothing
   double gate_tol;
   unsigned long long* dbg;          // diagnostic builds (-DSDFS_STAMP): per-phase s_memtime stamps
-  unsigned* cu_token;               // optional per-CU compute tokens (4096 words, zeroed), or null
 };
 
 typedef double v4d __attribute__((ext_vector_type(4)));
@@ -451,28 +450,6 @@ __device__ __forceinline__ void opaque(int (&a)[N]) {
 #define STAMP(slot) do {} while (0)
 #endif
 
-// Per-CU compute token.  fp64 MFMA and fp64 VALU share one datapath on gfx950 (tools/probes/
-// coissue_probe.hip: their times add), so two co-resident workgroups that compute at the same time
-// only slow each other down while the memory pipes idle.  With the token a workgroup computes alone
-// and its neighbour's loads / stores run underneath.  The slot is the physical CU (XCC id + SE/SH/CU
-// bits of HW_ID); the spin is bounded, so a stale token can delay a block but never hang it.
-__device__ __forceinline__ unsigned cu_token_slot() {
-  unsigned hw, xcc;
-  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
-  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-  return ((xcc & 15u) << 8) | ((hw >> 8) & 0xffu);
-}
-__device__ __forceinline__ bool cu_token_acquire(unsigned* tok) {
-  for (int spin = 0; spin < 20000; ++spin) {
-    unsigned expect = 0u;
-    // relaxed: the token orders no data, and acquire/release at agent scope would flush the XCD's L2
-    if (__hip_atomic_compare_exchange_strong(tok, &expect, 1u, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
-                                             __HIP_MEMORY_SCOPE_AGENT)) return true;
-    __builtin_amdgcn_s_sleep(16);
-  }
-  return false;
-}
-
 // Compile-time role of a launch inside one operator application.
 enum PassMode { M_MID = 0, M_TFIRST = 1, M_TLAST = 2, M_TONLY = 3, M_JFIRST = 4, M_JLAST = 5,
                 M_TFIRST_LIN = 6, M_TLAST_LIN = 7, M_NMODES = 8 };
@@ -600,15 +577,6 @@ pass_kernel(const PassDesc P, const PassIO io) {
   }
   STAMP(2);
 
-  // compute token: taken only once every load of the block has landed in LDS
-  unsigned* tok = nullptr;
-  bool have_tok = false;
-  if (io.cu_token != nullptr) {
-    __syncthreads();
-    if (tid == 0) { tok = io.cu_token + cu_token_slot(); have_tok = cu_token_acquire(tok); }
-    __syncthreads();
-  }
-
   PowLane PT;
   if (POWP || CES) PT = pow_lane_init(lane);
 
@@ -680,10 +648,6 @@ pass_kernel(const PassDesc P, const PassIO io) {
     }
   }
   STAMP(11);
-  if (io.cu_token != nullptr) {
-    if (CES) __syncthreads();
-    if (have_tok) __hip_atomic_store(tok, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
 
   // ---- residual / scaling and the global store -------------------------------------------
   const bool need_old = CES ? (io.resid != nullptr) : (MULE && P.minus_identity);

@@ -87,7 +87,6 @@ struct sdfs_handle {
 
   // work buffers (lazy)
   double* tmp = nullptr;
-  unsigned* cu_token = nullptr;      // per-CU compute tokens (pass_kernel.hpp), null = disabled
   double *c1 = nullptr, *c2 = nullptr;
   double *buf0 = nullptr, *buf1 = nullptr;
   double *hostio = nullptr;          // device staging for the host-pointer entry points
@@ -455,10 +454,8 @@ int launch_pass(sdfs_handle* h, Pass& P, int pro, int epi, const PassIO& io, int
   }
   return 0;
 #endif
-  PassIO iot = io;
-  iot.cu_token = h->cu_token;
   ProfScope ps(h, cid);
-  hipLaunchKernelGGL(fn, dim3((unsigned)grid), dim3(block), P.lds_bytes, h->stream, d, iot);
+  hipLaunchKernelGGL(fn, dim3((unsigned)grid), dim3(block), P.lds_bytes, h->stream, d, io);
   HIPCHK(h, hipGetLastError());
   return 0;
 }
@@ -938,12 +935,6 @@ int create_common(int model, int ndim, const int64_t* shapes, const double* para
   }
   int rc = setup_model(h, model, ndim, shapes, params, nparams, arrays, sizes, narrays);
   if (rc) return bail(rc);
-  if (env_int("SDFS_CU_TOKEN", 0)) {
-    double* t = nullptr;
-    if ((rc = dev_alloc(h, &t, 4096 * sizeof(unsigned) / sizeof(double)))) return bail(rc);
-    hipMemset(t, 0, 4096 * sizeof(unsigned));
-    h->cu_token = reinterpret_cast<unsigned*>(t);
-  }
   // dynamic LDS above 64 KB has to be allowed per kernel variant (and per device)
   static unsigned long long attr_done = 0;
   if (device_id < 64 && !(attr_done & (1ULL << device_id))) {
