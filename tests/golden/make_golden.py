@@ -54,6 +54,29 @@ def install_shims():
     jax.numpy = jnp
     jax.jit = passthrough
     jax.device_put = lambda x: x
+
+    # the continuous modules also use jax.vmap (over axis 0 of the first argument only),
+    # jax.lax.map and jax.scipy.ndimage.map_coordinates: plain loops and scipy's function
+    def vmap(f, in_axes=0):
+        axes = in_axes if isinstance(in_axes, (tuple, list)) else None
+        def g(*args):
+            if axes is not None:
+                assert axes[0] == 0 and all(a is None for a in axes[1:])
+            return np.stack([f(a0, *args[1:]) for a0 in args[0]])
+        return g
+    jax.vmap = vmap
+    lax = types.ModuleType("jax.lax")
+    lax.map = lambda f, xs: np.stack([f(x) for x in xs])
+    jax.lax = lax
+    import scipy.ndimage as _ndi
+    jsp = types.ModuleType("jax.scipy")
+    jndi = types.ModuleType("jax.scipy.ndimage")
+    jndi.map_coordinates = _ndi.map_coordinates
+    jsp.ndimage = jndi
+    jax.scipy = jsp
+    qquad = types.ModuleType("quantecon.quad")
+    from oracle.continuous import qnwnorm as _qnwnorm
+    qquad.qnwnorm = _qnwnorm
     cfg_mod = types.ModuleType("jax.config")
     cfg_mod.config = types.SimpleNamespace(update=lambda *a, **k: None)
     jax.config = cfg_mod
@@ -64,8 +87,10 @@ def install_shims():
     qe.rouwenhorst = _rouwenhorst
     qe.tic = lambda: None
     qe.toc = lambda: 0.0
-    for name, mod in [("jax", jax), ("jax.numpy", jnp), ("jax.config", cfg_mod),
-                      ("numba", numba), ("jaxopt", jaxopt), ("quantecon", qe)]:
+    qe.quad = qquad
+    for name, mod in [("jax", jax), ("jax.numpy", jnp), ("jax.config", cfg_mod), ("jax.lax", lax),
+                      ("jax.scipy", jsp), ("jax.scipy.ndimage", jndi),
+                      ("numba", numba), ("jaxopt", jaxopt), ("quantecon", qe), ("quantecon.quad", qquad)]:
         sys.modules[name] = mod
 
 
@@ -185,12 +210,61 @@ def main():
                         x_gcy=xg, q_gcy=np.array([f_gcy(x) for x in xg]))
     print("loglinear ok", f_ssy(xs[0]), f_gcy(xg[0]))
 
+    # --- continuous-state operator (code/ssy/continuous_junnan, code/gcy/continuous): the reference's
+    #     build_grid / T_fun_factory / lin_interp run verbatim; quadrature and Monte-Carlo kernels ---
+    continuous_fixtures(ssy, gcy)
+
     # --- recorded notebook output (sandpit.ipynb:41-44), typed in as data ---
     np.savez(os.path.join(HERE, "sandpit_trace.npz"),
              shapes=np.array((10, 10, 10, 10)),
              errors=np.array([4302.341800771495, 4074.9605304521597,
                               112.01772152357796, 3.834976201446807]))
     print("done")
+
+
+def _load_by_path(name, path):
+    """The SSY and GCY continuous modules define the same function names: load each under its own name."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location(name, path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def continuous_fixtures(ssy, gcy):
+    from oracle.continuous import qnwnorm
+    CS = _load_by_path("ref_ssy_cont", REF + "/ssy/continuous_junnan/ssy_wc_ratio_continuous.py")
+    CG = _load_by_path("ref_gcy_cont", REF + "/gcy/continuous/gcy_wc_ratio_continuous.py")
+    rng = np.random.default_rng(7)
+    for tagname, C, model, sizes, d in [("ssy", CS, ssy, (3, 4, 3, 5), 3), ("ssy", CS, ssy, (5, 4, 6, 7), 4),
+                                        ("gcy", CG, gcy, (2, 3, 2, 3, 4, 3), 2), ("gcy", CG, gcy, (3, 2, 3, 2, 3, 4), 3)]:
+        for nsd in (3.2, 1.0):          # 1.0: many next states fall outside the grid (mode='nearest')
+            grids = C.build_grid(model, *sizes, nsd)
+            dim = len(grids)
+            nodes, weights = qnwnorm([d] * dim)
+            nodes = np.asarray(nodes.T)
+            pars = np.array(model.params)
+            w = 5.0 + 20.0 * rng.random(sizes)
+            Tq = C.T_fun_factory((pars, grids, nodes, weights), "quadrature", int(np.prod(sizes)))
+            draws = rng.standard_normal((dim, 50))
+            Tm = C.T_fun_factory((pars, grids, draws), "monte_carlo", int(np.prod(sizes)))
+            xq = np.stack([rng.uniform(g[0] - 0.3 * (g[-1] - g[0]), g[-1] + 0.3 * (g[-1] - g[0]), 40) for g in grids])
+            out = {"params": pars, "sizes": np.array(sizes), "num_std_devs": np.array(nsd), "d": np.array(d),
+                   "nodes": nodes, "weights": weights, "mc_draws": draws, "w": w,
+                   "T_quad": np.asarray(Tq(w)), "T_mc": np.asarray(Tm(w)),
+                   "x_query": xq, "interp": np.asarray(C.lin_interp(xq, w, grids))}
+            out.update({f"grid{i}": np.asarray(g) for i, g in enumerate(grids)})
+            fn = f"cont_{tagname}_{tag(sizes)}_sd{nsd}.npz"
+            np.savez_compressed(os.path.join(HERE, fn), **out)
+            print("continuous", fn, float(out["T_quad"].flat[0]), float(out["T_mc"].flat[0]))
+    # the reference's driver end to end (successive approximation from w = 1, its defaults) on a tiny grid
+    import contextlib, io
+    with contextlib.redirect_stdout(io.StringIO()):
+        grids, w_star = CS.wc_ratio_continuous(ssy, 3, 3, 3, 4, num_std_devs=3.2, d=3,
+                                               algorithm="successive_approx", write_to_file=False)
+    np.savez_compressed(os.path.join(HERE, "cont_ssy_driver_3x3x3x4.npz"), w_star=np.asarray(w_star),
+                        **{f"grid{i}": np.asarray(g) for i, g in enumerate(grids)})
+    print("continuous driver", float(np.asarray(w_star).flat[0]))
 
 
 if __name__ == "__main__":
