@@ -100,6 +100,26 @@ int sdfs_create_sharded(int model, int ndim, const int64_t* shapes,
                         int device_id, int axis_a, int64_t a_lo, int64_t a_len,
                         int axis_b, int64_t b_lo, int64_t b_len, sdfs_handle** out);
 
+/* Continuous-state operator: replaces the closure T_fun_factory(params, method, batch_size) returns
+ * (code/ssy/continuous_junnan/ssy_wc_ratio_continuous.py:156-226,
+ *  code/gcy/continuous/gcy_wc_ratio_continuous.py:190-260):
+ *   Tw(x) = 1 + beta * (const(x) * E_x[ exp(theta h_lambda') * lin_interp(w)(x')^theta ])^(1/theta)
+ * with the expectation a weighted sum over M shock nodes (Gauss-Hermite: `weights` from
+ * quantecon.quad.qnwnorm; Monte Carlo: weights == NULL, plain mean).  `grids`: ndim uniform axis
+ * grids in the reference's order (SSY h_lambda, h_c, h_z, z; GCY h_lambda, h_c, h_z, h_zpi, z, z_pi),
+ * grids[d] has shapes[d] >= 2 points; `nodes`: [ndim][M] row-major, as the reference passes them.
+ * The handle works with every entry point below (apply, JVP, solve, counters); batching is internal
+ * (the reference's batch_size / ram_free only bound JAX's temporaries). */
+int sdfs_create_continuous(int model, int ndim, const int64_t* shapes,
+                           const double* params, int nparams, const double* const* grids,
+                           const double* nodes, const double* weights, int64_t M,
+                           int device_id, sdfs_handle** out);
+
+/* lin_interp(x, fun_vals, grids) of code/utils.py:18-23 (multilinear, indices clipped to the grid):
+ * x is [ndim][nq] row-major, out[nq]; all host pointers; ndim 4 or 6. */
+int sdfs_lin_interp(int device_id, int ndim, const int64_t* shapes, const double* const* grids,
+                    const double* fun_vals, const double* x, int64_t nq, double* out);
+
 void sdfs_destroy(sdfs_handle* h);
 const char* sdfs_last_error(const sdfs_handle* h);   /* h may be NULL: last create error */
 int sdfs_default_opts(sdfs_opts* o);

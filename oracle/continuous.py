@@ -65,7 +65,8 @@ def build_grid_ssy(params, sizes, num_std_devs=3.2):
         g_max = num_std_devs * np.sqrt(s ** 2 / (1 - r ** 2))
         grids.append(np.linspace(-g_max, g_max, n))
     h_z_max = num_std_devs * np.sqrt(s_z ** 2 / (1 - ρ_z ** 2))
-    z_max = num_std_devs * ϕ_z * np.exp(h_z_max)
+    σ_z_max = ϕ_z * np.exp(h_z_max)
+    z_max = num_std_devs * σ_z_max
     grids.append(np.linspace(-z_max, z_max, sizes[3]))
     return tuple(grids)
 

@@ -19,6 +19,8 @@ from .solvers import (successive_approx, newton_solver, anderson_solver,
                       fixed_point_via_gradient_decent, solvers, solver,
                       default_tolerance, default_max_iter)
 from .loglinear import wc_loglinear_factory, loglinear_guess
+from .continuous import (ContinuousOperator, build_grid, T_fun_factory, wc_ratio_continuous, qnwnorm,
+                         lin_interp, vals_to_coords, construct_wstar_callable, save_wstar, load_wstar)
 from ._lib import SdfsError, LIB_PATH
 
 __all__ = ["SSY", "GCY", "rouwenhorst", "discretize_ssy", "discretize_gcy",
@@ -26,4 +28,6 @@ __all__ = ["SSY", "GCY", "rouwenhorst", "discretize_ssy", "discretize_gcy",
            "successive_approx", "newton_solver", "anderson_solver",
            "fixed_point_via_gradient_decent", "solvers", "solver",
            "default_tolerance", "default_max_iter", "wc_loglinear_factory", "loglinear_guess",
+           "ContinuousOperator", "build_grid", "T_fun_factory", "wc_ratio_continuous", "qnwnorm",
+           "lin_interp", "vals_to_coords", "construct_wstar_callable", "save_wstar", "load_wstar",
            "SdfsError", "LIB_PATH"]

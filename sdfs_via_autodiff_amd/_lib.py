@@ -50,6 +50,9 @@ SYMBOLS = {
     "sdfs_create_sharded": (C.c_int, [C.c_int, C.c_int, _I64, _D, C.c_int, C.POINTER(_D), _I64, C.c_int,
                                       C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_int, C.c_int64,
                                       C.c_int64, C.POINTER(_P)]),
+    "sdfs_create_continuous": (C.c_int, [C.c_int, C.c_int, _I64, _D, C.c_int, C.POINTER(_D), _D, _D, C.c_int64,
+                                         C.c_int, C.POINTER(_P)]),
+    "sdfs_lin_interp": (C.c_int, [C.c_int, C.c_int, _I64, C.POINTER(_D), _D, _D, C.c_int64, _D]),
     "sdfs_destroy": (None, [_P]),
     "sdfs_last_error": (C.c_char_p, [_P]),
     "sdfs_default_opts": (C.c_int, [C.POINTER(sdfs_opts)]),

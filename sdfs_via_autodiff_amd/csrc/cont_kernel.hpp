@@ -1,0 +1,207 @@
+// Continuous-state Koopmans operator on gfx950: expectation by quadrature / Monte Carlo over
+// multilinear interpolation of the current iterate.
+//
+// Reference (what is computed, not how):
+//   code/ssy/continuous_junnan/ssy_wc_ratio_continuous.py  next_state :66-87, Kg_vmap_quad :125-150,
+//                                                          Kg_vmap_mc :94-119, T_fun_factory :156-226
+//   code/gcy/continuous/gcy_wc_ratio_continuous.py         next_state :78-116, Kg_vmap_quad :159-184
+//   code/utils.py:6-23                                      vals_to_coords, lin_interp (order 1, 'nearest')
+//
+//   Tw(x) = 1 + beta * ( const(x) * sum_m W_m * exp(theta * h_lambda'(x, m)) * interp(w)(x'(x, m))^theta )^(1/theta)
+//
+// One 256-thread workgroup per grid point x; lanes run over the M shock nodes.  Per node the next
+// state is affine in the node (a_d(x) + k_d(x) * eta_d[m], already in grid coordinates), the 2^D
+// corners are gathered from the iterate (L2 / MALL resident: 160 KB for the 10x10x10x20 SSY grid,
+// 32 MB for the 10^4 x 20^2 GCY grid) and folded depth-first, the power is pow_fast_n.  The factor
+// exp(theta * s_lambda * eta_0[m]) of the reference's `pf` is folded into the node weight on the host,
+// exp(theta * rho_lambda * h_lambda) into the per-point constant.  fp64 VALU bound (no MFMA shape:
+// the power sits between the interpolation sum and the quadrature sum).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "pass_kernel.hpp"
+
+namespace sdfs {
+
+constexpr int CMAXD = 6;
+
+struct ContDesc {
+  int D, M;
+  long long N;
+  int n[CMAXD];
+  long long stride[CMAXD];
+  const double* grid[CMAXD];                     // device copies of the axis grids
+  double lo[CMAXD], inv_step[CMAXD];             // utils.py:11-15: first point, 1 / first spacing
+  // next state of dimension d (the reference's next_state):
+  //   rho[d] * x[d] + xcoef[d] * x[xdim[d]] + vol_d(x) * eta[d],
+  //   vol_d(x) = sconst[d] (voldim[d] < 0)  or  phi[d] * exp(x[voldim[d]])
+  double rho[CMAXD], xcoef[CMAXD], sconst[CMAXD], phi[CMAXD];
+  int xdim[CMAXD], voldim[CMAXD];
+  int zdim, hcdim;                               // the dimensions inside const(x)
+  double one_m_gamma, mu_c, phi_c, theta, inv_theta, beta, theta_rho0;
+  const double* eta;                             // [D][M] shocks
+  const double* wq;                              // [M]  W_m * exp(theta * sconst[0] * eta[0][m])
+};
+
+struct ContIO {
+  const double* w;        // iterate (T modes) or linearisation point (JVP)
+  const double* v;        // JVP direction
+  double* out;
+  double* c2_out;         // T_LIN: beta * C * u / Kg
+  const double* c2_in;    // JVP
+  const double* old;      // T modes: residual against this grid (or null)
+  unsigned long long* resid;
+  const unsigned long long* gate;
+  double gate_tol;
+  int minus_identity;
+};
+
+enum ContMode { C_T = 0, C_TLIN = 1, C_JVP = 2 };
+
+template <int D, int d>
+struct InterpRec {
+  static __device__ __forceinline__ double run(const double* __restrict__ f, long long off,
+                                               const long long (&delta)[D], const double (&t)[D]) {
+    const double v0 = InterpRec<D, d + 1>::run(f, off, delta, t);
+    const double v1 = InterpRec<D, d + 1>::run(f, off + delta[d], delta, t);
+    return fma(t[d], v1 - v0, v0);
+  }
+};
+template <int D>
+struct InterpRec<D, D> {
+  static __device__ __forceinline__ double run(const double* __restrict__ f, long long off,
+                                               const long long (&)[D], const double (&)[D]) {
+    return f[off];
+  }
+};
+
+// coordinates -> (base offset, per-dimension corner step, fraction); map_coordinates(order=1, 'nearest'):
+// weights from the unclipped coordinate, both indices clipped into the grid
+template <int D>
+__device__ __forceinline__ long long interp_setup(const ContDesc& P, const double (&c)[D],
+                                                  long long (&delta)[D], double (&t)[D]) {
+  long long base = 0;
+#pragma unroll
+  for (int d = 0; d < D; ++d) {
+    const double fl = floor(c[d]);
+    t[d] = c[d] - fl;
+    const double hi = (double)(P.n[d] - 1);
+    const int i0 = (int)fmin(fmax(fl, 0.0), hi);
+    const int i1 = (int)fmin(fmax(fl + 1.0, 0.0), hi);
+    base += (long long)i0 * P.stride[d];
+    delta[d] = (long long)(i1 - i0) * P.stride[d];
+  }
+  return base;
+}
+
+template <int D, int MODE>
+__global__ void __launch_bounds__(256) cont_kernel(const ContDesc P, const ContIO io) {
+  __shared__ double red[4];
+  if (io.gate != nullptr) {
+    const unsigned long long g = *io.gate;
+    if (g <= (unsigned long long)__double_as_longlong(io.gate_tol)) return;
+  }
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const long long p = blockIdx.x;
+
+  // this block's grid point and the affine map node -> next-state coordinates
+  double x[D], a[D], k[D];
+  {
+    long long r = p;
+#pragma unroll
+    for (int d = D - 1; d >= 0; --d) {
+      const int i = (int)(r % P.n[d]);
+      r /= P.n[d];
+      x[d] = P.grid[d][i];
+    }
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      double mean = P.rho[d] * x[d];
+      double vol = P.sconst[d];
+#pragma unroll
+      for (int e = 0; e < D; ++e) {
+        if (P.xdim[d] == e) mean += P.xcoef[d] * x[e];
+        if (P.voldim[d] == e) vol = P.phi[d] * exp(x[e]);
+      }
+      a[d] = (mean - P.lo[d]) * P.inv_step[d];
+      k[d] = vol * P.inv_step[d];
+    }
+  }
+
+  const PowLane PT = pow_lane_init(lane);
+  double acc = 0.0;
+  const int trips = (P.M + 255) >> 8;            // uniform: pow_fast_n needs whole waves
+  for (int it = 0; it < trips; ++it) {
+    const int m = it * 256 + tid;
+    const bool valid = m < P.M;
+    double g[1] = {1.0}, iv = 0.0, wq = 0.0;
+    if (valid) {
+      double c[D], t[D];
+      long long delta[D];
+#pragma unroll
+      for (int d = 0; d < D; ++d) c[d] = fma(k[d], P.eta[(long long)d * P.M + m], a[d]);
+      const long long base = interp_setup<D>(P, c, delta, t);
+      g[0] = InterpRec<D, 0>::run(io.w, base, delta, t);
+      if (MODE == C_JVP) iv = InterpRec<D, 0>::run(io.v, base, delta, t);
+      wq = P.wq[m];
+    }
+    double pw[1];
+    pow_fast_n<true, 1>(g, P.theta, PT, pw);
+    if (MODE == C_JVP) acc = fma(wq * (pw[0] / g[0]), iv, acc);      // W g^(theta-1) interp(v)
+    else acc = fma(wq, pw[0], acc);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+  if (lane == 0) red[wave] = acc;
+  __syncthreads();
+  if (wave != 0) return;
+  const double e = (red[0] + red[1]) + (red[2] + red[3]);
+
+  if (MODE == C_JVP) {
+    if (lane == 0) {
+      double r = io.c2_in[p] * e;
+      if (io.minus_identity) r -= io.v[p];
+      io.out[p] = r;
+    }
+    return;
+  }
+  double zval = 0.0, hcval = 0.0;
+#pragma unroll
+  for (int d = 0; d < D; ++d) {
+    if (P.zdim == d) zval = x[d];
+    if (P.hcdim == d) hcval = x[d];
+  }
+  const double sig_c = P.phi_c * exp(hcval);
+  const double C = exp(P.one_m_gamma * (P.mu_c + zval) + 0.5 * P.one_m_gamma * P.one_m_gamma * sig_c * sig_c)
+                   * exp(P.theta_rho0 * x[0]);
+  const double Kg[1] = {C * e};
+  double u[1];
+  pow_fast_n<false, 1>(Kg, P.inv_theta, PT, u);                       // every lane of wave 0, same value
+  if (lane == 0) {
+    const double tw = 1.0 + P.beta * u[0];
+    io.out[p] = tw;
+    if (MODE == C_TLIN) io.c2_out[p] = P.beta * C * u[0] / Kg[0];
+    if (io.resid != nullptr) {
+      double r = fabs(tw - io.old[p]);
+      if (!(r == r)) r = __longlong_as_double(0x7ff0000000000000LL);
+      const unsigned long long rb = (unsigned long long)__double_as_longlong(r);
+      if (rb > *(volatile unsigned long long*)io.resid) atomicMax(io.resid, rb);   // stale read only skips no-ops
+    }
+  }
+}
+
+// lin_interp(x, fun_vals, grids) of code/utils.py:18-23 at n query points, x laid out [D][n]
+template <int D>
+__global__ void __launch_bounds__(256) lin_interp_kernel(const ContDesc P, const double* __restrict__ f,
+                                                         const double* __restrict__ xq, long long nq,
+                                                         double* __restrict__ out) {
+  const long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= nq) return;
+  double c[D], t[D];
+  long long delta[D];
+#pragma unroll
+  for (int d = 0; d < D; ++d) c[d] = (xq[(long long)d * nq + q] - P.lo[d]) * P.inv_step[d];
+  const long long base = interp_setup<D>(P, c, delta, t);
+  out[q] = InterpRec<D, 0>::run(f, base, delta, t);
+}
+
+}  // namespace sdfs

@@ -20,6 +20,7 @@
 
 #include "../../include/sdfs_hip.h"
 #include "pass_kernel.hpp"
+#include "cont_kernel.hpp"
 #include "vec_kernels.hpp"
 
 using namespace sdfs;
@@ -84,6 +85,10 @@ struct sdfs_handle {
   Plan plan[2];
   bool sharded = false;
   int axis_a = -1, axis_b = -1;
+
+  // continuous-state operator (sdfs_create_continuous): no plan, one kernel per application
+  bool cont = false;
+  ContDesc cd;
 
   // work buffers (lazy)
   double* tmp = nullptr;
@@ -473,9 +478,46 @@ int ensure_lin(sdfs_handle* h) {
 
 // Run the passes of `plan`.  first/last tell whether this plan holds the operator's
 // first pass (prologue) and last pass (epilogue) -- a sharded stage holds only one.
+// One application of the continuous-state operator (cont_kernel.hpp) in the role run_plan has for the
+// discretised one, so that every solver loop below serves both.
+template <int D>
+void launch_cont(sdfs_handle* h, int mode, const ContIO& io) {
+  const dim3 grid((unsigned)h->cd.N), block(256);
+  if (mode == MODE_T) hipLaunchKernelGGL((cont_kernel<D, C_T>), grid, block, 0, h->stream, h->cd, io);
+  else if (mode == MODE_T_LIN) hipLaunchKernelGGL((cont_kernel<D, C_TLIN>), grid, block, 0, h->stream, h->cd, io);
+  else hipLaunchKernelGGL((cont_kernel<D, C_JVP>), grid, block, 0, h->stream, h->cd, io);
+}
+
+int run_cont(sdfs_handle* h, int mode, const double* in, double* out, const double* old,
+             unsigned long long* resid, const unsigned long long* gate, double gate_tol, int minus_identity) {
+  int rc = 0;
+  if (mode != MODE_T && (rc = ensure_lin(h))) return rc;
+  if (in == out) return fail(h, SDFS_ERR_ARG, "the continuous operator cannot run in place");
+  ContIO io;
+  memset(&io, 0, sizeof io);
+  io.out = out; io.gate = gate; io.gate_tol = gate_tol; io.minus_identity = minus_identity;
+  const double n8 = 8.0 * (double)h->cd.N;
+  const double corners = (double)(1 << h->cd.D);
+  double bytes = 2 * n8, flops = (double)h->cd.N * h->cd.M * (2.0 * corners + 2.0 * h->cd.D + 2.0);
+  const char* tag = "cont:T";
+  if (mode == MODE_T) { io.w = in; io.old = old; io.resid = resid; if (resid) bytes += n8; }
+  else if (mode == MODE_T_LIN) {
+    // keep the linearisation point: the JVP re-evaluates interp(w)^(theta-1) at every node
+    HIPCHK(h, hipMemcpyAsync(h->c1, in, (size_t)h->cd.N * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+    io.w = in; io.old = old; io.resid = resid; io.c2_out = h->c2; bytes += 3 * n8; tag = "cont:Tlin";
+  } else { io.w = h->c1; io.v = in; io.c2_in = h->c2; bytes += 2 * n8; flops *= 1.5; tag = "cont:jvp"; }
+  int cid = h->profiling ? counter_id(h, tag, bytes, flops) : -1;
+  ProfScope ps(h, cid);
+  if (h->cd.D == 4) launch_cont<4>(h, mode, io);
+  else launch_cont<6>(h, mode, io);
+  HIPCHK(h, hipGetLastError());
+  return 0;
+}
+
 int run_plan(sdfs_handle* h, Plan& plan, int mode, bool has_first, bool has_last,
              const double* in, double* out, const double* old, unsigned long long* resid,
              const unsigned long long* gate, double gate_tol, int minus_identity) {
+  if (h->cont) return run_cont(h, mode, in, out, old, resid, gate, gate_tol, minus_identity);
   int rc = ensure_tmp(h);
   if (rc) return rc;
   if (mode != MODE_T) { rc = ensure_lin(h); if (rc) return rc; }
@@ -1007,6 +1049,129 @@ int sdfs_create_sharded(int model, int ndim, const int64_t* shapes, const double
                        axis_a, a_lo, a_len, axis_b, b_lo, b_len, out);
 }
 
+// Fills the model-specific parts of a ContDesc (the reference's next_state / const term) and the
+// grid geometry.  Shared by sdfs_create_continuous and sdfs_lin_interp.
+static int cont_geometry(sdfs_handle* h, ContDesc& cd, int ndim, const int64_t* shapes, const double* const* grids) {
+  memset(&cd, 0, sizeof cd);
+  cd.D = ndim; cd.N = 1;
+  for (int d = ndim - 1; d >= 0; --d) {
+    if (shapes[d] < 2 || shapes[d] > (1 << 20)) return fail(h, SDFS_ERR_ARG, "grid %d needs 2 <= size, got %lld", d, (long long)shapes[d]);
+    if (!grids[d]) return fail(h, SDFS_ERR_ARG, "grids[%d] is NULL", d);
+    cd.n[d] = (int)shapes[d]; cd.stride[d] = cd.N; cd.N *= shapes[d];
+    const double step = grids[d][1] - grids[d][0];                  // utils.py:11 (uniform grids)
+    if (!(step > 0.0) || !std::isfinite(step)) return fail(h, SDFS_ERR_ARG, "grid %d is not increasing", d);
+    cd.lo[d] = grids[d][0]; cd.inv_step[d] = 1.0 / step;
+    cd.xdim[d] = -1; cd.voldim[d] = -1;
+  }
+  if (cd.N >= (1LL << 31)) return fail(h, SDFS_ERR_UNSUPPORTED, "more than 2^31 grid points");
+  return 0;
+}
+
+int sdfs_create_continuous(int model, int ndim, const int64_t* shapes, const double* params, int nparams,
+                           const double* const* grids, const double* nodes, const double* weights, int64_t M,
+                           int device_id, sdfs_handle** out) {
+  if (!out) return fail(nullptr, SDFS_ERR_ARG, "out is NULL");
+  *out = nullptr;
+  if (!shapes || !params || !grids || !nodes) return fail(nullptr, SDFS_ERR_ARG, "NULL argument");
+  if (M < 1 || M > (1 << 24)) return fail(nullptr, SDFS_ERR_ARG, "M = %lld nodes out of range", (long long)M);
+  if (model == SDFS_MODEL_SSY ? (ndim != 4 || nparams != 13) : (model == SDFS_MODEL_GCY ? (ndim != 6 || nparams != 18) : true))
+    return fail(nullptr, SDFS_ERR_ARG, "continuous SSY needs 4 grids / 13 params, GCY 6 grids / 18 params");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+    return fail(nullptr, SDFS_ERR_HIP, "no HIP device available (libsdfs_hip has no CPU fallback)");
+  if (device_id < 0 || device_id >= ndev) return fail(nullptr, SDFS_ERR_ARG, "device_id %d out of range (%d devices)", device_id, ndev);
+  sdfs_handle* h = new sdfs_handle();
+  memset(&h->counters, 0, sizeof h->counters);
+  h->device = device_id;
+  auto bail = [&](int rc) { g_create_error = h->err; sdfs_destroy(h); return rc; };
+  if (hipSetDevice(device_id) != hipSuccess) return bail(fail(h, SDFS_ERR_HIP, "hipSetDevice(%d) failed", device_id));
+  if (hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking) != hipSuccess)
+    return bail(fail(h, SDFS_ERR_HIP, "hipStreamCreate failed"));
+  h->stream = h->own_stream;
+  ContDesc& cd = h->cd;
+  int rc = cont_geometry(h, cd, ndim, shapes, grids);
+  if (rc) return bail(rc);
+  h->cont = true; h->model = model; h->ndim = ndim; h->N = cd.N;
+  for (int d = 0; d < ndim; ++d) h->shape[d] = cd.n[d];
+  h->plan[0].nloc = cd.N; h->plan[1].nloc = 0;
+  cd.M = (int)M;
+  double s0;
+  if (model == SDFS_MODEL_SSY) {
+    // params: beta, gamma, psi, mu_c, rho, phi_z, phi_c, rho_z, rho_c, rho_lam, s_z, s_c, s_lam (ssy_model.py:81)
+    // dims  : h_lam, h_c, h_z, z  (ssy_wc_ratio_continuous.py:66-87)
+    const double* q = params;
+    h->beta = q[0]; h->theta = (1 - q[1]) / (1 - 1 / q[2]);
+    cd.one_m_gamma = 1 - q[1]; cd.mu_c = q[3]; cd.phi_c = q[6];
+    cd.rho[0] = q[9]; cd.sconst[0] = q[12];
+    cd.rho[1] = q[8]; cd.sconst[1] = q[11];
+    cd.rho[2] = q[7]; cd.sconst[2] = q[10];
+    cd.rho[3] = q[4]; cd.voldim[3] = 2; cd.phi[3] = q[5];
+    cd.zdim = 3; cd.hcdim = 1;
+    s0 = q[12];
+  } else {
+    // params: beta, psi, gamma, rho_lam, s_lam, mu_c, phi_c, rho, rho_pi, phi_z, rho_c, s_c, rho_z, s_z,
+    //         rho_pipi, phi_zpi, rho_zpi, s_zpi (gcy_model.py:72-75)
+    // dims  : h_lam, h_c, h_z, h_zpi, z, z_pi  (gcy_wc_ratio_continuous.py:78-116)
+    const double* q = params;
+    h->beta = q[0]; h->theta = (1 - q[2]) / (1 - 1 / q[1]);
+    cd.one_m_gamma = 1 - q[2]; cd.mu_c = q[5]; cd.phi_c = q[6];
+    cd.rho[0] = q[3]; cd.sconst[0] = q[4];
+    cd.rho[1] = q[10]; cd.sconst[1] = q[11];
+    cd.rho[2] = q[12]; cd.sconst[2] = q[13];
+    cd.rho[3] = q[16]; cd.sconst[3] = q[17];
+    cd.rho[4] = q[7]; cd.xdim[4] = 5; cd.xcoef[4] = q[8]; cd.voldim[4] = 2; cd.phi[4] = q[9];
+    cd.rho[5] = q[14]; cd.voldim[5] = 3; cd.phi[5] = q[15];
+    cd.zdim = 4; cd.hcdim = 1;
+    s0 = q[4];
+  }
+  if (!(h->theta == h->theta) || h->theta == 0.0 || !std::isfinite(h->theta))
+    return bail(fail(h, SDFS_ERR_ARG, "theta = (1-gamma)/(1-1/psi) is not finite / zero"));
+  cd.theta = h->theta; cd.inv_theta = 1.0 / h->theta; cd.beta = h->beta; cd.theta_rho0 = h->theta * cd.rho[0];
+  for (int d = 0; d < ndim; ++d) {
+    double* g = nullptr;
+    if ((rc = upload(h, &g, grids[d], (size_t)shapes[d]))) return bail(rc);
+    cd.grid[d] = g;
+  }
+  // pf = exp(theta * h_lam') = exp(theta rho_lam h_lam) * exp(theta s_lam eta_0): the node part joins the weight
+  std::vector<double> wq((size_t)M);
+  for (int64_t m = 0; m < M; ++m)
+    wq[(size_t)m] = (weights ? weights[m] : 1.0 / (double)M) * std::exp(h->theta * s0 * nodes[m]);
+  double *eta = nullptr, *wqd = nullptr;
+  if ((rc = upload(h, &eta, nodes, (size_t)M * ndim)) || (rc = upload(h, &wqd, wq.data(), (size_t)M))) return bail(rc);
+  cd.eta = eta; cd.wq = wqd;
+  *out = h;
+  return 0;
+}
+
+int sdfs_lin_interp(int device_id, int ndim, const int64_t* shapes, const double* const* grids,
+                    const double* fun_vals, const double* x, int64_t nq, double* out) {
+  if (!shapes || !grids || !fun_vals || !x || !out || nq < 0) return fail(nullptr, SDFS_ERR_ARG, "NULL argument");
+  if (ndim != 4 && ndim != 6) return fail(nullptr, SDFS_ERR_UNSUPPORTED, "lin_interp supports 4 or 6 dimensions");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+    return fail(nullptr, SDFS_ERR_HIP, "no HIP device available (libsdfs_hip has no CPU fallback)");
+  if (device_id < 0 || device_id >= ndev || hipSetDevice(device_id) != hipSuccess)
+    return fail(nullptr, SDFS_ERR_ARG, "bad device_id %d", device_id);
+  if (nq == 0) return 0;
+  sdfs_handle tmp;                       // only for error text and allocation tracking
+  ContDesc cd;
+  int rc = cont_geometry(&tmp, cd, ndim, shapes, grids);
+  if (rc) { g_create_error = tmp.err; return rc; }
+  double *f = nullptr, *xd = nullptr, *od = nullptr;
+  auto done = [&](int code) { for (double* p : tmp.dev_allocs) hipFree(p); if (code) g_create_error = tmp.err; return code; };
+  if ((rc = upload(&tmp, &f, fun_vals, (size_t)cd.N)) || (rc = upload(&tmp, &xd, x, (size_t)nq * ndim)) ||
+      (rc = dev_alloc(&tmp, &od, (size_t)nq)))
+    return done(rc);
+  const dim3 grid((unsigned)((nq + 255) / 256)), block(256);
+  if (ndim == 4) hipLaunchKernelGGL((lin_interp_kernel<4>), grid, block, 0, 0, cd, f, xd, (long long)nq, od);
+  else hipLaunchKernelGGL((lin_interp_kernel<6>), grid, block, 0, 0, cd, f, xd, (long long)nq, od);
+  if (hipGetLastError() != hipSuccess || hipMemcpy(out, od, (size_t)nq * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) {
+    fail(&tmp, SDFS_ERR_HIP, "lin_interp launch / copy failed");
+    return done(SDFS_ERR_HIP);
+  }
+  return done(0);
+}
+
 void sdfs_destroy(sdfs_handle* h) {
   if (!h) return;
   hipSetDevice(h->device);
@@ -1207,6 +1372,11 @@ int sdfs_describe_plan(const sdfs_handle* h, char* buf, int64_t cap) {
   if (!h || !buf || cap < 1) return SDFS_ERR_ARG;
   std::string s;
   char line[256];
+  if (h->cont) {
+    snprintf(line, sizeof line, "continuous operator: %d-D grid of %lld points x %d nodes, one 256-thread block per point, "
+             "%d-corner multilinear gather + pow per node\n", h->cd.D, h->cd.N, h->cd.M, 1 << h->cd.D);
+    s += line;
+  }
   for (int st = 0; st < 2; ++st) {
     const Plan& pl = h->plan[st];
     for (size_t i = 0; i < pl.passes.size(); ++i) {

@@ -175,3 +175,34 @@ def test_loglinear_guess_shapes_and_values():
     a, b, c, d, e, ff = 1, 2, 3, 0, 1, 1
     x = (arr[13][ff], arr[7][d], arr[4][c], arr[10][e], arr[0][b, c, e, a], arr[2][e, b])
     assert w0.shape == shapes and abs(w0[a, b, c, d, e, ff] - (np.exp(f(x)) + 1)) < 1e-9
+
+
+def test_continuous_host_side_matches_reference_golden(tmp_path):
+    """build_grid / qnwnorm / vals_to_coords and the result file of the continuous path (host code)."""
+    import glob
+    import sdfs_via_autodiff_amd as S
+    files = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "cont_*_sd*.npz")))
+    assert len(files) == 8
+    for fn in files:
+        z = np.load(fn)
+        model = S.SSY() if "cont_ssy" in fn else S.GCY()
+        grids = S.build_grid(model, *[int(s) for s in z["sizes"]], float(z["num_std_devs"]))
+        for i, g in enumerate(grids):
+            np.testing.assert_array_equal(g, z[f"grid{i}"])
+        nodes, weights = S.qnwnorm([int(z["d"])] * len(grids))
+        np.testing.assert_array_equal(nodes.T, z["nodes"])
+        np.testing.assert_array_equal(weights, z["weights"])
+        c = S.vals_to_coords(grids, np.stack([g[[0, -1]] for g in grids]))
+        np.testing.assert_allclose(c[:, 0], 0.0, atol=1e-12)
+        np.testing.assert_allclose(c[:, 1], z["sizes"] - 1, rtol=1e-12)
+    # ragged (the reference's default sizes) and square grids both round-trip through the file
+    for grids in (S.build_grid(S.SSY(), 3, 3, 3, 4), S.build_grid(S.SSY(), 3, 3, 3, 3)):
+        w = np.random.default_rng(0).random(tuple(len(g) for g in grids))
+        fn = str(tmp_path / "w.npy")
+        S.save_wstar(fn, grids, w)
+        g2, w2 = S.load_wstar(fn)
+        np.testing.assert_array_equal(w2, w)
+        for a, b in zip(grids, g2):
+            np.testing.assert_array_equal(a, b)
+    with pytest.raises(TypeError):
+        S.build_grid(S.SSY(), 3, 3)
