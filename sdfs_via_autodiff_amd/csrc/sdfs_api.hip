@@ -483,9 +483,10 @@ int ensure_lin(sdfs_handle* h) {
 template <int D>
 void launch_cont(sdfs_handle* h, int mode, const ContIO& io) {
   const dim3 grid((unsigned)h->cd.N), block(256);
-  if (mode == MODE_T) hipLaunchKernelGGL((cont_kernel<D, C_T>), grid, block, 0, h->stream, h->cd, io);
-  else if (mode == MODE_T_LIN) hipLaunchKernelGGL((cont_kernel<D, C_TLIN>), grid, block, 0, h->stream, h->cd, io);
-  else hipLaunchKernelGGL((cont_kernel<D, C_JVP>), grid, block, 0, h->stream, h->cd, io);
+  const size_t lds = (size_t)h->cd.cap * sizeof(double);            // the staged box of the iterate (x2: JVP direction)
+  if (mode == MODE_T) hipLaunchKernelGGL((cont_kernel<D, C_T>), grid, block, lds, h->stream, h->cd, io);
+  else if (mode == MODE_T_LIN) hipLaunchKernelGGL((cont_kernel<D, C_TLIN>), grid, block, lds, h->stream, h->cd, io);
+  else hipLaunchKernelGGL((cont_kernel<D, C_JVP>), grid, block, 2 * lds, h->stream, h->cd, io);
 }
 
 int run_cont(sdfs_handle* h, int mode, const double* in, double* out, const double* old,
@@ -1139,6 +1140,13 @@ int sdfs_create_continuous(int model, int ndim, const int64_t* shapes, const dou
   double *eta = nullptr, *wqd = nullptr;
   if ((rc = upload(h, &eta, nodes, (size_t)M * ndim)) || (rc = upload(h, &wqd, wq.data(), (size_t)M))) return bail(rc);
   cd.eta = eta; cd.wq = wqd;
+  for (int d = 0; d < ndim; ++d) {
+    double mx = 0.0;
+    for (int64_t m = 0; m < M; ++m) mx = std::max(mx, std::fabs(nodes[(size_t)d * M + m]));
+    cd.etamax[d] = mx;
+  }
+  cd.cap = std::max(64, env_int("SDFS_CONT_LDS_CAP", 4000));        // doubles; 0 < 2 * cap * 8 < 64 KB
+  if (cd.cap > 4000) cd.cap = 4000;
   *out = h;
   return 0;
 }
