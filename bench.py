@@ -179,6 +179,20 @@ def main():
             sec[f"ssy15_{algo}"] = {"iterations": n, "operator_applies": info["n_apply"], "seconds": t,
                                     "iterations_per_s": n / t, "applies_per_s": info["n_apply"] / t,
                                     "final_err": info["final_err"]}
+        # continuous-state SSY at the reference's default size (10, 10, 10, 20; Gauss-Hermite d = 5)
+        grids = S.build_grid(m, 10, 10, 10, 20)
+        nodes, weights = S.qnwnorm([5] * 4)
+        Tc = S.T_fun_factory((np.array(m.params), grids, np.ascontiguousarray(nodes.T), weights), "quadrature", 20000)
+        w1 = np.ones(Tc.shapes)
+        for algo, kw in (("successive_approx", dict(tol=1e-5)),
+                         ("newton", dict(tol=1e-7, inner_rtol=1e-6, inner_atol=0.0))):
+            Tc.solve(w1, algo, max_iter=8)
+            t0 = time.perf_counter()
+            x, n, info = Tc.solve(w1, algo, **kw)
+            t = time.perf_counter() - t0
+            sec[f"ssy_continuous_10x10x10x20_d5_{algo}"] = {
+                "iterations": n, "operator_applies": info["n_apply"], "seconds": t,
+                "applies_per_s": info["n_apply"] / t, "final_err": info["final_err"]}
         line["secondary"] = sec
     print(json.dumps(line), flush=True)
 
