@@ -168,6 +168,18 @@ def main():
         line["gpu_over_cpu"] = line["value"] / line["cpu_baseline"]["value"]
     if not args.no_secondary:
         sec = {}
+        if args.workload == "gcy20":
+            # time-to-converge (sup-norm 1e-8) of the bench grid itself, device-resident Newton-Krylov
+            # from the reference's start w = 800 (includes one 512 MB upload and download)
+            del bufs
+            torch.cuda.empty_cache()
+            w800 = np.full(shapes, 800.0)
+            t0 = time.perf_counter()
+            x, n, info = op.solve(w800, "newton", tol=1e-8, inner_rtol=1e-6, inner_atol=0.0)
+            t = time.perf_counter() - t0
+            sec["gcy20_newton_1e-8"] = {"iterations": n, "operator_applies": info["n_apply"], "seconds": t,
+                                        "applies_per_s": info["n_apply"] / t, "final_err": info["final_err"]}
+            del x, w800
         m = S.SSY(); shp = (15,) * 4
         T = S.ssy_operator(shp, m.params, S.discretize_ssy(m, shp))
         for algo, kw in (("successive_approx", dict(tol=1e-8)),

@@ -13,7 +13,7 @@ Importing the package loads libsdfs_hip.so and fails loudly if it has not been
 built; there is no CPU fallback for the operator.
 """
 from .models import SSY, GCY
-from .discretize import rouwenhorst, discretize_ssy, discretize_gcy
+from .discretize import rouwenhorst, tauchen, discretize_ssy, discretize_gcy
 from .operators import (KoopmansOperator, ssy_operator, gcy_operator, T_ssy, T_gcy)
 from .solvers import (successive_approx, newton_solver, anderson_solver,
                       fixed_point_via_gradient_decent, solvers, solver,
@@ -23,7 +23,7 @@ from .continuous import (ContinuousOperator, build_grid, T_fun_factory, wc_ratio
                          lin_interp, vals_to_coords, construct_wstar_callable, save_wstar, load_wstar)
 from ._lib import SdfsError, LIB_PATH
 
-__all__ = ["SSY", "GCY", "rouwenhorst", "discretize_ssy", "discretize_gcy",
+__all__ = ["SSY", "GCY", "rouwenhorst", "tauchen", "discretize_ssy", "discretize_gcy",
            "KoopmansOperator", "ssy_operator", "gcy_operator", "T_ssy", "T_gcy",
            "successive_approx", "newton_solver", "anderson_solver",
            "fixed_point_via_gradient_decent", "solvers", "solver",

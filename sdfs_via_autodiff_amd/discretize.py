@@ -13,6 +13,10 @@ and the drift move the grid, not the probabilities -- so the conditional chains
 (one per volatility state) share one matrix and only their grids are rebuilt.
 The tensors are still returned in the reference's conditional layout
 (z_Q[i, j, J], z_Q[b, c, e, a, A], ...), which is what the operator consumes.
+
+``method="tauchen"`` (not in the reference; BASELINE.json's configurations name Tauchen grids) swaps
+the chain builder for Tauchen's (1986) method in the same tuple layout.  Its matrices, too, depend
+only on (n, rho, n_std): the grid scales with the innovation scale.
 """
 from collections import namedtuple
 from functools import lru_cache
@@ -59,10 +63,52 @@ def rouwenhorst(n, rho, sigma, mu=0.0):
                        state_values=_rouwenhorst_grid(int(n), float(rho), float(sigma), float(mu)))
 
 
-def discretize_ssy(ssy, shapes):
+@lru_cache(maxsize=64)
+def _tauchen_P(n, rho, n_std):
+    """Tauchen (1986) for a unit innovation scale: grid ±n_std/sqrt(1-rho²), bin-mass probabilities."""
+    from math import erf, sqrt
+    Phi = np.vectorize(lambda v: 0.5 * (1.0 + erf(v / sqrt(2.0))))
+    y = np.linspace(-n_std / np.sqrt(1.0 - rho ** 2), n_std / np.sqrt(1.0 - rho ** 2), n)
+    h = y[1] - y[0]
+    z = y[None, :] - rho * y[:, None]
+    P = Phi(z + h / 2) - Phi(z - h / 2)
+    P[:, 0] = Phi(z[:, 0] + h / 2)
+    P[:, -1] = 1.0 - Phi(z[:, -1] - h / 2)
+    P.setflags(write=False)
+    return P
+
+
+def _tauchen_grid(n, rho, sigma, mu=0.0, n_std=3):
+    sigma = np.asarray(sigma, dtype=np.float64)
+    mu = np.asarray(mu, dtype=np.float64)
+    ymax = n_std * sigma / np.sqrt(1.0 - rho ** 2)
+    k = np.arange(n, dtype=np.float64)
+    grid = -ymax[..., None] + k * (2.0 * ymax / (n - 1))[..., None]
+    grid[..., -1] = ymax
+    return grid + (mu / (1.0 - rho))[..., None]
+
+
+def tauchen(n, rho, sigma, mu=0.0, n_std=3):
+    """Discretise y' = mu + rho*y + sigma*eps by Tauchen's method; MarkovChain(P, state_values)."""
+    if n < 2:
+        raise ValueError("tauchen: n must be >= 2")
+    return MarkovChain(P=np.array(_tauchen_P(int(n), float(rho), float(n_std))),
+                       state_values=_tauchen_grid(int(n), float(rho), float(sigma), float(mu), n_std))
+
+
+def _chain_builders(method):
+    if method == "rouwenhorst":
+        return rouwenhorst, _rouwenhorst_grid, lambda n, rho: _rouwenhorst_P(n, float(rho))
+    if method == "tauchen":
+        return tauchen, _tauchen_grid, lambda n, rho: _tauchen_P(n, float(rho), 3.0)
+    raise ValueError(f"unknown discretisation method {method!r} (rouwenhorst, tauchen)")
+
+
+def discretize_ssy(ssy, shapes, method="rouwenhorst"):
     """Multi-index discretisation of SSY: states (h_λ, h_c, h_z, z) = indices (l, k, i, j)."""
     n_h_λ, n_h_c, n_h_z, n_z = (int(s) for s in shapes)
     β, γ, ψ, μ_c, ρ, φ_z, φ_c, ρ_z, ρ_c, ρ_λ, s_z, s_c, s_λ = ssy.params
+    rouwenhorst, _rouwenhorst_grid, _rouwenhorst_P = _chain_builders(method)
 
     h_λ_mc = rouwenhorst(n_h_λ, ρ_λ, s_λ, 0)
     h_c_mc = rouwenhorst(n_h_c, ρ_c, s_c, 0)
@@ -84,11 +130,12 @@ def discretize_ssy(ssy, shapes):
             σ_c_states, σ_z_states)
 
 
-def discretize_gcy(gcy, shapes):
+def discretize_gcy(gcy, shapes, method="rouwenhorst"):
     """Multi-index discretisation of GCY: states (z, z_π, h_z, h_c, h_zπ, h_λ)."""
     n_z, n_z_π, n_h_z, n_h_c, n_h_zπ, n_h_λ = (int(s) for s in shapes)
     (β, ψ, γ, ρ_λ, s_λ, μ_c, φ_c, ρ, ρ_π, φ_z, ρ_c, s_c, ρ_z, s_z,
      ρ_ππ, φ_zπ, ρ_zπ, s_zπ) = gcy.params
+    rouwenhorst, _rouwenhorst_grid, _rouwenhorst_P = _chain_builders(method)
 
     h_z_mc = rouwenhorst(n_h_z, ρ_z, s_z)
     h_c_mc = rouwenhorst(n_h_c, ρ_c, s_c)

@@ -322,3 +322,24 @@ def test_loglinear_warm_start_reaches_same_fixed_point(S):
     xb, nb, _ = T.solve(np.full(shapes, 800.0), "newton", tol=1e-10, inner_rtol=1e-8, inner_atol=0.0)
     np.testing.assert_allclose(xa, xb, rtol=0, atol=1e-8)
     assert na <= nb + 1
+
+
+def test_tauchen_discretisation_through_the_same_operator(S):
+    """method="tauchen" (BASELINE.json's configurations name Tauchen grids; the reference has none):
+    the operator takes the tensors as they come -- parity against the oracle's factorised and
+    literal T on the same arrays, and the JVP."""
+    from oracle import models, ssy as ossy, gcy as ogcy
+    shapes = (4, 5, 3, 6)
+    m = S.SSY(); arr = S.discretize_ssy(m, shapes, method="tauchen")
+    T = S.ssy_operator(shapes, m.params, arr)
+    w = wbench(shapes, seed=4)
+    p = models.ssy_params()
+    np.testing.assert_allclose(T(w), ossy.T_ssy_factorised(w, shapes, p, arr), rtol=APPLY_RTOL)
+    np.testing.assert_allclose(T(w), ossy.T_ssy(w, shapes, p, arr), rtol=1e-11)
+    v = np.random.default_rng(6).standard_normal(shapes)
+    np.testing.assert_allclose(T.jvp(w, v), ossy.jvp_ssy(w, v, shapes, p, arr), rtol=1e-10, atol=1e-12)
+    gshapes = (3, 4, 2, 3, 2, 4)
+    g = S.GCY(); garr = S.discretize_gcy(g, gshapes, method="tauchen")
+    Tg = S.gcy_operator(gshapes, g.params, garr)
+    wg = wbench(gshapes, seed=5)
+    np.testing.assert_allclose(Tg(wg), ogcy.T_gcy_factorised(wg, gshapes, models.gcy_params(), garr), rtol=APPLY_RTOL)

@@ -206,3 +206,21 @@ def test_continuous_host_side_matches_reference_golden(tmp_path):
             np.testing.assert_array_equal(a, b)
     with pytest.raises(TypeError):
         S.build_grid(S.SSY(), 3, 3)
+
+
+def test_tauchen_chains():
+    import sdfs_via_autodiff_amd as S
+    for n, rho, sig, mu in [(7, 0.9, 0.1, 0.0), (15, 0.987, 0.02, 0.003), (2, 0.5, 1.0, 0.0)]:
+        mc = S.tauchen(n, rho, sig, mu)
+        np.testing.assert_allclose(mc.P.sum(1), 1.0, atol=1e-14)
+        assert np.all(mc.P >= 0) and np.all(np.diff(mc.state_values) > 0)
+        np.testing.assert_allclose(mc.state_values.mean(), mu / (1 - rho), atol=1e-12)
+        # conditional mean of the chain tracks mu + rho*y away from the edges
+        if n >= 7:
+            i = n // 2
+            assert abs(mc.P[i] @ mc.state_values - (mu + rho * mc.state_values[i])) < 0.02 * sig + 1e-3 * abs(mu)
+    a = S.discretize_ssy(S.SSY(), (3, 4, 5, 6), method="tauchen")
+    b = S.discretize_ssy(S.SSY(), (3, 4, 5, 6))
+    assert [x.shape for x in a] == [x.shape for x in b]
+    with pytest.raises(ValueError):
+        S.discretize_gcy(S.GCY(), (2,) * 6, method="simpson")
