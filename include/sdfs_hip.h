@@ -115,6 +115,12 @@ int sdfs_create_continuous(int model, int ndim, const int64_t* shapes,
                            const double* nodes, const double* weights, int64_t M,
                            int device_id, sdfs_handle** out);
 
+/* Single-index dense form (code/ssy/discrete/temp_ssy.py:109-159: H = compute_H_single_index(ssy, shapes),
+ * single_index_T(w, H, params) = 1 + beta * (H @ w**theta)**(1/theta); analytic Jacobian :204-216).  The
+ * reference keeps it "for cross-checking solutions produced by the multi-index code"; same role here.
+ * H: N x N row-major host array (copied to the device).  The handle works with every entry point below. */
+int sdfs_create_dense(int64_t N, const double* H, double beta, double theta, int device_id, sdfs_handle** out);
+
 /* lin_interp(x, fun_vals, grids) of code/utils.py:18-23 (multilinear, indices clipped to the grid):
  * x is [ndim][nq] row-major, out[nq]; all host pointers; ndim 4 or 6. */
 int sdfs_lin_interp(int device_id, int ndim, const int64_t* shapes, const double* const* grids,

@@ -21,6 +21,8 @@ from .solvers import (successive_approx, newton_solver, anderson_solver,
 from .loglinear import wc_loglinear_factory, loglinear_guess
 from .continuous import (ContinuousOperator, build_grid, T_fun_factory, wc_ratio_continuous, qnwnorm,
                          lin_interp, vals_to_coords, construct_wstar_callable, save_wstar, load_wstar)
+from .single_index import (DenseOperator, compute_H_single_index, discretize_single_index, single_index_T,
+                           single_to_multi, multi_to_single)
 from ._lib import SdfsError, LIB_PATH
 
 __all__ = ["SSY", "GCY", "rouwenhorst", "tauchen", "discretize_ssy", "discretize_gcy",
@@ -30,4 +32,6 @@ __all__ = ["SSY", "GCY", "rouwenhorst", "tauchen", "discretize_ssy", "discretize
            "default_tolerance", "default_max_iter", "wc_loglinear_factory", "loglinear_guess",
            "ContinuousOperator", "build_grid", "T_fun_factory", "wc_ratio_continuous", "qnwnorm",
            "lin_interp", "vals_to_coords", "construct_wstar_callable", "save_wstar", "load_wstar",
+           "DenseOperator", "compute_H_single_index", "discretize_single_index", "single_index_T",
+           "single_to_multi", "multi_to_single",
            "SdfsError", "LIB_PATH"]

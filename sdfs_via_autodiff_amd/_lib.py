@@ -52,6 +52,7 @@ SYMBOLS = {
                                       C.c_int64, C.POINTER(_P)]),
     "sdfs_create_continuous": (C.c_int, [C.c_int, C.c_int, _I64, _D, C.c_int, C.POINTER(_D), _D, _D, C.c_int64,
                                          C.c_int, C.POINTER(_P)]),
+    "sdfs_create_dense": (C.c_int, [C.c_int64, _D, C.c_double, C.c_double, C.c_int, C.POINTER(_P)]),
     "sdfs_lin_interp": (C.c_int, [C.c_int, C.c_int, _I64, C.POINTER(_D), _D, _D, C.c_int64, _D]),
     "sdfs_destroy": (None, [_P]),
     "sdfs_last_error": (C.c_char_p, [_P]),

@@ -21,6 +21,7 @@
 #include "../../include/sdfs_hip.h"
 #include "pass_kernel.hpp"
 #include "cont_kernel.hpp"
+#include "dense_kernel.hpp"
 #include "vec_kernels.hpp"
 
 using namespace sdfs;
@@ -89,6 +90,10 @@ struct sdfs_handle {
   // continuous-state operator (sdfs_create_continuous): no plan, one kernel per application
   bool cont = false;
   ContDesc cd;
+
+  // single-index dense form (sdfs_create_dense): H materialised, one GEMV per application
+  bool dense = false;
+  double* denseH = nullptr;
 
   // work buffers (lazy)
   double* tmp = nullptr;
@@ -515,10 +520,46 @@ int run_cont(sdfs_handle* h, int mode, const double* in, double* out, const doub
   return 0;
 }
 
+// One application of the dense single-index operator (dense_kernel.hpp), same role as run_plan.
+int run_dense(sdfs_handle* h, int mode, const double* in, double* out, const double* old,
+              unsigned long long* resid, const unsigned long long* gate, double gate_tol, int minus_identity) {
+  int rc = ensure_tmp(h);
+  if (rc) return rc;
+  if (mode != MODE_T && (rc = ensure_lin(h))) return rc;
+  const long long N = h->N;
+  DenseIO io;
+  memset(&io, 0, sizeof io);
+  io.H = h->denseH; io.N = N; io.out = out; io.gate = gate; io.gate_tol = gate_tol;
+  io.beta = h->beta; io.inv_theta = 1.0 / h->theta; io.minus_identity = minus_identity;
+  const double hbytes = 8.0 * (double)N * (double)N, flops = 2.0 * (double)N * (double)N;
+  const dim3 rows((unsigned)N), block(256);
+  if (mode == MODE_JVP) {
+    io.x = in; io.c1 = h->c1; io.c2_in = h->c2; io.old = in;
+    int cid = h->profiling ? counter_id(h, "dense:jvp", hbytes + 40.0 * N, flops) : -1;
+    ProfScope ps(h, cid);
+    hipLaunchKernelGGL((dense_gemv_kernel<D_JVP>), rows, block, 0, h->stream, io);
+    HIPCHK(h, hipGetLastError());
+    return 0;
+  }
+  const unsigned pblocks = (unsigned)std::min<long long>((N + 255) / 256, 4096);
+  if (mode == MODE_T_LIN)
+    hipLaunchKernelGGL((dense_pow_kernel<true>), dim3(pblocks), block, 0, h->stream, in, h->tmp, h->c1, N, h->theta, gate, gate_tol);
+  else
+    hipLaunchKernelGGL((dense_pow_kernel<false>), dim3(pblocks), block, 0, h->stream, in, h->tmp, (double*)nullptr, N, h->theta, gate, gate_tol);
+  io.x = h->tmp; io.old = old; io.resid = resid; io.c2_out = h->c2;
+  int cid = h->profiling ? counter_id(h, mode == MODE_T ? "dense:T" : "dense:Tlin", hbytes + 32.0 * N, flops) : -1;
+  ProfScope ps(h, cid);
+  if (mode == MODE_T) hipLaunchKernelGGL((dense_gemv_kernel<D_T>), rows, block, 0, h->stream, io);
+  else hipLaunchKernelGGL((dense_gemv_kernel<D_TLIN>), rows, block, 0, h->stream, io);
+  HIPCHK(h, hipGetLastError());
+  return 0;
+}
+
 int run_plan(sdfs_handle* h, Plan& plan, int mode, bool has_first, bool has_last,
              const double* in, double* out, const double* old, unsigned long long* resid,
              const unsigned long long* gate, double gate_tol, int minus_identity) {
   if (h->cont) return run_cont(h, mode, in, out, old, resid, gate, gate_tol, minus_identity);
+  if (h->dense) return run_dense(h, mode, in, out, old, resid, gate, gate_tol, minus_identity);
   int rc = ensure_tmp(h);
   if (rc) return rc;
   if (mode != MODE_T) { rc = ensure_lin(h); if (rc) return rc; }
@@ -1151,6 +1192,34 @@ int sdfs_create_continuous(int model, int ndim, const int64_t* shapes, const dou
   return 0;
 }
 
+int sdfs_create_dense(int64_t N, const double* H, double beta, double theta, int device_id, sdfs_handle** out) {
+  if (!out) return fail(nullptr, SDFS_ERR_ARG, "out is NULL");
+  *out = nullptr;
+  if (!H) return fail(nullptr, SDFS_ERR_ARG, "H is NULL");
+  if (N < 1 || N > 46340) return fail(nullptr, SDFS_ERR_ARG, "N = %lld out of range (1 .. 46340)", (long long)N);
+  if (!(theta == theta) || theta == 0.0 || !std::isfinite(theta) || !std::isfinite(beta))
+    return fail(nullptr, SDFS_ERR_ARG, "beta / theta must be finite, theta non-zero");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+    return fail(nullptr, SDFS_ERR_HIP, "no HIP device available (libsdfs_hip has no CPU fallback)");
+  if (device_id < 0 || device_id >= ndev) return fail(nullptr, SDFS_ERR_ARG, "device_id %d out of range (%d devices)", device_id, ndev);
+  sdfs_handle* h = new sdfs_handle();
+  memset(&h->counters, 0, sizeof h->counters);
+  h->device = device_id;
+  auto bail = [&](int rc) { g_create_error = h->err; sdfs_destroy(h); return rc; };
+  if (hipSetDevice(device_id) != hipSuccess) return bail(fail(h, SDFS_ERR_HIP, "hipSetDevice(%d) failed", device_id));
+  if (hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking) != hipSuccess)
+    return bail(fail(h, SDFS_ERR_HIP, "hipStreamCreate failed"));
+  h->stream = h->own_stream;
+  h->dense = true; h->model = -1; h->ndim = 1; h->N = N; h->shape[0] = (int)N;
+  h->plan[0].nloc = N; h->plan[1].nloc = 0;
+  h->beta = beta; h->theta = theta;
+  int rc = upload(h, &h->denseH, H, (size_t)N * (size_t)N);
+  if (rc) return bail(rc);
+  *out = h;
+  return 0;
+}
+
 int sdfs_lin_interp(int device_id, int ndim, const int64_t* shapes, const double* const* grids,
                     const double* fun_vals, const double* x, int64_t nq, double* out) {
   if (!shapes || !grids || !fun_vals || !x || !out || nq < 0) return fail(nullptr, SDFS_ERR_ARG, "NULL argument");
@@ -1380,6 +1449,11 @@ int sdfs_describe_plan(const sdfs_handle* h, char* buf, int64_t cap) {
   if (!h || !buf || cap < 1) return SDFS_ERR_ARG;
   std::string s;
   char line[256];
+  if (h->dense) {
+    snprintf(line, sizeof line, "dense single-index operator: N = %lld, one GEMV (8 N^2 = %.3g bytes) per application\n",
+             h->N, 8.0 * (double)h->N * (double)h->N);
+    s += line;
+  }
   if (h->cont) {
     snprintf(line, sizeof line, "continuous operator: %d-D grid of %lld points x %d nodes, one 256-thread block per point, "
              "%d-corner multilinear gather + pow per node\n", h->cd.D, h->cd.N, h->cd.M, 1 << h->cd.D);

@@ -214,12 +214,36 @@ def main():
     #     build_grid / T_fun_factory / lin_interp run verbatim; quadrature and Monte-Carlo kernels ---
     continuous_fixtures(ssy, gcy)
 
+    # --- single-index dense form (code/ssy/discrete/temp_ssy.py: a scratch file without imports) ---
+    dense_fixtures(S, ssy)
+
     # --- recorded notebook output (sandpit.ipynb:41-44), typed in as data ---
     np.savez(os.path.join(HERE, "sandpit_trace.npz"),
              shapes=np.array((10, 10, 10, 10)),
              errors=np.array([4302.341800771495, 4074.9605304521597,
                               112.01772152357796, 3.834976201446807]))
     print("done")
+
+
+def dense_fixtures(S, ssy):
+    """temp_ssy.py has no import lines (it was cut out of a notebook): its text is executed as it
+    stands in a namespace that supplies the names it expects -- numpy, the jax stand-ins, njit, and
+    the reference's own discretize_ssy under the name the file uses (discretize_multi_index)."""
+    import jax
+    ns = {"np": np, "jax": jax, "jnp": jax.numpy, "njit": lambda f=None, **k: f if f is not None else (lambda g: g),
+          "discretize_multi_index": S.discretize_ssy, "SSY": S.SSY, "solver": None}
+    exec(compile(open(REF + "/ssy/discrete/temp_ssy.py").read(), "temp_ssy.py", "exec"), ns)
+    rng = np.random.default_rng(9)
+    for shapes in [(2, 3, 2, 3), (3, 2, 4, 3)]:
+        H = ns["compute_H_single_index"](ssy, shapes)
+        N = int(np.prod(shapes))
+        w = 400 + 500 * rng.random(N)
+        Tw = np.asarray(ns["single_index_T"](w, H, ssy.params))
+        arrays = S.discretize_ssy(ssy, shapes)
+        Tm = np.asarray(S.T_ssy(w.reshape(shapes), shapes, ssy.params, arrays))
+        np.savez_compressed(os.path.join(HERE, f"dense_ssy_{tag(shapes)}.npz"), shapes=np.array(shapes),
+                            params=np.array(ssy.params), H=H, w=w, T_single=Tw, T_multi=Tm)
+        print("dense", shapes, float(np.max(np.abs(Tw - Tm.ravel()))))
 
 
 def _load_by_path(name, path):

@@ -224,3 +224,21 @@ def test_tauchen_chains():
     assert [x.shape for x in a] == [x.shape for x in b]
     with pytest.raises(ValueError):
         S.discretize_gcy(S.GCY(), (2,) * 6, method="simpson")
+
+
+def test_single_index_H_matches_reference_golden():
+    """compute_H_single_index (Kronecker assembly) against the H the reference's temp_ssy.py builds."""
+    import sdfs_via_autodiff_amd as S
+    for name in ("dense_ssy_2x3x2x3", "dense_ssy_3x2x4x3"):
+        z = np.load(os.path.join(os.path.dirname(__file__), "golden", name + ".npz"))
+        shapes = tuple(int(s) for s in z["shapes"])
+        H = S.compute_H_single_index(S.SSY(), shapes)
+        np.testing.assert_allclose(H, z["H"], rtol=1e-14, atol=0)
+        params, arrays, x_states, P_x = S.discretize_single_index(S.SSY(), shapes)
+        np.testing.assert_allclose(P_x.sum(1), 1.0, atol=1e-13)
+        L, K, I, J = shapes
+        m = S.multi_to_single(1, 1, 1, 2, K, I, J)
+        assert S.single_to_multi(m, K, I, J) == (1, 1, 1, 2)
+        assert x_states[3, m] == arrays[6][1, 2] and x_states[0, m] == arrays[0][1]
+        # the reference's own numbers: dense and multi-index T agree
+        np.testing.assert_allclose(z["T_single"], z["T_multi"].ravel(), rtol=1e-12)
