@@ -343,3 +343,30 @@ def test_tauchen_discretisation_through_the_same_operator(S):
     Tg = S.gcy_operator(gshapes, g.params, garr)
     wg = wbench(gshapes, seed=5)
     np.testing.assert_allclose(Tg(wg), ogcy.T_gcy_factorised(wg, gshapes, models.gcy_params(), garr), rtol=APPLY_RTOL)
+
+
+def test_full_size_bench_grids_vs_c_oracle(S):
+    """BASELINE.json's full sizes, directly: GCY 20^6 (the bench grid, 6.4e7 points) and SSY 15^4
+    against the C/OpenMP oracle (itself pinned to the numpy oracle in tests/test_oracle_c.py), plus
+    the size-independent properties: T >= 1, monotone, JVP linear and equal to the directional derivative."""
+    from oracle.c_oracle import COperator
+    for model, shapes in (("ssy", (15,) * 4), ("gcy", (20,) * 6)):
+        T, params, arr = make_op(S, model, shapes)
+        w = wbench(shapes, seed=1)
+        tw = T(w)
+        want = COperator(model, shapes, params, arr)(w)
+        rel = np.max(np.abs(tw - want) / want)
+        assert rel < 1e-12, (model, rel)
+        assert T.residual() == pytest.approx(float(np.max(np.abs(want - w))), rel=1e-12)
+        assert tw.min() >= 1.0
+        w2 = w * 1.01
+        tw2 = T(w2)
+        assert np.all(tw2 >= tw)
+        v = np.random.default_rng(2).standard_normal(shapes)
+        jv = T.jvp(w, v)
+        np.testing.assert_allclose(T.jvp(w, -2.5 * v), -2.5 * jv, rtol=1e-12, atol=1e-14)
+        # T(w + tw) - T(w) for w2 = 1.01 w equals the JVP along 0.01 w to first order
+        lin = T.jvp(w, 0.01 * w)
+        assert np.max(np.abs((tw2 - tw) - lin) / np.abs(lin).max()) < 5e-2
+        del tw, tw2, want, jv, lin, v, w, w2
+        T.close()

@@ -242,3 +242,19 @@ def test_single_index_H_matches_reference_golden():
         assert x_states[3, m] == arrays[6][1, 2] and x_states[0, m] == arrays[0][1]
         # the reference's own numbers: dense and multi-index T agree
         np.testing.assert_allclose(z["T_single"], z["T_multi"].ravel(), rtol=1e-12)
+
+
+def test_header_is_plain_c_and_binds_from_c(tmp_path):
+    """include/sdfs_hip.h must be consumable by a C compiler (the boundary is a C ABI, no C++ or torch
+    types): compile a C99 translation unit that takes the address of every declared entry point."""
+    import subprocess
+    hdr = open(os.path.join(REPO, "include", "sdfs_hip.h")).read()
+    names = sorted(set(re.findall(r"\b(sdfs_[a-z_A-Z0-9]+)\s*\(", re.sub(r"/\*.*?\*/", "", hdr, flags=re.S))))
+    src = tmp_path / "bind.c"
+    src.write_text('#include "sdfs_hip.h"\n#include <stddef.h>\n'
+                   "const void* sdfs_entry_points[] = {\n" +
+                   "".join(f"  (const void*)(size_t)&{n},\n" for n in names) + "};\n"
+                   "int n_entry_points(void) { return (int)(sizeof sdfs_entry_points / sizeof sdfs_entry_points[0]); }\n")
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(REPO, "include"),
+                        "-c", str(src), "-o", str(tmp_path / "bind.o")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
