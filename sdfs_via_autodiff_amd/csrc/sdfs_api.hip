@@ -858,6 +858,13 @@ int solve_anderson(sdfs_handle* h, const sdfs_opts& o, double* w, int64_t* n_ite
   double err = std::numeric_limits<double>::infinity();
   int status = 0;
   const int cvec = h->profiling ? counter_id(h, "anderson_blas1", 0, 0) : -1;
+  // Safeguard (not in jaxopt): when a mixing step leaves the domain (w <= 0 -> NaN in the next
+  // application; the (m+1)^2 system is badly conditioned once the residual history is nearly
+  // collinear and N r^2 dwarfs the absolute ridge), fall back to the plain step x_prev + r_prev from
+  // the last good iterate, drop the poisoned history slot and pause mixing until the history refills.
+  bool last_mixed = false;
+  int prev_pos = -1, rejected = 0;
+  long long no_mix_until = 0;
   while (err > o.tol && it < o.max_iter) {
     if ((rc = apply_T_dev(h, x, fx, nullptr, nullptr, 0.0))) return rc;
     const int pos = (int)(it % m);
@@ -868,9 +875,22 @@ int solve_anderson(sdfs_handle* h, const sdfs_opts& o, double* w, int64_t* n_ite
     HIPCHK(h, hipStreamSynchronize(st));
     for (int j = 0; j < m; ++j) { G[(size_t)pos * m + j] = h->gram_row_host[j]; G[(size_t)j * m + pos] = h->gram_row_host[j]; }
     err = std::sqrt(G[(size_t)pos * m + pos]);
+    if (!std::isfinite(err) && last_mixed && prev_pos >= 0 && rejected < 1000) {
+      for (int j = 0; j < m; ++j) { G[(size_t)pos * m + j] = 0.0; G[(size_t)j * m + pos] = 0.0; }
+      HIPCHK(h, hipMemsetAsync(h->andR[pos], 0, nb, st));
+      AndCoef c;
+      memset(&c, 0, sizeof c);
+      c.a[prev_pos] = 1.0;
+      { ProfScope ps(h, cvec);
+        hipLaunchKernelGGL(k_and_mix, dim3(g), dim3(VEC_BLOCK), 0, st, hp, c, m, 1.0, x, n); }   // x = X_prev + R_prev
+      err = std::sqrt(G[(size_t)prev_pos * m + prev_pos]);
+      last_mixed = false; ++rejected; ++it;
+      no_mix_until = it + m;
+      continue;
+    }
     if (o.record_errors) h->trace.push_back(err);
     bool mixed = false;
-    if (it + 1 >= m && (it + 1) % o.mixing_freq == 0 && std::isfinite(err)) {
+    if (it + 1 >= m && it + 1 >= no_mix_until && (it + 1) % o.mixing_freq == 0 && std::isfinite(err)) {
       const int d = m + 1;
       std::vector<double> A((size_t)d * d, 0.0), b(d, 0.0);
       for (int j = 1; j < d; ++j) { A[j] = 1.0; A[(size_t)j * d] = 1.0; }
@@ -887,6 +907,7 @@ int solve_anderson(sdfs_handle* h, const sdfs_opts& o, double* w, int64_t* n_ite
       }
     }
     if (!mixed) std::swap(x, fx);
+    last_mixed = mixed; prev_pos = pos;
     ++it;
     if (!std::isfinite(err)) { status = SDFS_ERR_NUMERIC; break; }
   }

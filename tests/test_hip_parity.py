@@ -370,3 +370,15 @@ def test_full_size_bench_grids_vs_c_oracle(S):
         assert np.max(np.abs((tw2 - tw) - lin) / np.abs(lin).max()) < 5e-2
         del tw, tw2, want, jv, lin, v, w, w2
         T.close()
+
+
+def test_anderson_safeguard_on_large_gcy_grid(S):
+    """At GCY 12^6 jaxopt's hyper-parameters (beta = 8, absolute ridge 1e-6) throw a mixing step out of
+    the domain (w <= 0 -> NaN); the loop falls back to the plain step and still reaches the fixed point."""
+    shapes = (12,) * 6
+    T, _, _ = make_op(S, "gcy", shapes)
+    w0 = np.full(shapes, 800.0)
+    xa, na, ia = T.solve(w0, "anderson", tol=1e-6, max_iter=5000)
+    xn, nn, _ = T.solve(w0, "newton", tol=1e-9, inner_rtol=1e-8, inner_atol=0.0)
+    assert ia["status"] == 0 and na < 5000 and np.all(np.isfinite(xa))
+    np.testing.assert_allclose(xa, xn, rtol=0, atol=1e-4)
