@@ -59,7 +59,9 @@ typedef struct sdfs_opts {
   int32_t check_every;   /* host polls the device residual every k iterations (>=1) */
   int32_t use_graph;     /* 1: replay the iteration chunk from a hipGraph   */
   int32_t record_errors; /* 1: keep the per-iteration error trace (sdfs_error_trace) */
-  int32_t reserved;
+  int32_t krylov_f32;    /* Newton: 1 = inner BiCGSTAB in fp32 storage (Krylov vectors, J.v streams), fp64
+                          * arithmetic and reductions, fp64 outer residual and iterate -- the mixed-precision
+                          * configuration of BASELINE.json (config 5).  Default 0 (everything fp64).    */
 } sdfs_opts;
 
 /* Per-kernel counters for the roofline line of bench.py. */

@@ -310,6 +310,8 @@ template <> struct VecT<1> {
   double v[1];
   __device__ __forceinline__ void load(const double* p) { v[0] = *p; }
   __device__ __forceinline__ void store(double* p) const { *p = v[0]; }
+  __device__ __forceinline__ void load(const float* p) { v[0] = (double)*p; }
+  __device__ __forceinline__ void store(float* p) const { *p = (float)v[0]; }
 };
 template <> struct VecT<2> {
   double v[2];
@@ -317,7 +319,22 @@ template <> struct VecT<2> {
     const double2 t = *reinterpret_cast<const double2*>(p); v[0] = t.x; v[1] = t.y; }
   __device__ __forceinline__ void store(double* p) const {
     double2 t; t.x = v[0]; t.y = v[1]; *reinterpret_cast<double2*>(p) = t; }
+  __device__ __forceinline__ void load(const float* p) {
+    const float2 t = *reinterpret_cast<const float2*>(p); v[0] = (double)t.x; v[1] = (double)t.y; }
+  __device__ __forceinline__ void store(float* p) const {
+    float2 t; t.x = (float)v[0]; t.y = (float)v[1]; *reinterpret_cast<float2*>(p) = t; }
 };
+
+// A grid stream is fp64 by default; under PREC = 1 (fp32 Krylov storage) the streams of
+// the J.v path hold floats behind the same pointer fields.  Arithmetic stays fp64 either way.
+template <bool F32, int VEC>
+__device__ __forceinline__ void gload(VecT<VEC>& v, const double* base, long long off) {
+  if (F32) v.load(reinterpret_cast<const float*>(base) + off); else v.load(base + off);
+}
+template <bool F32, int VEC>
+__device__ __forceinline__ void gstore(const VecT<VEC>& v, double* base, long long off) {
+  if (F32) v.store(reinterpret_cast<float*>(base) + off); else v.store(base + off);
+}
 
 // One contraction y[i, col] = sum_I Q[i, I] x[I, col] over the columns of the LDS tile.
 // Output rows are covered by N16 row tiles of v_mfma_f64_16x16x4_f64 (64 cycles, 16 rows)
@@ -485,9 +502,14 @@ __device__ __forceinline__ TileCtx decode_tile(const PassDesc& P, long long tile
 //   store  : residual / JVP scaling and the global store
 // Two 512-thread workgroups share a CU (LDS-limited), so one block's memory phases overlap the
 // other's MFMA / pow phases.  MODE is the compile-time role of the launch.
-template <int EPT, int VEC, int MODE>
+template <int EPT, int VEC, int MODE, int PREC = 0>
 __global__ void __launch_bounds__(512, 4)
 pass_kernel(const PassDesc P, const PassIO io) {
+  // PREC = 1: the J.v streams (v, the intermediate grid, c1, c2, the result) are fp32; a linearising
+  // application of T keeps its own streams fp64 and only writes c1 / c2 as fp32
+  constexpr bool JV = PREC == 1 && (MODE == M_JFIRST || MODE == M_MID || MODE == M_JLAST);
+  constexpr bool F_IN = JV, F_OUT = JV, F_OLD = JV, F_AUXIN = JV;
+  constexpr bool F_AUXOUT = PREC == 1 && (MODE == M_TFIRST_LIN || MODE == M_TLAST_LIN);
   constexpr bool POWP = (MODE == M_TFIRST || MODE == M_TONLY || MODE == M_TFIRST_LIN);   // x = a1 w^theta
   constexpr bool CES = (MODE == M_TLAST || MODE == M_TONLY || MODE == M_TLAST_LIN);      // Tw = 1 + beta (K S)^(1/theta)
   constexpr bool LINP = (MODE == M_TFIRST_LIN);                  // also write c1 = a1 w^(theta-1)
@@ -545,8 +567,8 @@ pass_kernel(const PassDesc P, const PassIO io) {
     for (int k = 0; k < EPT; ++k) {
       if (tid + k * B < tot) {
         const int go = wk.t0 * g0 + wk.t1 * g1 + wk.t2u * VEC * g2;
-        val[k].load(io.in + cur.gbase + go);
-        if (MULP) aux[MULP ? k : 0].load(io.aux_in + cur.gbase + go);
+        gload<F_IN>(val[k], io.in, cur.gbase + go);
+        if (MULP) gload<F_AUXIN>(aux[MULP ? k : 0], io.aux_in, cur.gbase + go);
       }
       wk.next();
     }
@@ -580,6 +602,19 @@ pass_kernel(const PassDesc P, const PassIO io) {
   PowLane PT;
   if (POWP || CES) PT = pow_lane_init(lane);
 
+  // fp32 c1 / c2: c1 = w^(theta-1) is ~1e-50 and c2 ~1e+50 at theta = -16 .. -36 -- outside fp32 -- while
+  // only their product matters.  Both are stored scaled by an exact power of two taken from the first
+  // grid point (c1 * 2^k, c2 * 2^-k, k = -ilogb(w_0^(theta-1))): the first pass reads w_0 from its input,
+  // the last pass from the grid it forms the residual against, so both arrive at the same k.
+  double lin_scale = 1.0;
+  if (F_AUXOUT) {
+    const double wref[1] = {LINP ? io.in[0] : io.old[0]};
+    double xr[1];
+    pow_fast_n<true, 1>(wref, P.theta, PT, xr);
+    const int k = -ilogb(xr[0] / wref[0]);
+    lin_scale = ldexp(1.0, LINP ? k : -k);
+  }
+
   // ---- prologue x = a1 w^theta, in place in LDS (each thread revisits its own units).
   //      Uniform trip count: pow_fast needs every lane of the wave active.
   if (POWP && !(P.ablate & 1)) {
@@ -598,12 +633,12 @@ pass_kernel(const PassDesc P, const PassIO io) {
       pow_fast_n<true, VEC>(xin, P.theta, PT, xw);
 #pragma unroll
       for (int j = 0; j < VEC; ++j) {
-        if (LINP) c1.v[j] = xw[j] / xin[j];                     // c1 = a1 w^(theta-1)
+        if (LINP) c1.v[j] = xw[j] / xin[j] * lin_scale;         // c1 = w^(theta-1)
         x.v[j] = xw[j];
       }
       if (valid) {
         x.store(lds + lo);
-        if (LINP) c1.store(io.aux_out + cur.gbase + wk.t0 * g0 + wk.t1 * g1 + t2 * g2);
+        if (LINP) gstore<F_AUXOUT>(c1, io.aux_out, cur.gbase + wk.t0 * g0 + wk.t1 * g1 + t2 * g2);
       }
       wk.next();
     }
@@ -637,12 +672,12 @@ pass_kernel(const PassDesc P, const PassIO io) {
       pow_fast_n<false, VEC>(sv, P.inv_theta, PT, uu);
 #pragma unroll
       for (int j = 0; j < VEC; ++j) {
-        if (LINE) c2.v[j] = P.beta * uu[j] / sv[j];             // c2 = beta K (K S)^(1/theta-1) = beta u / S
+        if (LINE) c2.v[j] = P.beta * uu[j] / sv[j] * lin_scale; // c2 = beta S^(1/theta-1) = beta u / S
         y.v[j] = 1.0 + P.beta * uu[j];
       }
       if (valid) {
         y.store(lds + lo);
-        if (LINE) c2.store(io.aux_out + cur.gbase + wk.t0 * g0 + wk.t1 * g1 + t2 * g2);
+        if (LINE) gstore<F_AUXOUT>(c2, io.aux_out, cur.gbase + wk.t0 * g0 + wk.t1 * g1 + t2 * g2);
       }
       wk.next();
     }
@@ -662,8 +697,8 @@ pass_kernel(const PassDesc P, const PassIO io) {
       for (int k = 0; k < EPT; ++k) {
         if (tid + k * B < tot) {
           const int go = wk.t0 * g0 + wk.t1 * g1 + wk.t2u * VEC * g2;
-          if (need_old) oldv[k].load(io.old + cur.gbase + go);
-          if (MULE) c2v[MULE ? k : 0].load(io.aux_in + cur.gbase + go);
+          if (need_old) gload<F_OLD>(oldv[k], io.old, cur.gbase + go);
+          if (MULE) gload<F_AUXIN>(c2v[MULE ? k : 0], io.aux_in, cur.gbase + go);
         }
         wk.next();
       }
@@ -690,7 +725,7 @@ pass_kernel(const PassDesc P, const PassIO io) {
             rmax = fmax(rmax, r);
           }
         }
-        y.store(io.out + cur.gbase + go);
+        gstore<F_OUT>(y, io.out, cur.gbase + go);
       }
       wk.next();
     }
@@ -724,10 +759,10 @@ __global__ void __launch_bounds__(256) debug_pow_kernel(const double* __restrict
 
 typedef void (*pass_fn)(const PassDesc, const PassIO);
 
-// EPT in {1,2,4,8,16}, VEC in {1,2}, MODE in PassMode
-template <int MODE>
+// EPT in {1,2,4,8,16}, VEC in {1,2}, MODE in PassMode, PREC in {0, 1}
+template <int MODE, int PREC>
 inline pass_fn pass_kernel_variant_m(int ept, int vec) {
-#define SDFS_V(E) (vec == 2 ? (pass_fn)pass_kernel<E, 2, MODE> : (pass_fn)pass_kernel<E, 1, MODE>)
+#define SDFS_V(E) (vec == 2 ? (pass_fn)pass_kernel<E, 2, MODE, PREC> : (pass_fn)pass_kernel<E, 1, MODE, PREC>)
   switch (ept) {
     case 1: return SDFS_V(1);
     case 2: return SDFS_V(2);
@@ -738,16 +773,26 @@ inline pass_fn pass_kernel_variant_m(int ept, int vec) {
   }
 #undef SDFS_V
 }
-inline pass_fn pass_kernel_variant(int ept, int vec, int mode) {
+inline pass_fn pass_kernel_variant(int ept, int vec, int mode, int prec = 0) {
+  if (prec == 1) {
+    switch (mode) {                        // only the modes of the J.v path and of the linearisation
+      case M_MID: return pass_kernel_variant_m<M_MID, 1>(ept, vec);
+      case M_JFIRST: return pass_kernel_variant_m<M_JFIRST, 1>(ept, vec);
+      case M_JLAST: return pass_kernel_variant_m<M_JLAST, 1>(ept, vec);
+      case M_TFIRST_LIN: return pass_kernel_variant_m<M_TFIRST_LIN, 1>(ept, vec);
+      case M_TLAST_LIN: return pass_kernel_variant_m<M_TLAST_LIN, 1>(ept, vec);
+      default: return nullptr;
+    }
+  }
   switch (mode) {
-    case M_MID: return pass_kernel_variant_m<M_MID>(ept, vec);
-    case M_TFIRST: return pass_kernel_variant_m<M_TFIRST>(ept, vec);
-    case M_TLAST: return pass_kernel_variant_m<M_TLAST>(ept, vec);
-    case M_TONLY: return pass_kernel_variant_m<M_TONLY>(ept, vec);
-    case M_JFIRST: return pass_kernel_variant_m<M_JFIRST>(ept, vec);
-    case M_JLAST: return pass_kernel_variant_m<M_JLAST>(ept, vec);
-    case M_TFIRST_LIN: return pass_kernel_variant_m<M_TFIRST_LIN>(ept, vec);
-    case M_TLAST_LIN: return pass_kernel_variant_m<M_TLAST_LIN>(ept, vec);
+    case M_MID: return pass_kernel_variant_m<M_MID, 0>(ept, vec);
+    case M_TFIRST: return pass_kernel_variant_m<M_TFIRST, 0>(ept, vec);
+    case M_TLAST: return pass_kernel_variant_m<M_TLAST, 0>(ept, vec);
+    case M_TONLY: return pass_kernel_variant_m<M_TONLY, 0>(ept, vec);
+    case M_JFIRST: return pass_kernel_variant_m<M_JFIRST, 0>(ept, vec);
+    case M_JLAST: return pass_kernel_variant_m<M_JLAST, 0>(ept, vec);
+    case M_TFIRST_LIN: return pass_kernel_variant_m<M_TFIRST_LIN, 0>(ept, vec);
+    case M_TLAST_LIN: return pass_kernel_variant_m<M_TLAST_LIN, 0>(ept, vec);
     default: return nullptr;
   }
 }

@@ -87,6 +87,9 @@ struct sdfs_handle {
   bool sharded = false;
   int axis_a = -1, axis_b = -1;
 
+  // Newton-Krylov with fp32 Krylov vectors / J.v streams (opts.krylov_f32); set while such a solve runs
+  bool krylov_f32 = false;
+
   // continuous-state operator (sdfs_create_continuous): no plan, one kernel per application
   bool cont = false;
   ContDesc cd;
@@ -407,7 +410,7 @@ int vec_grid(long long n) {
 enum { MODE_T = 0, MODE_JVP = 1, MODE_T_LIN = 2 };
 
 int launch_pass(sdfs_handle* h, Pass& P, int pro, int epi, const PassIO& io, int minus_identity,
-                const char* tag, double bytes) {
+                const char* tag, double bytes, int prec = 0) {
   PassDesc d = P.d;
   d.pro = pro; d.epi = epi; d.minus_identity = minus_identity;
   d.theta = h->theta; d.inv_theta = 1.0 / h->theta; d.beta = h->beta;
@@ -432,7 +435,7 @@ int launch_pass(sdfs_handle* h, Pass& P, int pro, int epi, const PassIO& io, int
   else if (epi == EPI_MUL) mode = M_JLAST;
   if (pro == PRO_MUL && epi == EPI_MUL) return fail(h, SDFS_ERR_UNSUPPORTED, "single-pass JVP not supported");
   const int block = P.block;
-  pass_fn fn = pass_kernel_variant(v2 ? P.ept2 : P.ept1, v2 ? 2 : 1, mode);
+  pass_fn fn = pass_kernel_variant(v2 ? P.ept2 : P.ept1, v2 ? 2 : 1, mode, prec);
   if (!fn) return fail(h, SDFS_ERR_UNSUPPORTED, "no kernel variant for EPT %d", v2 ? P.ept2 : P.ept1);
   const long long grid = d.ntiles;
 #ifdef SDFS_STAMP
@@ -594,8 +597,12 @@ int run_plan(sdfs_handle* h, Plan& plan, int mode, bool has_first, bool has_last
         io.aux_in = h->c2; io.old = old; if (minus_identity) bytes += n8;
       }
     }
-    const char* tag = (mode == MODE_JVP) ? "jvp" : (mode == MODE_T_LIN ? "Tlin" : "T");
-    rc = launch_pass(h, P, pro, epi, io, minus_identity, tag, bytes);
+    // fp32 Krylov storage: every stream of a J.v application is fp32; a linearising T keeps fp64
+    // streams and writes only c1 (first pass) and c2 (last pass) as fp32
+    const int prec = (h->krylov_f32 && (mode == MODE_JVP || (mode == MODE_T_LIN && (first || last)))) ? 1 : 0;
+    if (h->krylov_f32 && mode == MODE_JVP) bytes *= 0.5;
+    const char* tag = (mode == MODE_JVP) ? (h->krylov_f32 ? "jvp32" : "jvp") : (mode == MODE_T_LIN ? "Tlin" : "T");
+    rc = launch_pass(h, P, pro, epi, io, minus_identity, tag, bytes, prec);
     if (rc) return rc;
   }
   return 0;
@@ -711,17 +718,21 @@ int solve_sa(sdfs_handle* h, const sdfs_opts& o, double* w, int64_t* n_iter, int
 // BiCGSTAB on device vectors (jax.scipy.sparse.linalg.bicgstab semantics: x0 = 0,
 // stop when |r|^2 <= max(rtol^2 |b|^2, atol^2), breakdown flags, maxiter 10 N).
 // b in kry[6]; solution in kry[5].  One host sync per iteration (reads rr).
-int bicgstab_dev(sdfs_handle* h, const sdfs_opts& o, int64_t* matvecs) {
-  double *r = h->kry[0], *rhat = h->kry[1], *p = h->kry[2], *q = h->kry[3], *t = h->kry[4],
-         *x = h->kry[5], *b = h->kry[6];
+// T = storage type of the Krylov vectors: double, or float under opts.krylov_f32 (the vectors then
+// occupy the first half of the same allocations and the J.v kernels read / write fp32, see run_plan)
+template <typename T>
+int bicgstab_dev_t(sdfs_handle* h, const sdfs_opts& o, int64_t* matvecs) {
+  T *r = (T*)h->kry[0], *rhat = (T*)h->kry[1], *p = (T*)h->kry[2], *q = (T*)h->kry[3], *t = (T*)h->kry[4],
+    *x = (T*)h->kry[5];
+  const double* b = h->kry[6];
   const long long n = h->N;
   const int g = vec_grid(n);
   hipStream_t st = h->stream;
   const int cvec = h->profiling ? counter_id(h, "bicgstab_blas1", 0, 0) : -1;
   {
     ProfScope ps(h, cvec);
-    hipLaunchKernelGGL(k_bicg_init, dim3(g), dim3(VEC_BLOCK), 0, st, b, r, rhat, p, q, x, n);
-    hipLaunchKernelGGL(k_dot, dim3(g), dim3(VEC_BLOCK), 0, st, b, b, n, h->partial);
+    hipLaunchKernelGGL(k_bicg_init<T>, dim3(g), dim3(VEC_BLOCK), 0, st, b, r, rhat, p, q, x, n);
+    hipLaunchKernelGGL(k_dot<T>, dim3(g), dim3(VEC_BLOCK), 0, st, (const T*)r, (const T*)r, n, h->partial);
     hipLaunchKernelGGL(k_bicg_init_finish, dim3(1), dim3(VEC_BLOCK), 0, st, h->partial, g, h->sc, o.inner_rtol, o.inner_atol);
   }
   HIPCHK(h, hipMemcpyAsync(h->sc_host, h->sc, sizeof(double) * SC_COUNT, hipMemcpyDeviceToHost, st));
@@ -733,18 +744,18 @@ int bicgstab_dev(sdfs_handle* h, const sdfs_opts& o, int64_t* matvecs) {
   while (rr > atol2 && k < maxit) {
     int rc;
     { ProfScope ps(h, cvec);
-      hipLaunchKernelGGL(k_bicg_update_p, dim3(g), dim3(VEC_BLOCK), 0, st, r, p, q, n, h->sc); }
-    if ((rc = run_plan(h, h->plan[0], MODE_JVP, true, true, p, q, p, nullptr, nullptr, 0.0, 1))) return rc;
+      hipLaunchKernelGGL(k_bicg_update_p<T>, dim3(g), dim3(VEC_BLOCK), 0, st, (const T*)r, p, (const T*)q, n, h->sc); }
+    if ((rc = run_plan(h, h->plan[0], MODE_JVP, true, true, (const double*)p, (double*)q, (const double*)p, nullptr, nullptr, 0.0, 1))) return rc;
     { ProfScope ps(h, cvec);
-      hipLaunchKernelGGL(k_dot, dim3(g), dim3(VEC_BLOCK), 0, st, rhat, q, n, h->partial);
+      hipLaunchKernelGGL(k_dot<T>, dim3(g), dim3(VEC_BLOCK), 0, st, (const T*)rhat, (const T*)q, n, h->partial);
       hipLaunchKernelGGL(k_bicg_alpha_finish, dim3(1), dim3(VEC_BLOCK), 0, st, h->partial, g, h->sc);
-      hipLaunchKernelGGL(k_bicg_s, dim3(g), dim3(VEC_BLOCK), 0, st, r, q, n, h->sc, h->partial);
+      hipLaunchKernelGGL(k_bicg_s<T>, dim3(g), dim3(VEC_BLOCK), 0, st, r, (const T*)q, n, h->sc, h->partial);
       hipLaunchKernelGGL(k_bicg_s_finish, dim3(1), dim3(VEC_BLOCK), 0, st, h->partial, g, h->sc); }
-    if ((rc = run_plan(h, h->plan[0], MODE_JVP, true, true, r, t, r, nullptr, nullptr, 0.0, 1))) return rc;
+    if ((rc = run_plan(h, h->plan[0], MODE_JVP, true, true, (const double*)r, (double*)t, (const double*)r, nullptr, nullptr, 0.0, 1))) return rc;
     { ProfScope ps(h, cvec);
-      hipLaunchKernelGGL(k_dot2, dim3(g), dim3(VEC_BLOCK), 0, st, t, r, n, h->partial);
+      hipLaunchKernelGGL(k_dot2<T>, dim3(g), dim3(VEC_BLOCK), 0, st, (const T*)t, (const T*)r, n, h->partial);
       hipLaunchKernelGGL(k_bicg_omega_finish, dim3(1), dim3(VEC_BLOCK), 0, st, h->partial, g, h->sc);
-      hipLaunchKernelGGL(k_bicg_update_xr, dim3(g), dim3(VEC_BLOCK), 0, st, x, r, p, t, rhat, n, h->sc, h->partial);
+      hipLaunchKernelGGL(k_bicg_update_xr<T>, dim3(g), dim3(VEC_BLOCK), 0, st, x, r, (const T*)p, (const T*)t, (const T*)rhat, n, h->sc, h->partial);
       hipLaunchKernelGGL(k_bicg_iter_finish, dim3(1), dim3(VEC_BLOCK), 0, st, h->partial, g, h->sc); }
     *matvecs += 2;
     HIPCHK(h, hipGetLastError());
@@ -760,6 +771,11 @@ int bicgstab_dev(sdfs_handle* h, const sdfs_opts& o, int64_t* matvecs) {
 
 // Newton on g = T - id (code/solvers.py:51-95): x <- x - J(x)^{-1} g(x), outer loop is
 // the successive_approx stopping rule on the Newton map.
+
+int bicgstab_dev(sdfs_handle* h, const sdfs_opts& o, int64_t* matvecs) {
+  return h->krylov_f32 ? bicgstab_dev_t<float>(h, o, matvecs) : bicgstab_dev_t<double>(h, o, matvecs);
+}
+
 int solve_newton(sdfs_handle* h, const sdfs_opts& o, double* w, int64_t* n_iter, int64_t* n_apply, double* final_err) {
   int rc;
   if ((rc = ensure_buf(h, &h->buf0)) || (rc = ensure_buf(h, &h->buf1)) || (rc = ensure_scalars(h)) ||
@@ -779,6 +795,11 @@ int solve_newton(sdfs_handle* h, const sdfs_opts& o, double* w, int64_t* n_iter,
   int64_t applies = 0;
   int status = 0;
   const int cvec = h->profiling ? counter_id(h, "newton_blas1", 0, 0) : -1;
+  // opts.krylov_f32: inexact Newton with the inner solve in fp32 storage (Krylov vectors, c1 / c2, the
+  // J.v intermediates) and fp64 arithmetic / reductions; the outer residual T(x) - x and the iterate
+  // stay fp64, so the fixed point is reached to the same tolerance.  Discretised, unsharded handles only.
+  struct F32Guard { sdfs_handle* h; ~F32Guard() { h->krylov_f32 = false; } } f32_guard{h};
+  h->krylov_f32 = o.krylov_f32 != 0 && !h->cont && !h->dense && !h->sharded;
   while (err > o.tol && it < o.max_iter) {
     // g(x) = T(x) - x, linearisation cached for the J.v products
     if ((rc = run_plan(h, h->plan[0], MODE_T_LIN, true, true, x, Tx, x, nullptr, nullptr, 0.0, 0))) return rc;
@@ -786,12 +807,22 @@ int solve_newton(sdfs_handle* h, const sdfs_opts& o, double* w, int64_t* n_iter,
     { ProfScope ps(h, cvec);
       hipLaunchKernelGGL(k_sub_dot, dim3(g), dim3(VEC_BLOCK), 0, st, Tx, x, h->kry[6], n, h->partial); }
     if ((rc = bicgstab_dev(h, o, &applies))) return rc;
+    // fp32 storage can overflow while the iterate is still far from the fixed point ((w / w_0)^(theta-1)
+    // spans more than fp32's range): keep the iterate so that such a step can be redone in fp64
+    if (h->krylov_f32) HIPCHK(h, hipMemcpyAsync(Tx, x, nb, hipMemcpyDeviceToDevice, st));
     HIPCHK(h, hipMemsetAsync(h->slots, 0, 8, st));
     { ProfScope ps(h, cvec);
-      hipLaunchKernelGGL(k_newton_update, dim3(g), dim3(VEC_BLOCK), 0, st, x, h->kry[5], x, n, h->slots); }
+      if (h->krylov_f32) hipLaunchKernelGGL(k_newton_update<float>, dim3(g), dim3(VEC_BLOCK), 0, st, x, (const float*)h->kry[5], x, n, h->slots);
+      else hipLaunchKernelGGL(k_newton_update<double>, dim3(g), dim3(VEC_BLOCK), 0, st, x, (const double*)h->kry[5], x, n, h->slots); }
     HIPCHK(h, hipMemcpyAsync(h->slots_host, h->slots, 8, hipMemcpyDeviceToHost, st));
     HIPCHK(h, hipStreamSynchronize(st));
     err = bits_to_double(h->slots_host[0]);
+    if (!std::isfinite(err) && h->krylov_f32) {
+      HIPCHK(h, hipMemcpyAsync(x, Tx, nb, hipMemcpyDeviceToDevice, st));
+      h->krylov_f32 = false;                 // rest of this solve in fp64
+      err = o.tol + 1;
+      continue;
+    }
     if (o.record_errors) h->trace.push_back(err);
     ++it;
     if (!std::isfinite(err)) { status = SDFS_ERR_NUMERIC; break; }
@@ -1046,7 +1077,10 @@ int create_common(int model, int ndim, const int64_t* shapes, const double* para
     for (int e = 1; e <= 16; e <<= 1)
       for (int v = 1; v <= 2; ++v)
         for (int j = 0; j < M_NMODES; ++j)
-          hipFuncSetAttribute((const void*)pass_kernel_variant(e, v, j), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
+          for (int pr = 0; pr < 2; ++pr) {
+            pass_fn fn = pass_kernel_variant(e, v, j, pr);
+            if (fn) hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
+          }
     attr_done |= 1ULL << device_id;
   }
   std::vector<int> all;

@@ -82,15 +82,29 @@ k_sub_dot(const double* __restrict__ a, const double* __restrict__ b, double* __
   block_partials<1>(acc, partial);
 }
 
-// BiCGSTAB start: r = rhat = p = q = b (x0 = 0, so r0 = b); x = 0; partial sums of <b,b>
+// BiCGSTAB kernels.  T is the storage type of the Krylov vectors (double, or float for
+// opts.krylov_f32): arithmetic and every reduction are fp64 either way.
+// start: r = rhat = p = q = b (x0 = 0, so r0 = b); x = 0  (b is always fp64: it is g(x) = T(x) - x)
+template <typename T>
 __global__ void __launch_bounds__(VEC_BLOCK)
-k_bicg_init(const double* __restrict__ b, double* __restrict__ r, double* __restrict__ rhat,
-            double* __restrict__ p, double* __restrict__ q, double* __restrict__ x, long long n) {
+k_bicg_init(const double* __restrict__ b, T* __restrict__ r, T* __restrict__ rhat,
+            T* __restrict__ p, T* __restrict__ q, T* __restrict__ x, long long n) {
   for (long long i = (long long)blockIdx.x * VEC_BLOCK + threadIdx.x; i < n;
        i += (long long)gridDim.x * VEC_BLOCK) {
-    const double v = b[i];
-    r[i] = v; rhat[i] = v; p[i] = v; q[i] = v; x[i] = 0.0;
+    const T v = (T)b[i];
+    r[i] = v; rhat[i] = v; p[i] = v; q[i] = v; x[i] = (T)0;
   }
+}
+
+// partial sums of <r, r> of the stored (rounded) start vector: the tolerance refers to what is iterated on
+template <typename T>
+__global__ void __launch_bounds__(VEC_BLOCK)
+k_dot(const T* __restrict__ a, const T* __restrict__ b, long long n, double* __restrict__ partial) {
+  double acc[1] = {0.0};
+  for (long long i = (long long)blockIdx.x * VEC_BLOCK + threadIdx.x; i < n;
+       i += (long long)gridDim.x * VEC_BLOCK)
+    acc[0] += (double)a[i] * (double)b[i];
+  block_partials<1>(acc, partial);
 }
 
 // one block: bb = sum(partials); atol2 = max(rtol^2 bb, atol^2); rho=alpha=omega=1;
@@ -111,25 +125,15 @@ k_bicg_init_finish(const double* __restrict__ partial, int nb, double* __restric
 }
 
 // p = r + beta (p - omega q)
+template <typename T>
 __global__ void __launch_bounds__(VEC_BLOCK)
-k_bicg_update_p(const double* __restrict__ r, double* __restrict__ p, const double* __restrict__ q,
+k_bicg_update_p(const T* __restrict__ r, T* __restrict__ p, const T* __restrict__ q,
                 long long n, const double* __restrict__ sc) {
   const double beta = sc[SC_BETA], omega = sc[SC_OMEGA];
   for (long long i = (long long)blockIdx.x * VEC_BLOCK + threadIdx.x; i < n;
        i += (long long)gridDim.x * VEC_BLOCK) {
-    p[i] = r[i] + beta * (p[i] - omega * q[i]);
+    p[i] = (T)((double)r[i] + beta * ((double)p[i] - omega * (double)q[i]));
   }
-}
-
-// partial sums of <a, b>
-__global__ void __launch_bounds__(VEC_BLOCK)
-k_dot(const double* __restrict__ a, const double* __restrict__ b, long long n,
-      double* __restrict__ partial) {
-  double acc[1] = {0.0};
-  for (long long i = (long long)blockIdx.x * VEC_BLOCK + threadIdx.x; i < n;
-       i += (long long)gridDim.x * VEC_BLOCK)
-    acc[0] += a[i] * b[i];
-  block_partials<1>(acc, partial);
 }
 
 // alpha = rho_new / <rhat, q>
@@ -140,16 +144,17 @@ k_bicg_alpha_finish(const double* __restrict__ partial, int nb, double* __restri
 }
 
 // s = r - alpha q (in place in r); partial sums of <s,s>
+template <typename T>
 __global__ void __launch_bounds__(VEC_BLOCK)
-k_bicg_s(double* __restrict__ r, const double* __restrict__ q, long long n,
+k_bicg_s(T* __restrict__ r, const T* __restrict__ q, long long n,
          const double* __restrict__ sc, double* __restrict__ partial) {
   const double alpha = sc[SC_ALPHA];
   double acc[1] = {0.0};
   for (long long i = (long long)blockIdx.x * VEC_BLOCK + threadIdx.x; i < n;
        i += (long long)gridDim.x * VEC_BLOCK) {
-    const double s = r[i] - alpha * q[i];
+    const T s = (T)((double)r[i] - alpha * (double)q[i]);
     r[i] = s;
-    acc[0] += s * s;
+    acc[0] += (double)s * (double)s;
   }
   block_partials<1>(acc, partial);
 }
@@ -161,14 +166,14 @@ k_bicg_s_finish(const double* __restrict__ partial, int nb, double* __restrict__
 }
 
 // partial sums of <t,s> and <t,t>
+template <typename T>
 __global__ void __launch_bounds__(VEC_BLOCK)
-k_dot2(const double* __restrict__ t, const double* __restrict__ s, long long n,
-       double* __restrict__ partial) {
+k_dot2(const T* __restrict__ t, const T* __restrict__ s, long long n, double* __restrict__ partial) {
   double acc[2] = {0.0, 0.0};
   for (long long i = (long long)blockIdx.x * VEC_BLOCK + threadIdx.x; i < n;
        i += (long long)gridDim.x * VEC_BLOCK) {
-    const double tv = t[i];
-    acc[0] += tv * s[i];
+    const double tv = (double)t[i];
+    acc[0] += tv * (double)s[i];
     acc[1] += tv * tv;
   }
   block_partials<2>(acc, partial);
@@ -183,9 +188,10 @@ k_bicg_omega_finish(const double* __restrict__ partial, int nb, double* __restri
 
 // x += alpha p (+ omega s);  r = s (- omega t);  partial sums of <r,r>, <rhat,r>
 // (`s` lives in r on entry.)  early = s already below tolerance (JAX's exit_early select).
+template <typename T>
 __global__ void __launch_bounds__(VEC_BLOCK)
-k_bicg_update_xr(double* __restrict__ x, double* __restrict__ r, const double* __restrict__ p,
-                 const double* __restrict__ t, const double* __restrict__ rhat, long long n,
+k_bicg_update_xr(T* __restrict__ x, T* __restrict__ r, const T* __restrict__ p,
+                 const T* __restrict__ t, const T* __restrict__ rhat, long long n,
                  const double* __restrict__ sc, double* __restrict__ partial) {
   const double alpha = sc[SC_ALPHA];
   const bool early = sc[SC_EARLY] != 0.0;
@@ -193,12 +199,12 @@ k_bicg_update_xr(double* __restrict__ x, double* __restrict__ r, const double* _
   double acc[2] = {0.0, 0.0};
   for (long long i = (long long)blockIdx.x * VEC_BLOCK + threadIdx.x; i < n;
        i += (long long)gridDim.x * VEC_BLOCK) {
-    const double s = r[i];
-    const double rn = early ? s : s - omega * t[i];
-    x[i] += alpha * p[i] + omega * s;
+    const double s = (double)r[i];
+    const T rn = (T)(early ? s : s - omega * (double)t[i]);
+    x[i] = (T)((double)x[i] + alpha * (double)p[i] + omega * s);
     r[i] = rn;
-    acc[0] += rn * rn;
-    acc[1] += rhat[i] * rn;
+    acc[0] += (double)rn * (double)rn;
+    acc[1] += (double)rhat[i] * (double)rn;
   }
   block_partials<2>(acc, partial);
 }
@@ -222,14 +228,15 @@ k_bicg_iter_finish(const double* __restrict__ partial, int nb, double* __restric
 }
 
 // Newton update: x_new = x - step ; stepmax = max|step| (bits, atomicMax)
+template <typename T>
 __global__ void __launch_bounds__(VEC_BLOCK)
-k_newton_update(const double* __restrict__ x, const double* __restrict__ step,
+k_newton_update(const double* __restrict__ x, const T* __restrict__ step,
                 double* __restrict__ xnew, long long n, unsigned long long* __restrict__ stepmax) {
   __shared__ double sm[VEC_BLOCK / 64];
   double mx = 0.0;
   for (long long i = (long long)blockIdx.x * VEC_BLOCK + threadIdx.x; i < n;
        i += (long long)gridDim.x * VEC_BLOCK) {
-    const double st = step[i];
+    const double st = (double)step[i];
     xnew[i] = x[i] - st;
     double a = fabs(st);
     if (!(a == a)) a = __longlong_as_double(0x7ff0000000000000LL);

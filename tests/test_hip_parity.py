@@ -382,3 +382,22 @@ def test_anderson_safeguard_on_large_gcy_grid(S):
     xn, nn, _ = T.solve(w0, "newton", tol=1e-9, inner_rtol=1e-8, inner_atol=0.0)
     assert ia["status"] == 0 and na < 5000 and np.all(np.isfinite(xa))
     np.testing.assert_allclose(xa, xn, rtol=0, atol=1e-4)
+
+
+def test_newton_with_fp32_krylov_storage_reaches_the_fp64_fixed_point(S):
+    """opts.krylov_f32 (BASELINE config 5's mixed precision): fp32 Krylov vectors and J.v streams, fp64
+    arithmetic, reductions, outer residual and iterate.  Inexact Newton: same fixed point to 1e-8."""
+    for model, shapes in (("ssy", (6, 5, 4, 7)), ("ssy", (15,) * 4), ("gcy", (3, 4, 2, 3, 2, 4)), ("gcy", (8,) * 6)):
+        T, _, _ = make_op(S, model, shapes)
+        w0 = np.full(shapes, 800.0)
+        kw = dict(tol=1e-9, inner_rtol=1e-6, inner_atol=0.0)
+        x64, n64, i64 = T.solve(w0, "newton", **kw)
+        x32, n32, i32 = T.solve(w0, "newton", krylov_f32=1, **kw)
+        assert i32["status"] == 0 and n32 <= n64 + 2, (model, shapes, n64, n32)
+        np.testing.assert_allclose(x32, x64, rtol=0, atol=1e-8)
+        assert np.max(np.abs(T(x32) - x32)) < 1e-8
+        # and the fp64 path is untouched by a previous fp32 solve on the same handle
+        v = np.random.default_rng(1).standard_normal(shapes)
+        oT, oJ = oracle_T(model, shapes) if int(np.prod(shapes)) < 20000 else (None, None)
+        if oJ is not None:
+            np.testing.assert_allclose(T.jvp(x64, v), oJ(x64, v), rtol=1e-9, atol=1e-11)
