@@ -1469,6 +1469,12 @@ int sdfs_set_profiling(sdfs_handle* h, int on) {
   if (!h) return SDFS_ERR_ARG;
   int rc = drain_events(h); if (rc) return rc;
   h->profiling = on != 0;
+  // events are created here, not inside a timed region: enough for ~340 launches between two drains
+  while (on && h->event_pool.size() < 2048) {
+    hipEvent_t e;
+    HIPCHK(h, hipEventCreate(&e));
+    h->event_pool.push_back(e);
+  }
   return 0;
 }
 

@@ -355,9 +355,9 @@ def bench_sharded(S, model, shapes, params, arrays, args, rank, local_rank, worl
         w_new, state["res"], state["w_b"] = op.apply_T_resid(w, state["w_b"])
         return w_new
 
+    op.backend.set_profiling(True)
     for _ in range(max(args.warmup, 1)):
         w = step(w)
-    op.backend.set_profiling(True)
     op.backend.reset_counters()
     dist.barrier()
     torch.cuda.synchronize()
