@@ -63,6 +63,7 @@ struct PassDesc {
   double theta, inv_theta, beta;
   long long ntiles;
   int ablate;                  // diagnostics only (SDFS_ABLATE): 1 = skip the powers, 2 = skip the contractions
+  long long ref_off;           // grid offset of the mid-grid point (reference of the fp32 c1 / c2 scaling)
 };
 
 struct PassIO {
@@ -323,6 +324,23 @@ template <> struct VecT<2> {
     const float2 t = *reinterpret_cast<const float2*>(p); v[0] = (double)t.x; v[1] = (double)t.y; }
   __device__ __forceinline__ void store(float* p) const {
     float2 t; t.x = (float)v[0]; t.y = (float)v[1]; *reinterpret_cast<float2*>(p) = t; }
+};
+
+// four points per unit: the 16-byte access of the fp32 streams (LDS side: two double2)
+template <> struct VecT<4> {
+  double v[4];
+  __device__ __forceinline__ void load(const double* p) {
+    const double2 a = *reinterpret_cast<const double2*>(p), b = *reinterpret_cast<const double2*>(p + 2);
+    v[0] = a.x; v[1] = a.y; v[2] = b.x; v[3] = b.y; }
+  __device__ __forceinline__ void store(double* p) const {
+    double2 a, b; a.x = v[0]; a.y = v[1]; b.x = v[2]; b.y = v[3];
+    *reinterpret_cast<double2*>(p) = a; *reinterpret_cast<double2*>(p + 2) = b; }
+  __device__ __forceinline__ void load(const float* p) {
+    const float4 t = *reinterpret_cast<const float4*>(p);
+    v[0] = (double)t.x; v[1] = (double)t.y; v[2] = (double)t.z; v[3] = (double)t.w; }
+  __device__ __forceinline__ void store(float* p) const {
+    float4 t; t.x = (float)v[0]; t.y = (float)v[1]; t.z = (float)v[2]; t.w = (float)v[3];
+    *reinterpret_cast<float4*>(p) = t; }
 };
 
 // A grid stream is fp64 by default; under PREC = 1 (fp32 Krylov storage) the streams of
@@ -603,12 +621,13 @@ pass_kernel(const PassDesc P, const PassIO io) {
   if (POWP || CES) PT = pow_lane_init(lane);
 
   // fp32 c1 / c2: c1 = w^(theta-1) is ~1e-50 and c2 ~1e+50 at theta = -16 .. -36 -- outside fp32 -- while
-  // only their product matters.  Both are stored scaled by an exact power of two taken from the first
-  // grid point (c1 * 2^k, c2 * 2^-k, k = -ilogb(w_0^(theta-1))): the first pass reads w_0 from its input,
-  // the last pass from the grid it forms the residual against, so both arrive at the same k.
+  // only their product matters.  Both are stored scaled by an exact power of two taken from the point in
+  // the middle of the grid (c1 * 2^k, c2 * 2^-k, k = -ilogb(w_mid^(theta-1)); the middle, so that the
+  // spread (w / w_mid)^(theta-1) splits evenly over fp32's range): the first pass reads w_mid from its
+  // input, the last pass from the grid it forms the residual against, so both arrive at the same k.
   double lin_scale = 1.0;
   if (F_AUXOUT) {
-    const double wref[1] = {LINP ? io.in[0] : io.old[0]};
+    const double wref[1] = {LINP ? io.in[P.ref_off] : io.old[P.ref_off]};
     double xr[1];
     pow_fast_n<true, 1>(wref, P.theta, PT, xr);
     const int k = -ilogb(xr[0] / wref[0]);
@@ -762,6 +781,19 @@ typedef void (*pass_fn)(const PassDesc, const PassIO);
 // EPT in {1,2,4,8,16}, VEC in {1,2}, MODE in PassMode, PREC in {0, 1}
 template <int MODE, int PREC>
 inline pass_fn pass_kernel_variant_m(int ept, int vec) {
+  // VEC = 4 exists only where every global stream of the launch is fp32 (the J.v passes under PREC = 1)
+  if constexpr (PREC == 1 && (MODE == M_JFIRST || MODE == M_MID || MODE == M_JLAST)) {
+    if (vec == 4) {
+      switch (ept) {
+        case 1: return (pass_fn)pass_kernel<1, 4, MODE, PREC>;
+        case 2: return (pass_fn)pass_kernel<2, 4, MODE, PREC>;
+        case 4: return (pass_fn)pass_kernel<4, 4, MODE, PREC>;
+        case 8: return (pass_fn)pass_kernel<8, 4, MODE, PREC>;
+        default: return nullptr;
+      }
+    }
+  }
+  if (vec == 4) return nullptr;
 #define SDFS_V(E) (vec == 2 ? (pass_fn)pass_kernel<E, 2, MODE, PREC> : (pass_fn)pass_kernel<E, 1, MODE, PREC>)
   switch (ept) {
     case 1: return SDFS_V(1);

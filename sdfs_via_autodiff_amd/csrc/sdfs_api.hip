@@ -47,7 +47,8 @@ struct Pass {
   PassDesc d;
   int block = 256;
   bool vec2 = false;        // tile runs are even and 16-B aligned: double2 accesses
-  int ept1 = 1, ept2 = 1;   // units per thread for VEC = 1 / 2
+  bool vec4 = false;        // ... multiples of four: float4 accesses of the fp32 J.v streams
+  int ept1 = 1, ept2 = 1, ept4 = 1;   // units per thread for VEC = 1 / 2 / 4
   size_t lds_bytes = 0;
   int tile_axes[3] = {-1, -1, -1};
   int step_axes[3] = {-1, -1, -1};
@@ -336,6 +337,10 @@ int build_plan(sdfs_handle* h, Plan& plan, const std::vector<int>& todo_in, std:
     for (int k = 0; k < d.nfixed; ++k) if (d.fstride[k] % 2 != 0 && d.fext[k] > 1) v2 = false;
     P.vec2 = v2;
     P.ept2 = v2 ? units_per_thread(tot / 2) : P.ept1;
+    bool v4 = v2 && (d.m[2] % 4 == 0) && (d.gstride[0] % 4 == 0 || d.m[0] == 1) && (d.gstride[1] % 4 == 0 || d.m[1] == 1);
+    for (int k = 0; k < d.nfixed; ++k) if (d.fstride[k] % 4 != 0 && d.fext[k] > 1) v4 = false;
+    P.vec4 = v4 && units_per_thread(tot / 4) <= 8;
+    P.ept4 = P.vec4 ? units_per_thread(tot / 4) : P.ept2;
     char lab[96];
     int o = snprintf(lab, sizeof lab, "expect[");
     for (int s = 0; s < d.nsteps; ++s) o += snprintf(lab + o, sizeof lab - o, "%s%s", s ? "," : "", h->ax[G[s]].name);
@@ -415,6 +420,11 @@ int launch_pass(sdfs_handle* h, Pass& P, int pro, int epi, const PassIO& io, int
   d.pro = pro; d.epi = epi; d.minus_identity = minus_identity;
   d.theta = h->theta; d.inv_theta = 1.0 / h->theta; d.beta = h->beta;
   d.ablate = env_int("SDFS_ABLATE", 0);
+  d.ref_off = 0;
+  if (!h->sharded) {                       // C-order offset of the mid-grid point
+    long long stride = 1;
+    for (int a = h->ndim - 1; a >= 0; --a) { d.ref_off += (long long)(h->shape[a] / 2) * stride; stride *= h->shape[a]; }
+  }
   int cid = -1;
   if (h->profiling) {
     char nm[48];
@@ -435,8 +445,11 @@ int launch_pass(sdfs_handle* h, Pass& P, int pro, int epi, const PassIO& io, int
   else if (epi == EPI_MUL) mode = M_JLAST;
   if (pro == PRO_MUL && epi == EPI_MUL) return fail(h, SDFS_ERR_UNSUPPORTED, "single-pass JVP not supported");
   const int block = P.block;
-  pass_fn fn = pass_kernel_variant(v2 ? P.ept2 : P.ept1, v2 ? 2 : 1, mode, prec);
-  if (!fn) return fail(h, SDFS_ERR_UNSUPPORTED, "no kernel variant for EPT %d", v2 ? P.ept2 : P.ept1);
+  const bool v4 = v2 && P.vec4 && prec == 1 && (mode == M_JFIRST || mode == M_MID || mode == M_JLAST) &&
+                  env_int("SDFS_NO_VEC4", 0) == 0;
+  const int vec = v4 ? 4 : (v2 ? 2 : 1), ept = v4 ? P.ept4 : (v2 ? P.ept2 : P.ept1);
+  pass_fn fn = pass_kernel_variant(ept, vec, mode, prec);
+  if (!fn) return fail(h, SDFS_ERR_UNSUPPORTED, "no kernel variant for EPT %d VEC %d", ept, vec);
   const long long grid = d.ntiles;
 #ifdef SDFS_STAMP
   PassIO io2 = io;
@@ -799,7 +812,9 @@ int solve_newton(sdfs_handle* h, const sdfs_opts& o, double* w, int64_t* n_iter,
   // J.v intermediates) and fp64 arithmetic / reductions; the outer residual T(x) - x and the iterate
   // stay fp64, so the fixed point is reached to the same tolerance.  Discretised, unsharded handles only.
   struct F32Guard { sdfs_handle* h; ~F32Guard() { h->krylov_f32 = false; } } f32_guard{h};
-  h->krylov_f32 = o.krylov_f32 != 0 && !h->cont && !h->dense && !h->sharded;
+  const bool want_f32 = o.krylov_f32 != 0 && !h->cont && !h->dense && !h->sharded;
+  int f32_failures = 0;
+  h->krylov_f32 = want_f32;
   while (err > o.tol && it < o.max_iter) {
     // g(x) = T(x) - x, linearisation cached for the J.v products
     if ((rc = run_plan(h, h->plan[0], MODE_T_LIN, true, true, x, Tx, x, nullptr, nullptr, 0.0, 0))) return rc;
@@ -819,10 +834,14 @@ int solve_newton(sdfs_handle* h, const sdfs_opts& o, double* w, int64_t* n_iter,
     err = bits_to_double(h->slots_host[0]);
     if (!std::isfinite(err) && h->krylov_f32) {
       HIPCHK(h, hipMemcpyAsync(x, Tx, nb, hipMemcpyDeviceToDevice, st));
-      h->krylov_f32 = false;                 // rest of this solve in fp64
+      h->krylov_f32 = false;                 // redo this step in fp64
+      ++f32_failures;
       err = o.tol + 1;
       continue;
     }
+    // an fp64 step after an overflow went through: the iterate has usually calmed down, try fp32 again
+    // (twice at most -- every failed attempt costs one inner solve)
+    if (want_f32 && !h->krylov_f32 && f32_failures < 3) h->krylov_f32 = true;
     if (o.record_errors) h->trace.push_back(err);
     ++it;
     if (!std::isfinite(err)) { status = SDFS_ERR_NUMERIC; break; }
@@ -1078,6 +1097,10 @@ int create_common(int model, int ndim, const int64_t* shapes, const double* para
       for (int v = 1; v <= 2; ++v)
         for (int j = 0; j < M_NMODES; ++j)
           for (int pr = 0; pr < 2; ++pr) {
+            if (v == 2 && pr == 1) {
+              pass_fn f4 = pass_kernel_variant(e, 4, j, 1);
+              if (f4) hipFuncSetAttribute((const void*)f4, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
+            }
             pass_fn fn = pass_kernel_variant(e, v, j, pr);
             if (fn) hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
           }
