@@ -186,6 +186,12 @@ def main():
             t = time.perf_counter() - t0
             sec["gcy20_newton_1e-8"] = {"iterations": n, "operator_applies": info["n_apply"], "seconds": t,
                                         "applies_per_s": info["n_apply"] / t, "final_err": info["final_err"]}
+            # BASELINE config 5: the same solve with fp32 Krylov storage (fp64 arithmetic and outer residual)
+            t0 = time.perf_counter()
+            x, n, info = op.solve(w800, "newton", tol=1e-8, inner_rtol=1e-6, inner_atol=0.0, krylov_f32=1)
+            t = time.perf_counter() - t0
+            sec["gcy20_newton_1e-8_krylov_f32"] = {"iterations": n, "operator_applies": info["n_apply"], "seconds": t,
+                                                   "applies_per_s": info["n_apply"] / t, "final_err": info["final_err"]}
             del x, w800
         m = S.SSY(); shp = (15,) * 4
         T = S.ssy_operator(shp, m.params, S.discretize_ssy(m, shp))
