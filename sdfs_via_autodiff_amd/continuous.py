@@ -215,21 +215,13 @@ def wc_ratio_continuous(model, *grid_sizes, num_std_devs=3.2, d=5, mc_draw_size=
         sim_size = mc_draw_size
     else:
         raise KeyError("Approximation method not found.")
-    scale = 8 if algorithm == 'newton' else 1
-    batch_size = (ram_free * 1024 ** 3 // 14) // (dim * sim_size * scale)
+    # The reference sizes a vmap batch from `ram_free` and prints it.  The kernel needs no batching;
+    # the figure is still reported (largest divisor of the state space that fits the reference's
+    # memory estimate) so that logs of the two codes line up.
     state_size = int(np.prod(sizes))
-    if state_size <= batch_size:
-        batch_size = state_size
-    else:
-        max_div = 1
-        for i in range(1, int(np.sqrt(state_size)) + 1):
-            if state_size % i == 0:
-                if i <= batch_size:
-                    max_div = max(max_div, i)
-                z = state_size // i
-                if z <= batch_size:
-                    max_div = max(max_div, z)
-        batch_size = max_div
+    cap = (ram_free * 1024 ** 3 // 14) // (dim * sim_size * (8 if algorithm == 'newton' else 1))
+    batch_size = max((q for q in range(1, int(np.sqrt(state_size)) + 1)
+                      for q in (q, state_size // q) if state_size % q == 0 and q <= max(cap, 1)), default=1)
     print("batch_size =", batch_size)
 
     T = T_fun_factory(params, method, batch_size)
