@@ -462,15 +462,6 @@ __device__ __forceinline__ void contract_step(double* __restrict__ lds, const Pa
 #undef SDFS_CC
 }
 
-// Zero-instruction barrier: redefines the offsets as far as the optimiser can tell, so address
-// arithmetic built on them is neither hoisted out of the tile loop nor kept live from one
-// phase to the next (both cost dozens of VGPRs and ended in scratch spills).
-template <int N>
-__device__ __forceinline__ void opaque(int (&a)[N]) {
-#pragma unroll
-  for (int k = 0; k < N; ++k) asm volatile("" : "+v"(a[k]));
-}
-
 #ifdef SDFS_STAMP
 #define STAMP(slot)                                                                        \
   do {                                                                                     \
