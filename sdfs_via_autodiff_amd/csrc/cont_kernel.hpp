@@ -21,7 +21,13 @@
 // short against the stationary range the grids span), so the block first copies that box of the
 // iterate into LDS (up to `cap` doubles, else it gathers from global memory) and the 2^D-corner
 // reads of every node hit LDS; neighbouring corners along the fastest axis are one ds_read2_b64.
-// First version (gathers from L2): 7.4 ms per application at GCY 4x4x4x4x6x6, d = 5.
+// First version (gathers from L2): 7.4 ms per application at GCY 4x4x4x4x6x6, d = 5; LDS box: 1.7 ms.
+//
+// Tensor-product rules.  With Gauss-Hermite nodes m = (j_0 .. j_{D-1}) the next state of dimension d
+// depends on j_d only, so the interpolation over the two fastest dimensions is done once per
+// (outer box cell, j_{D-2}, j_{D-1}) into a second LDS array U and every node then interpolates over
+// the D-2 outer dimensions only: 2^(D-2) instead of 2^D corner reads per node (16 instead of 64 in
+// 6-D, 4 instead of 16 in 4-D).  Monte-Carlo draws, or boxes that do not fit, take the path above.
 #pragma once
 #include <hip/hip_runtime.h>
 #include "pass_kernel.hpp"
@@ -48,6 +54,12 @@ struct ContDesc {
   const double* wq;                              // [M]  W_m * exp(theta * sconst[0] * eta[0][m])
   double etamax[CMAXD];                          // max_m |eta[d][m]|: bounds the box of next states
   int cap;                                       // LDS doubles available per staged array
+  // tensor-product quadrature (M = tq^D, node m = (j_0 .. j_{D-1}), j_0 fastest): tq > 0 enables the
+  // pre-contraction of the two fastest dimensions; tstride[d] = tq^d locates the 1-D node j of
+  // dimension d at eta[d][j * tstride[d]]; ucap = LDS doubles per pre-contracted array
+  int tq, ucap;
+  int tstride[CMAXD];
+  unsigned tmagic, tmagic2;                      // ceil(2^32 / tq), ceil(2^32 / tq^2): exact division of m < 2^24
 };
 
 struct ContIO {
@@ -165,6 +177,48 @@ __global__ void __launch_bounds__(256) cont_kernel(const ContDesc P, const ContI
     __syncthreads();
   }
 
+  // pre-contraction of the two fastest dimensions (tensor rules only)
+  constexpr int DO = D - 2;                                      // outer dimensions
+  const int tq = P.tq, tq2 = tq * tq;
+  const int inner_v = bext[D - 1] * bext[D - 2];
+  const int Vo = staged ? V / inner_v : 0;
+  const bool tensor = staged && tq > 0 && (long long)Vo * tq2 <= (long long)P.ucap;
+  double* const Uw = box + (MODE == C_JVP ? 2 : 1) * P.cap;
+  double* const Uv = Uw + P.ucap;
+  int lsU[DO > 0 ? DO : 1];
+  if (tensor) {
+#pragma unroll
+    for (int d = 0; d < DO; ++d) lsU[d] = ls[d] / inner_v * tq2;
+    for (int e = tid; e < Vo * tq2; e += 256) {
+      const int o = (int)__umulhi((unsigned)e, P.tmagic2), jj = e - o * tq2;
+      const int ja = (int)__umulhi((unsigned)jj, P.tmagic), jb = jj - ja * tq;
+      int il[2];
+      double tt[2];
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int d = D - 2 + q;
+        const double c = fma(k[d], P.eta[(long long)d * P.M + (long long)(q ? jb : ja) * P.tstride[d]], a[d]);
+        const double cc = fmin(fmax(c, 0.0), (double)(P.n[d] - 1));
+        const int i0 = min((int)cc, P.n[d] - 2);
+        il[q] = min(max(i0 - blo[d], 0), bext[d] - 2);
+        tt[q] = cc - (double)(blo[d] + il[q]);
+      }
+      const int base = o * inner_v + il[0] * ls[D - 2] + il[1];
+      {
+        const double v0 = fma(tt[1], box[base + 1] - box[base], box[base]);
+        const double v1 = fma(tt[1], box[base + ls[D - 2] + 1] - box[base + ls[D - 2]], box[base + ls[D - 2]]);
+        Uw[e] = fma(tt[0], v1 - v0, v0);
+      }
+      if (MODE == C_JVP) {
+        const double* bv = box + P.cap;
+        const double v0 = fma(tt[1], bv[base + 1] - bv[base], bv[base]);
+        const double v1 = fma(tt[1], bv[base + ls[D - 2] + 1] - bv[base + ls[D - 2]], bv[base + ls[D - 2]]);
+        Uv[e] = fma(tt[0], v1 - v0, v0);
+      }
+    }
+    __syncthreads();
+  }
+
   const PowLane PT = pow_lane_init(lane);
   double acc = 0.0;
   const int trips = (P.M + 255) >> 8;            // uniform: pow_fast_n needs whole waves
@@ -172,7 +226,28 @@ __global__ void __launch_bounds__(256) cont_kernel(const ContDesc P, const ContI
     const int m = it * 256 + tid;
     const bool valid = m < P.M;
     double g[1] = {1.0}, iv = 0.0, wq = 0.0;
-    if (valid) {
+    if (valid && tensor) {
+      // digits of m in base tq: j_0 fastest; the inner pair selects the column of U
+      int r = m, off = 0;
+      double to[DO > 0 ? DO : 1];
+#pragma unroll
+      for (int d = 0; d < DO; ++d) {
+        const int rq = (int)__umulhi((unsigned)r, P.tmagic);
+        const int j = r - rq * tq;
+        r = rq;
+        const double c = fma(k[d], P.eta[(long long)d * P.M + (long long)j * P.tstride[d]], a[d]);
+        const double cc = fmin(fmax(c, 0.0), (double)(P.n[d] - 1));
+        const int i0 = min((int)cc, P.n[d] - 2);
+        const int il = min(max(i0 - blo[d], 0), bext[d] - 2);
+        to[d] = cc - (double)(blo[d] + il);
+        off += il * lsU[d];
+      }
+      const int jb = (int)__umulhi((unsigned)r, P.tmagic), ja = r - jb * tq;   // j_{D-1}, j_{D-2}
+      off += ja * tq + jb;
+      g[0] = InterpRec<DO, 0, int>::run(Uw, off, lsU, to);
+      if (MODE == C_JVP) iv = InterpRec<DO, 0, int>::run(Uv, off, lsU, to);
+      wq = P.wq[m];
+    } else if (valid) {
       double c[D], t[D];
       int i0[D];
 #pragma unroll

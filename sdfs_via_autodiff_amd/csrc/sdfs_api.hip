@@ -504,7 +504,8 @@ int ensure_lin(sdfs_handle* h) {
 template <int D>
 void launch_cont(sdfs_handle* h, int mode, const ContIO& io) {
   const dim3 grid((unsigned)h->cd.N), block(256);
-  const size_t lds = (size_t)h->cd.cap * sizeof(double);            // the staged box of the iterate (x2: JVP direction)
+  // the staged box of the iterate + its pre-contracted form (x2 in the J.v kernel: the direction too)
+  const size_t lds = (size_t)(h->cd.cap + h->cd.ucap) * sizeof(double);
   if (mode == MODE_T) hipLaunchKernelGGL((cont_kernel<D, C_T>), grid, block, lds, h->stream, h->cd, io);
   else if (mode == MODE_T_LIN) hipLaunchKernelGGL((cont_kernel<D, C_TLIN>), grid, block, lds, h->stream, h->cd, io);
   else hipLaunchKernelGGL((cont_kernel<D, C_JVP>), grid, block, 2 * lds, h->stream, h->cd, io);
@@ -1264,8 +1265,52 @@ int sdfs_create_continuous(int model, int ndim, const int64_t* shapes, const dou
     for (int64_t m = 0; m < M; ++m) mx = std::max(mx, std::fabs(nodes[(size_t)d * M + m]));
     cd.etamax[d] = mx;
   }
-  cd.cap = std::max(64, env_int("SDFS_CONT_LDS_CAP", 4000));        // doubles; 0 < 2 * cap * 8 < 64 KB
-  if (cd.cap > 4000) cd.cap = 4000;
+  // Gauss-Hermite tensor rule?  M = tq^D and node m = (j_0 .. j_{D-1}) (j_0 fastest) with
+  // eta[d][m] = xi_d[j_d]: checked value by value, Monte-Carlo draws fail the test and keep tq = 0.
+  int tq = 0;
+  for (int c = 2; c <= 64 && tq == 0; ++c) {
+    long long pw = 1;
+    for (int d = 0; d < ndim; ++d) pw *= c;
+    if (pw == M) tq = c;
+  }
+  if (tq && env_int("SDFS_CONT_NO_TENSOR", 0) == 0) {
+    long long st = 1;
+    for (int d = 0; d < ndim && tq; ++d, st *= tq) {
+      cd.tstride[d] = (int)st;
+      for (int64_t m = 0; m < M; ++m)
+        if (nodes[(size_t)d * M + m] != nodes[(size_t)d * M + ((m / st) % tq) * st]) { tq = 0; break; }
+    }
+  } else tq = 0;
+  // LDS need: the largest box any grid point can ask for, dimension by dimension (same formulas as
+  // the kernel; the kernel re-checks its own box against these caps and falls back if it is larger)
+  long long vmax = 1, uomax = 1;
+  for (int d = 0; d < ndim; ++d) {
+    int mext = 2;
+    const int nx = cd.xdim[d] >= 0 ? cd.n[cd.xdim[d]] : 1, nv = cd.voldim[d] >= 0 ? cd.n[cd.voldim[d]] : 1;
+    for (int i = 0; i < cd.n[d]; ++i)
+      for (int ix = 0; ix < nx; ++ix)
+        for (int iv = 0; iv < nv; ++iv) {
+          const double mean = cd.rho[d] * grids[d][i] + (cd.xdim[d] >= 0 ? cd.xcoef[d] * grids[cd.xdim[d]][ix] : 0.0);
+          const double vol = cd.voldim[d] >= 0 ? cd.phi[d] * std::exp(grids[cd.voldim[d]][iv]) : cd.sconst[d];
+          const double a = (mean - cd.lo[d]) * cd.inv_step[d], span = std::fabs(vol * cd.inv_step[d]) * cd.etamax[d];
+          const double hi = (double)(cd.n[d] - 1);
+          const double cmin = std::min(std::max(a - span, 0.0), hi), cmax = std::min(std::max(a + span, 0.0), hi);
+          const int blo = std::min((int)cmin, cd.n[d] - 2);
+          const int bhi = std::max(blo + 1, std::min((int)cmax + 1, cd.n[d] - 1));
+          mext = std::max(mext, bhi - blo + 1);
+        }
+    vmax *= mext;
+    if (d < ndim - 2) uomax *= mext;
+  }
+  const int cap_limit = std::max(64, std::min(4000, env_int("SDFS_CONT_LDS_CAP", 4000)));   // doubles; 2 * cap * 8 < 64 KB
+  cd.cap = (int)std::min<long long>(vmax, cap_limit);
+  cd.cap += cd.cap & 1;
+  cd.tq = 0; cd.ucap = 0;
+  if (tq && vmax <= cap_limit && uomax * tq * tq + cd.cap <= 4000) {
+    cd.tq = tq; cd.ucap = (int)(uomax * tq * tq);
+    cd.tmagic = (unsigned)((1ULL << 32) / (unsigned)tq + 1);
+    cd.tmagic2 = (unsigned)((1ULL << 32) / (unsigned)(tq * tq) + 1);
+  }
   *out = h;
   return 0;
 }
