@@ -59,7 +59,8 @@ struct ContDesc {
   // dimension d at eta[d][j * tstride[d]]; ucap = LDS doubles per pre-contracted array
   int tq, ucap;
   int tstride[CMAXD];
-  unsigned tmagic, tmagic2;                      // ceil(2^32 / tq), ceil(2^32 / tq^2): exact division of m < 2^24
+  unsigned tmagic, tmagic2;                      // floor(2^32 / tq) + 1: exact m / tq for m <= 2^24, tq <= 64;
+                                                 // floor(2^32 / tq^2) + 1: exact e / tq^2 for e <= ucap <= 4000
 };
 
 struct ContIO {
