@@ -13,7 +13,7 @@
 namespace sdfs {
 
 constexpr int VEC_BLOCK = 256;
-constexpr int MAX_PARTIAL_BLOCKS = 1024;
+constexpr int MAX_PARTIAL_BLOCKS = 2048;
 
 // device scalar block of the BiCGSTAB recurrence
 enum {
@@ -82,6 +82,59 @@ k_sub_dot(const double* __restrict__ a, const double* __restrict__ b, double* __
   block_partials<1>(acc, partial);
 }
 
+// 16-byte packets: W consecutive elements per lane and access (2 doubles / 4 floats); a stream of
+// another type rides along in as many 16-byte pieces as it needs.  Converted to double in registers.
+template <typename T> struct PkW { static constexpr int W = 16 / (int)sizeof(T); };
+template <int W>
+__device__ __forceinline__ void ldv(const double* __restrict__ p, long long e, double (&v)[W]) {
+#pragma unroll
+  for (int j = 0; j < W; j += 2) { const double2 t = *reinterpret_cast<const double2*>(p + e + j); v[j] = t.x; v[j + 1] = t.y; }
+}
+template <int W>
+__device__ __forceinline__ void ldv(const float* __restrict__ p, long long e, double (&v)[W]) {
+  static_assert(W == 4, "float packets hold four elements");
+  const float4 t = *reinterpret_cast<const float4*>(p + e);
+  v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+}
+template <int W>
+__device__ __forceinline__ void stv(double* __restrict__ p, long long e, const double (&v)[W]) {
+#pragma unroll
+  for (int j = 0; j < W; j += 2) { double2 t; t.x = v[j]; t.y = v[j + 1]; *reinterpret_cast<double2*>(p + e + j) = t; }
+}
+template <int W>
+__device__ __forceinline__ void stv(float* __restrict__ p, long long e, const double (&v)[W]) {
+  static_assert(W == 4, "float packets hold four elements");
+  float4 t; t.x = (float)v[0]; t.y = (float)v[1]; t.z = (float)v[2]; t.w = (float)v[3];
+  *reinterpret_cast<float4*>(p + e) = t;
+}
+// grid-stride over packets, then over the < W leftover elements; BODY(e, W_) sees `e` (first element)
+// and processes W_ elements through the LD / ST helpers below
+#define SDFS_PACKET_LOOP(T, n, BODY)                                                        \
+  {                                                                                         \
+    constexpr int W = PkW<T>::W;                                                            \
+    const long long gid_ = (long long)blockIdx.x * VEC_BLOCK + threadIdx.x;                 \
+    const long long str_ = (long long)gridDim.x * VEC_BLOCK;                                \
+    const long long np_ = (n) / W;                                                          \
+    for (long long ip_ = gid_; ip_ < np_; ip_ += str_) { const long long e = ip_ * W; BODY(W) } \
+    for (long long e = np_ * W + gid_; e < (n); e += str_) { BODY(1) }                      \
+  }
+template <int W>
+__device__ __forceinline__ void LDx(const double* __restrict__ p, long long e, double (&v)[W]) {
+  if constexpr (W == 1) v[0] = p[e]; else ldv<W>(p, e, v);
+}
+template <int W>
+__device__ __forceinline__ void LDx(const float* __restrict__ p, long long e, double (&v)[W]) {
+  if constexpr (W == 1) v[0] = (double)p[e]; else ldv<W>(p, e, v);
+}
+template <int W>
+__device__ __forceinline__ void STx(double* __restrict__ p, long long e, const double (&v)[W]) {
+  if constexpr (W == 1) p[e] = v[0]; else stv<W>(p, e, v);
+}
+template <int W>
+__device__ __forceinline__ void STx(float* __restrict__ p, long long e, const double (&v)[W]) {
+  if constexpr (W == 1) p[e] = (float)v[0]; else stv<W>(p, e, v);
+}
+
 // BiCGSTAB kernels.  T is the storage type of the Krylov vectors (double, or float for
 // opts.krylov_f32): arithmetic and every reduction are fp64 either way.
 // start: r = rhat = p = q = b (x0 = 0, so r0 = b); x = 0  (b is always fp64: it is g(x) = T(x) - x)
@@ -89,21 +142,21 @@ template <typename T>
 __global__ void __launch_bounds__(VEC_BLOCK)
 k_bicg_init(const double* __restrict__ b, T* __restrict__ r, T* __restrict__ rhat,
             T* __restrict__ p, T* __restrict__ q, T* __restrict__ x, long long n) {
-  for (long long i = (long long)blockIdx.x * VEC_BLOCK + threadIdx.x; i < n;
-       i += (long long)gridDim.x * VEC_BLOCK) {
-    const T v = (T)b[i];
-    r[i] = v; rhat[i] = v; p[i] = v; q[i] = v; x[i] = (T)0;
-  }
+#define BODY(W_) { double v[W_], z[W_]; LDx<W_>(b, e, v); _Pragma("unroll") for (int j = 0; j < W_; ++j) z[j] = 0.0; \
+                   STx<W_>(r, e, v); STx<W_>(rhat, e, v); STx<W_>(p, e, v); STx<W_>(q, e, v); STx<W_>(x, e, z); }
+  SDFS_PACKET_LOOP(T, n, BODY)
+#undef BODY
 }
 
-// partial sums of <r, r> of the stored (rounded) start vector: the tolerance refers to what is iterated on
+// partial sums of <a, b>
 template <typename T>
 __global__ void __launch_bounds__(VEC_BLOCK)
 k_dot(const T* __restrict__ a, const T* __restrict__ b, long long n, double* __restrict__ partial) {
   double acc[1] = {0.0};
-  for (long long i = (long long)blockIdx.x * VEC_BLOCK + threadIdx.x; i < n;
-       i += (long long)gridDim.x * VEC_BLOCK)
-    acc[0] += (double)a[i] * (double)b[i];
+#define BODY(W_) { double x_[W_], y_[W_]; LDx<W_>(a, e, x_); LDx<W_>(b, e, y_); \
+                   _Pragma("unroll") for (int j = 0; j < W_; ++j) acc[0] += x_[j] * y_[j]; }
+  SDFS_PACKET_LOOP(T, n, BODY)
+#undef BODY
   block_partials<1>(acc, partial);
 }
 
@@ -130,10 +183,11 @@ __global__ void __launch_bounds__(VEC_BLOCK)
 k_bicg_update_p(const T* __restrict__ r, T* __restrict__ p, const T* __restrict__ q,
                 long long n, const double* __restrict__ sc) {
   const double beta = sc[SC_BETA], omega = sc[SC_OMEGA];
-  for (long long i = (long long)blockIdx.x * VEC_BLOCK + threadIdx.x; i < n;
-       i += (long long)gridDim.x * VEC_BLOCK) {
-    p[i] = (T)((double)r[i] + beta * ((double)p[i] - omega * (double)q[i]));
-  }
+#define BODY(W_) { double r_[W_], p_[W_], q_[W_]; LDx<W_>(r, e, r_); LDx<W_>((const T*)p, e, p_); LDx<W_>(q, e, q_); \
+                   _Pragma("unroll") for (int j = 0; j < W_; ++j) p_[j] = r_[j] + beta * (p_[j] - omega * q_[j]); \
+                   STx<W_>(p, e, p_); }
+  SDFS_PACKET_LOOP(T, n, BODY)
+#undef BODY
 }
 
 // alpha = rho_new / <rhat, q>
@@ -150,12 +204,11 @@ k_bicg_s(T* __restrict__ r, const T* __restrict__ q, long long n,
          const double* __restrict__ sc, double* __restrict__ partial) {
   const double alpha = sc[SC_ALPHA];
   double acc[1] = {0.0};
-  for (long long i = (long long)blockIdx.x * VEC_BLOCK + threadIdx.x; i < n;
-       i += (long long)gridDim.x * VEC_BLOCK) {
-    const T s = (T)((double)r[i] - alpha * (double)q[i]);
-    r[i] = s;
-    acc[0] += (double)s * (double)s;
-  }
+#define BODY(W_) { double r_[W_], q_[W_]; LDx<W_>((const T*)r, e, r_); LDx<W_>(q, e, q_); \
+                   _Pragma("unroll") for (int j = 0; j < W_; ++j) { const double s = (double)(T)(r_[j] - alpha * q_[j]); r_[j] = s; acc[0] += s * s; } \
+                   STx<W_>(r, e, r_); }
+  SDFS_PACKET_LOOP(T, n, BODY)
+#undef BODY
   block_partials<1>(acc, partial);
 }
 
@@ -170,12 +223,10 @@ template <typename T>
 __global__ void __launch_bounds__(VEC_BLOCK)
 k_dot2(const T* __restrict__ t, const T* __restrict__ s, long long n, double* __restrict__ partial) {
   double acc[2] = {0.0, 0.0};
-  for (long long i = (long long)blockIdx.x * VEC_BLOCK + threadIdx.x; i < n;
-       i += (long long)gridDim.x * VEC_BLOCK) {
-    const double tv = (double)t[i];
-    acc[0] += tv * (double)s[i];
-    acc[1] += tv * tv;
-  }
+#define BODY(W_) { double t_[W_], s_[W_]; LDx<W_>(t, e, t_); LDx<W_>(s, e, s_); \
+                   _Pragma("unroll") for (int j = 0; j < W_; ++j) { acc[0] += t_[j] * s_[j]; acc[1] += t_[j] * t_[j]; } }
+  SDFS_PACKET_LOOP(T, n, BODY)
+#undef BODY
   block_partials<2>(acc, partial);
 }
 
@@ -197,15 +248,16 @@ k_bicg_update_xr(T* __restrict__ x, T* __restrict__ r, const T* __restrict__ p,
   const bool early = sc[SC_EARLY] != 0.0;
   const double omega = early ? 0.0 : sc[SC_OMEGA];
   double acc[2] = {0.0, 0.0};
-  for (long long i = (long long)blockIdx.x * VEC_BLOCK + threadIdx.x; i < n;
-       i += (long long)gridDim.x * VEC_BLOCK) {
-    const double s = (double)r[i];
-    const T rn = (T)(early ? s : s - omega * (double)t[i]);
-    x[i] = (T)((double)x[i] + alpha * (double)p[i] + omega * s);
-    r[i] = rn;
-    acc[0] += (double)rn * (double)rn;
-    acc[1] += (double)rhat[i] * (double)rn;
-  }
+#define BODY(W_) { double x_[W_], r_[W_], p_[W_], t_[W_], h_[W_]; LDx<W_>((const T*)x, e, x_); LDx<W_>((const T*)r, e, r_); \
+                   LDx<W_>(p, e, p_); LDx<W_>(t, e, t_); LDx<W_>(rhat, e, h_); \
+                   _Pragma("unroll") for (int j = 0; j < W_; ++j) { \
+                     const double s = r_[j]; \
+                     const double rn = (double)(T)(early ? s : s - omega * t_[j]); \
+                     x_[j] = x_[j] + alpha * p_[j] + omega * s; r_[j] = rn; \
+                     acc[0] += rn * rn; acc[1] += h_[j] * rn; } \
+                   STx<W_>(x, e, x_); STx<W_>(r, e, r_); }
+  SDFS_PACKET_LOOP(T, n, BODY)
+#undef BODY
   block_partials<2>(acc, partial);
 }
 
