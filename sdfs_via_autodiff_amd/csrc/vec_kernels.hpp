@@ -315,17 +315,17 @@ k_and_push(const double* __restrict__ x, const double* __restrict__ fx, AndPtrs 
   double acc[AND_MAX_M];
 #pragma unroll
   for (int j = 0; j < AND_MAX_M; ++j) acc[j] = 0.0;
-  for (long long i = (long long)blockIdx.x * VEC_BLOCK + threadIdx.x; i < n;
-       i += (long long)gridDim.x * VEC_BLOCK) {
-    const double xv = x[i];
-    const double r = fx[i] - xv;
-    h.X[pos][i] = xv;
-    h.R[pos][i] = r;
-#pragma unroll
-    for (int j = 0; j < AND_MAX_M; ++j) {
-      if (j < m) acc[j] += r * ((j == pos) ? r : h.R[j][i]);
-    }
-  }
+#define BODY(W_) { double x_[W_], f_[W_], r_[W_]; LDx<W_>(x, e, x_); LDx<W_>(fx, e, f_); \
+                   _Pragma("unroll") for (int q = 0; q < W_; ++q) r_[q] = f_[q] - x_[q]; \
+                   STx<W_>(h.X[pos], e, x_); STx<W_>(h.R[pos], e, r_); \
+                   _Pragma("unroll") for (int j = 0; j < AND_MAX_M; ++j) { \
+                     if (j < m) { \
+                       double o_[W_]; \
+                       if (j == pos) { _Pragma("unroll") for (int q = 0; q < W_; ++q) o_[q] = r_[q]; } \
+                       else LDx<W_>((const double*)h.R[j], e, o_); \
+                       _Pragma("unroll") for (int q = 0; q < W_; ++q) acc[j] += r_[q] * o_[q]; } } }
+  SDFS_PACKET_LOOP(double, n, BODY)
+#undef BODY
   block_partials<AND_MAX_M>(acc, partial);
 }
 
@@ -343,15 +343,15 @@ struct AndCoef { double a[AND_MAX_M]; };
 // x_next = sum_j alpha_j (X[j] + beta R[j])
 __global__ void __launch_bounds__(VEC_BLOCK)
 k_and_mix(AndPtrs h, AndCoef c, int m, double beta, double* __restrict__ xnext, long long n) {
-  for (long long i = (long long)blockIdx.x * VEC_BLOCK + threadIdx.x; i < n;
-       i += (long long)gridDim.x * VEC_BLOCK) {
-    double xa = 0.0, ra = 0.0;
-#pragma unroll
-    for (int j = 0; j < AND_MAX_M; ++j) {
-      if (j < m) { xa += c.a[j] * h.X[j][i]; ra += c.a[j] * h.R[j][i]; }
-    }
-    xnext[i] = xa + beta * ra;
-  }
+#define BODY(W_) { double xa[W_], ra[W_]; \
+                   _Pragma("unroll") for (int q = 0; q < W_; ++q) { xa[q] = 0.0; ra[q] = 0.0; } \
+                   _Pragma("unroll") for (int j = 0; j < AND_MAX_M; ++j) { \
+                     if (j < m) { double x_[W_], r_[W_]; LDx<W_>((const double*)h.X[j], e, x_); LDx<W_>((const double*)h.R[j], e, r_); \
+                       _Pragma("unroll") for (int q = 0; q < W_; ++q) { xa[q] += c.a[j] * x_[q]; ra[q] += c.a[j] * r_[q]; } } } \
+                   _Pragma("unroll") for (int q = 0; q < W_; ++q) xa[q] = xa[q] + beta * ra[q]; \
+                   STx<W_>(xnext, e, xa); }
+  SDFS_PACKET_LOOP(double, n, BODY)
+#undef BODY
 }
 
 }  // namespace sdfs
