@@ -46,11 +46,13 @@ struct PassDesc {
   int foff[MAXF];              // global index of local index 0 (sharded runs)
   long long fstride[MAXF];     // element stride in the (local) grid
   int fq[3][MAXF];             // matrix-index stride of step s's Q tensor
+  int fa3[MAXF];               // index stride into the a3 table (only when a3 != nullptr)
   // tile axes, slot 0 slowest .. slot 2 fastest; unused slots have extent 1
   int m[3];
   int toff[3];
   int gstride[3];              // element strides inside the tile (tile span < 2^31)
   int L[3];                    // LDS strides (L[2] == 1)
+  int ta3[3];                  // a3 index strides of the tile slots
   // contraction steps
   int nsteps;
   int sslot[3];
@@ -61,6 +63,10 @@ struct PassDesc {
   int pro, epi;
   int minus_identity;          // EPI_MUL: subtract old[idx]
   double theta, inv_theta, beta;
+  // current-state scale a3 applied by the aggregator instead of being folded into the z tensor: set
+  // when every slice of a conditional tensor is the same matrix (Rouwenhorst / Tauchen chains), which
+  // lets the planner treat that axis as unconditional (longer contiguous runs in the last pass)
+  const double* a3;
   long long ntiles;
   int ablate;                  // diagnostics only (SDFS_ABLATE): 1 = skip the powers, 2 = skip the contractions
   long long ref_off;           // grid offset of the mid-grid point (reference of the fp32 c1 / c2 scaling)
@@ -483,11 +489,12 @@ enum PassMode { M_MID = 0, M_TFIRST = 1, M_TLAST = 2, M_TONLY = 3, M_JFIRST = 4,
 struct TileCtx {
   long long gbase;
   int q0, q1, q2;
+  int ia3b;
 };
 
 __device__ __forceinline__ TileCtx decode_tile(const PassDesc& P, long long tile) {
   TileCtx c;
-  c.gbase = 0; c.q0 = 0; c.q1 = 0; c.q2 = 0;
+  c.gbase = 0; c.q0 = 0; c.q1 = 0; c.q2 = 0; c.ia3b = 0;
 #pragma unroll
   for (int k = MAXF - 1; k >= 0; --k) {
     if (k < P.nfixed) {
@@ -497,8 +504,11 @@ __device__ __forceinline__ TileCtx decode_tile(const PassDesc& P, long long tile
       const int gc = cc + P.foff[k];
       c.gbase += (long long)cc * P.fstride[k];
       c.q0 += gc * P.fq[0][k]; c.q1 += gc * P.fq[1][k]; c.q2 += gc * P.fq[2][k];
+      c.ia3b += gc * P.fa3[k];
     }
   }
+#pragma unroll
+  for (int j = 0; j < 3; ++j) c.ia3b += P.toff[j] * P.ta3[j];
   return c;
 }
 
@@ -676,13 +686,18 @@ pass_kernel(const PassDesc P, const PassIO io) {
       const int lo = valid ? wk.t0 * L0 + wk.t1 * L1 + t2 : 0;
       VecT<VEC> y, c2;
       y.load(lds + lo);
-      double sv[VEC], uu[VEC];
+      double sv[VEC], ks[VEC], uu[VEC];
 #pragma unroll
-      for (int j = 0; j < VEC; ++j) sv[j] = valid ? y.v[j] : 1.0;
-      pow_fast_n<false, VEC>(sv, P.inv_theta, PT, uu);
+      for (int j = 0; j < VEC; ++j) { sv[j] = valid ? y.v[j] : 1.0; ks[j] = sv[j]; }
+      if (P.a3 != nullptr && valid) {
+        const int i3 = cur.ia3b + wk.t0 * P.ta3[0] + wk.t1 * P.ta3[1] + t2 * P.ta3[2];
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) ks[j] = P.a3[i3 + j * P.ta3[2]] * sv[j];
+      }
+      pow_fast_n<false, VEC>(ks, P.inv_theta, PT, uu);
 #pragma unroll
       for (int j = 0; j < VEC; ++j) {
-        if (LINE) c2.v[j] = P.beta * uu[j] / sv[j] * lin_scale; // c2 = beta S^(1/theta-1) = beta u / S
+        if (LINE) c2.v[j] = P.beta * uu[j] / sv[j] * lin_scale; // c2 = beta a3 (a3 S)^(1/theta-1) = beta u / S (S unscaled)
         y.v[j] = 1.0 + P.beta * uu[j];
       }
       if (valid) {

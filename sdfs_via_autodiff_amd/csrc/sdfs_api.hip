@@ -40,6 +40,7 @@ struct AxisInfo {
   const double* Q = nullptr;   // device transition tensor [.., n, n]
   int qs[MAXD] = {0, 0, 0, 0, 0, 0};  // matrix-index stride per conditioning axis
   long long qcount = 0;        // number of n x n matrices in Q
+  int a3s = 0;                 // index stride of this axis in the a3 table (when it is kept as a table)
   char name[8] = "";
 };
 
@@ -87,6 +88,8 @@ struct sdfs_handle {
   Plan plan[2];
   bool sharded = false;
   int axis_a = -1, axis_b = -1;
+
+  double* a3 = nullptr;              // current-state scale table, kept only when the z tensor is slice-identical
 
   // Newton-Krylov with fp32 Krylov vectors / J.v streams (opts.krylov_f32); set while such a solve runs
   bool krylov_f32 = false;
@@ -254,11 +257,12 @@ int build_plan(sdfs_handle* h, Plan& plan, const std::vector<int>& todo_in, std:
     memset(&P.d, 0, sizeof P.d);
     PassDesc& d = P.d;
     const int nt = (int)tile.size();
-    for (int j = 0; j < 3; ++j) { d.m[j] = 1; d.toff[j] = 0; d.gstride[j] = 0; }
+    for (int j = 0; j < 3; ++j) { d.m[j] = 1; d.toff[j] = 0; d.gstride[j] = 0; d.ta3[j] = 0; }
     for (int j = 0; j < nt; ++j) {
       const int slot = 3 - nt + j, a = tile[j];
       d.m[slot] = (a == chunk_axis) ? chunk : h->ax[a].nloc; d.toff[slot] = h->ax[a].off; d.gstride[slot] = (int)stride[a];
       P.tile_axes[slot] = a;
+      d.ta3[slot] = h->ax[a].a3s;
     }
     d.nfixed = 0;
     long long ntiles = 1;
@@ -268,6 +272,7 @@ int build_plan(sdfs_handle* h, Plan& plan, const std::vector<int>& todo_in, std:
         const int k = d.nfixed++;
         d.fext[k] = h->ax[a].nloc / chunk; d.foff[k] = 0; d.fstride[k] = stride[a] * chunk;
         for (int s = 0; s < (int)G.size(); ++s) d.fq[s][k] = 0;
+        d.fa3[k] = h->ax[a].a3s * chunk;
         ntiles *= d.fext[k];
         continue;
       }
@@ -276,6 +281,7 @@ int build_plan(sdfs_handle* h, Plan& plan, const std::vector<int>& todo_in, std:
       const int k = d.nfixed++;
       d.fext[k] = h->ax[a].nloc; d.foff[k] = h->ax[a].off; d.fstride[k] = stride[a];
       for (int s = 0; s < (int)G.size(); ++s) d.fq[s][k] = h->ax[G[s]].qs[a];
+      d.fa3[k] = h->ax[a].a3s;
       ntiles *= h->ax[a].nloc;
     }
     d.ntiles = ntiles;
@@ -420,6 +426,7 @@ int launch_pass(sdfs_handle* h, Pass& P, int pro, int epi, const PassIO& io, int
   d.pro = pro; d.epi = epi; d.minus_identity = minus_identity;
   d.theta = h->theta; d.inv_theta = 1.0 / h->theta; d.beta = h->beta;
   d.ablate = env_int("SDFS_ABLATE", 0);
+  d.a3 = (epi == EPI_CES || epi == EPI_CES_LIN) ? h->a3 : nullptr;
   d.ref_off = 0;
   if (!h->sharded) {                       // C-order offset of the mid-grid point
     long long stride = 1;
@@ -971,6 +978,13 @@ int solve_anderson(sdfs_handle* h, const sdfs_opts& o, double* w, int64_t* n_ite
 }
 
 // ---------------------------------------------------------------------------
+// true when the `count` consecutive blocks of `len` doubles are bit for bit the same
+bool slices_identical(const double* p, long long count, size_t len) {
+  for (long long i = 1; i < count; ++i)
+    if (memcmp(p, p + (size_t)i * len, len * sizeof(double)) != 0) return false;
+  return true;
+}
+
 int setup_model(sdfs_handle* h, int model, int ndim, const int64_t* shapes, const double* params, int nparams,
                 const double* const* arrays, const int64_t* sizes, int narrays) {
   h->model = model; h->ndim = ndim;
@@ -1013,14 +1027,23 @@ int setup_model(sdfs_handle* h, int model, int ndim, const int64_t* shapes, cons
     for (int a = 0; a < 4; ++a) qf[a].assign(arrays[qi[a]], arrays[qi[a]] + sizes[qi[a]]);
     for (int l = 0; l < nl; ++l) for (int L = 0; L < nl; ++L) qf[0][(size_t)l * nl + L] *= a1[L];
     for (int k = 0; k < nc; ++k) for (int K = 0; K < nc; ++K) qf[1][(size_t)k * nc + K] *= a2[k];
-    for (size_t r = 0; r < a3.size(); ++r) for (int J = 0; J < nj; ++J) qf[3][r * nj + J] *= a3[r];
+    // z_Q[i, :, :] the same matrix for every i (Rouwenhorst / Tauchen: it depends on (n, rho) only)?  Then
+    // z is an unconditional axis with one matrix, and a3 stays a table the aggregator applies.
+    const bool z_same = slices_identical(qf[3].data(), nz, (size_t)nj * nj) && env_int("SDFS_NO_SLICE_MERGE", 0) == 0;
+    if (z_same) qf[3].resize((size_t)nj * nj);
+    else for (size_t r = 0; r < a3.size(); ++r) for (int J = 0; J < nj; ++J) qf[3][r * nj + J] *= a3[r];
     for (int a = 0; a < 4; ++a) {
       double* q = nullptr;
       if ((rc = upload(h, &q, qf[a].data(), qf[a].size()))) return rc;
-      h->ax[a].Q = q; h->ax[a].qcount = sizes[qi[a]] / ((long long)h->shape[a] * h->shape[a]);
+      h->ax[a].Q = q; h->ax[a].qcount = (long long)qf[a].size() / ((long long)h->shape[a] * h->shape[a]);
       strncpy(h->ax[a].name, nm[a], sizeof h->ax[a].name - 1);
     }
-    h->ax[3].qs[2] = 1;                 // z_Q[i, j, J] conditioned on the current h_z index
+    if (z_same) {
+      if ((rc = upload(h, &h->a3, a3.data(), a3.size()))) return rc;
+      h->ax[2].a3s = nj; h->ax[3].a3s = 1;            // a3[i, j]
+    } else {
+      h->ax[3].qs[2] = 1;               // z_Q[i, j, J] conditioned on the current h_z index
+    }
   } else if (model == SDFS_MODEL_GCY) {
     if (ndim != 6 || nparams != 18 || narrays != 15) return fail(h, SDFS_ERR_ARG, "GCY needs ndim 6, 18 params, 15 arrays");
     // params: beta, psi, gamma, rho_lam, s_lam, mu_c, ...  (gcy_model.py:72-75)
@@ -1046,17 +1069,28 @@ int setup_model(sdfs_handle* h, int model, int ndim, const int64_t* shapes, cons
     for (int a = 0; a < 6; ++a) qf[a].assign(arrays[qi[a]], arrays[qi[a]] + sizes[qi[a]]);
     for (int f = 0; f < nf; ++f) for (int F = 0; F < nf; ++F) qf[5][(size_t)f * nf + F] *= a1[F];
     for (int d = 0; d < nd; ++d) for (int D = 0; D < nd; ++D) qf[3][(size_t)d * nd + D] *= a2[d];
-    for (size_t r = 0; r < a3.size(); ++r) for (int A = 0; A < na; ++A) qf[0][r * na + A] *= a3[r];
+    // slice-identical conditional tensors become unconditional axes (see SSY above)
+    const bool merge = env_int("SDFS_NO_SLICE_MERGE", 0) == 0;
+    const bool z_same = merge && slices_identical(qf[0].data(), nbp * nc * ne, (size_t)(na * na));
+    const bool zpi_same = merge && slices_identical(qf[1].data(), ne, (size_t)(nbp * nbp));
+    if (z_same) qf[0].resize((size_t)(na * na));
+    else for (size_t r = 0; r < a3.size(); ++r) for (int A = 0; A < na; ++A) qf[0][r * na + A] *= a3[r];
+    if (zpi_same) qf[1].resize((size_t)(nbp * nbp));
     for (int a = 0; a < 6; ++a) {
       double* q = nullptr;
       if ((rc = upload(h, &q, qf[a].data(), qf[a].size()))) return rc;
-      h->ax[a].Q = q; h->ax[a].qcount = sizes[qi[a]] / ((long long)h->shape[a] * h->shape[a]);
+      h->ax[a].Q = q; h->ax[a].qcount = (long long)qf[a].size() / ((long long)h->shape[a] * h->shape[a]);
       strncpy(h->ax[a].name, nm[a], sizeof h->ax[a].name - 1);
     }
-    // z_Q[b, c, e, a, A]: conditioned on current (z_pi, h_z, h_zpi)
-    h->ax[0].qs[1] = (int)(nc * ne); h->ax[0].qs[2] = (int)ne; h->ax[0].qs[4] = 1;
+    if (z_same) {
+      if ((rc = upload(h, &h->a3, a3.data(), a3.size()))) return rc;
+      h->ax[0].a3s = 1; h->ax[4].a3s = (int)na; h->ax[2].a3s = (int)(ne * na); h->ax[1].a3s = (int)(nc * ne * na);  // a3[b,c,e,a]
+    } else {
+      // z_Q[b, c, e, a, A]: conditioned on current (z_pi, h_z, h_zpi)
+      h->ax[0].qs[1] = (int)(nc * ne); h->ax[0].qs[2] = (int)ne; h->ax[0].qs[4] = 1;
+    }
     // z_pi_Q[e, b, B]: conditioned on current h_zpi
-    h->ax[1].qs[4] = 1;
+    if (!zpi_same) h->ax[1].qs[4] = 1;
   } else {
     return fail(h, SDFS_ERR_ARG, "unknown model %d", model);
   }
