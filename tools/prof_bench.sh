@@ -6,7 +6,7 @@ ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-ARGS="--steps 50 --warmup 5 --no-cpu --no-secondary $@"
+ARGS="--no-cpu --no-secondary $@"   # bench.py defaults: 200 timed steps after 50 warm-up steps
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- python3 $ROOT/bench.py $ARGS > $OUT/kt.log 2>&1 || { echo "kernel-trace run failed"; tail -5 $OUT/kt.log; exit 1; }
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_LDS_BANK_CONFLICT --output-format csv -d $OUT/pmc1 -- python3 $ROOT/bench.py $ARGS > $OUT/pmc1.log 2>&1 || { echo "pmc1 failed"; tail -5 $OUT/pmc1.log; exit 1; }
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc2 -- python3 $ROOT/bench.py $ARGS > $OUT/pmc2.log 2>&1 || { echo "pmc2 failed"; exit 1; }
