@@ -82,6 +82,8 @@ struct PassIO {
   const unsigned long long* gate;   // if non-null and *gate <= tol bits: the iteration has converged, do nothing
   double gate_tol;
   unsigned long long* dbg;          // diagnostic builds (-DSDFS_STAMP): per-phase s_memtime stamps
+  double* dotp;                     // EPI_MUL with minus_identity: per-block partial sums of <out, v> and <out, out>
+                                    // (BiCGSTAB's <t, s>, <t, t>: s is in registers anyway), [2][ntiles], or null
 };
 
 typedef double v4d __attribute__((ext_vector_type(4)));
@@ -712,6 +714,7 @@ pass_kernel(const PassDesc P, const PassIO io) {
   // ---- residual / scaling and the global store -------------------------------------------
   const bool need_old = CES ? (io.resid != nullptr) : (MULE && P.minus_identity);
   double rmax = 0.0;
+  double dot_yv = 0.0, dot_yy = 0.0;
   {
     VecT<VEC> oldv[EPT];
     VecT<VEC> c2v[NC2];
@@ -740,7 +743,13 @@ pass_kernel(const PassDesc P, const PassIO io) {
 #pragma unroll
           for (int j = 0; j < VEC; ++j) {
             y.v[j] *= c2v[MULE ? k : 0].v[j];
-            if (P.minus_identity) y.v[j] -= oldv[k].v[j];
+            if (P.minus_identity) {
+              y.v[j] -= oldv[k].v[j];
+              // what gets stored is what the dots refer to (fp32 storage rounds first)
+              const double yr = F_OUT ? (double)(float)y.v[j] : y.v[j];
+              dot_yv = fma(yr, oldv[k].v[j], dot_yv);
+              dot_yy = fma(yr, yr, dot_yy);
+            }
           }
         } else if (CES && need_old) {
 #pragma unroll
@@ -757,6 +766,18 @@ pass_kernel(const PassDesc P, const PassIO io) {
   }
   STAMP(12);
 
+  if (MULE && io.dotp != nullptr) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { dot_yv += __shfl_xor(dot_yv, o); dot_yy += __shfl_xor(dot_yy, o); }
+    if (lane == 0) { red[wave] = dot_yv; red[8 + wave] = dot_yy; }
+    __syncthreads();
+    if (tid == 0) {
+      double a = 0.0, b = 0.0;
+      for (int w = 0; w < nwaves; ++w) { a += red[w]; b += red[8 + w]; }
+      io.dotp[blockIdx.x] = a;
+      io.dotp[P.ntiles + blockIdx.x] = b;
+    }
+  }
   if (CES && io.resid != nullptr) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) rmax = fmax(rmax, __shfl_xor(rmax, o));

@@ -581,7 +581,7 @@ int run_dense(sdfs_handle* h, int mode, const double* in, double* out, const dou
 
 int run_plan(sdfs_handle* h, Plan& plan, int mode, bool has_first, bool has_last,
              const double* in, double* out, const double* old, unsigned long long* resid,
-             const unsigned long long* gate, double gate_tol, int minus_identity) {
+             const unsigned long long* gate, double gate_tol, int minus_identity, double* dotp = nullptr) {
   if (h->cont) return run_cont(h, mode, in, out, old, resid, gate, gate_tol, minus_identity);
   if (h->dense) return run_dense(h, mode, in, out, old, resid, gate, gate_tol, minus_identity);
   int rc = ensure_tmp(h);
@@ -616,6 +616,7 @@ int run_plan(sdfs_handle* h, Plan& plan, int mode, bool has_first, bool has_last
         epi = EPI_MUL; bytes += n8;
         if (first) return fail(h, SDFS_ERR_UNSUPPORTED, "single-pass JVP not supported");
         io.aux_in = h->c2; io.old = old; if (minus_identity) bytes += n8;
+        if (minus_identity) io.dotp = dotp;
       }
     }
     // fp32 Krylov storage: every stream of a J.v application is fp32; a linearising T keeps fp64
@@ -772,10 +773,15 @@ int bicgstab_dev_t(sdfs_handle* h, const sdfs_opts& o, int64_t* matvecs) {
       hipLaunchKernelGGL(k_bicg_alpha_finish, dim3(1), dim3(VEC_BLOCK), 0, st, h->partial, g, h->sc);
       hipLaunchKernelGGL(k_bicg_s<T>, dim3(g), dim3(VEC_BLOCK), 0, st, r, (const T*)q, n, h->sc, h->partial);
       hipLaunchKernelGGL(k_bicg_s_finish, dim3(1), dim3(VEC_BLOCK), 0, st, h->partial, g, h->sc); }
-    if ((rc = run_plan(h, h->plan[0], MODE_JVP, true, true, (const double*)r, (double*)t, (const double*)r, nullptr, nullptr, 0.0, 1))) return rc;
+    // <t, s> and <t, t> come out of the last J.v pass when its tiles fit the partial-sum buffer
+    const long long last_tiles = (h->cont || h->dense || h->plan[0].passes.empty()) ? 0 : h->plan[0].passes.back().d.ntiles;
+    const bool fused_dots = last_tiles > 0 && 2 * last_tiles <= (long long)MAX_PARTIAL_BLOCKS * AND_MAX_M &&
+                            h->plan[0].passes.size() > 1 && env_int("SDFS_NO_DOT_FUSION", 0) == 0;
+    if ((rc = run_plan(h, h->plan[0], MODE_JVP, true, true, (const double*)r, (double*)t, (const double*)r, nullptr, nullptr, 0.0, 1,
+                       fused_dots ? h->partial : nullptr))) return rc;
     { ProfScope ps(h, cvec);
-      hipLaunchKernelGGL(k_dot2<T>, dim3(g), dim3(VEC_BLOCK), 0, st, (const T*)t, (const T*)r, n, h->partial);
-      hipLaunchKernelGGL(k_bicg_omega_finish, dim3(1), dim3(VEC_BLOCK), 0, st, h->partial, g, h->sc);
+      if (!fused_dots) hipLaunchKernelGGL(k_dot2<T>, dim3(g), dim3(VEC_BLOCK), 0, st, (const T*)t, (const T*)r, n, h->partial);
+      hipLaunchKernelGGL(k_bicg_omega_finish, dim3(1), dim3(VEC_BLOCK), 0, st, h->partial, fused_dots ? (int)last_tiles : g, h->sc);
       hipLaunchKernelGGL(k_bicg_update_xr<T>, dim3(g), dim3(VEC_BLOCK), 0, st, x, r, (const T*)p, (const T*)t, (const T*)rhat, n, h->sc, h->partial);
       hipLaunchKernelGGL(k_bicg_iter_finish, dim3(1), dim3(VEC_BLOCK), 0, st, h->partial, g, h->sc); }
     *matvecs += 2;
