@@ -63,6 +63,26 @@ def cpu_baseline(model, shapes, params, arrays, w_host, budget_s=12.0):
                       f"(oracle/c/wc_oracle.c, factorised, OpenMP), {dt:.1f} s"}
 
 
+def spawn_ranks(n, backend):
+    """`python bench.py --gpus N` without a launcher: run torch.distributed.run as a child (one rank per GPU,
+    rendezvous on 127.0.0.1) with this command line; rank 0 of the child prints the JSON line."""
+    import socket
+    import subprocess
+    import torch
+    ndev = torch.cuda.device_count()
+    if backend == "nccl" and ndev < n:
+        print(f"bench.py: --gpus {n} needs {n} devices, {ndev} visible", file=sys.stderr)
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -73,16 +93,27 @@ def main():
     ap.add_argument("--no-secondary", action="store_true")
     args = ap.parse_args()
 
+    # SDFS_BENCH_BACKEND=gloo rehearses the N > 1 path on a single GPU (all ranks on one device,
+    # exchanges staged through the host); the real run uses RCCL ("nccl"), one rank per GPU.
+    backend = os.environ.get("SDFS_BENCH_BACKEND", "nccl")
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # not under a launcher: start one rank per GPU ourselves, as a CHILD process and before anything in
+        # this process touches the GPU (device_count() does not initialise it), and pass its exit code on
+        sys.exit(spawn_ranks(args.gpus, backend))
+
     import torch
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus != world and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE {world}")
-    # SDFS_BENCH_BACKEND=gloo rehearses the N > 1 path on a single GPU (all ranks on one device,
-    # exchanges staged through the host); the real run uses RCCL ("nccl"), one rank per GPU.
-    backend = os.environ.get("SDFS_BENCH_BACKEND", "nccl")
-    local_rank = local_rank % max(torch.cuda.device_count(), 1)
+    if args.gpus != world:
+        # never fall through to a one-GPU measurement labelled as something else
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE {world}")
+    ndev = torch.cuda.device_count()
+    if backend == "nccl" and ndev < world:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} needs {args.gpus} devices, {ndev} visible")
+    local_rank = local_rank % max(ndev, 1)
     torch.cuda.set_device(local_rank)
     if world > 1:
         import torch.distributed as dist

@@ -18,6 +18,7 @@ from .operators import (KoopmansOperator, ssy_operator, gcy_operator, T_ssy, T_g
 from .solvers import (successive_approx, newton_solver, anderson_solver,
                       fixed_point_via_gradient_decent, solvers, solver,
                       default_tolerance, default_max_iter)
+from .drivers import test_compute_wc_ratio_ssy, test_compute_wc_ratio_gcy
 from .loglinear import wc_loglinear_factory, loglinear_guess
 from .continuous import (ContinuousOperator, build_grid, T_fun_factory, wc_ratio_continuous, qnwnorm,
                          lin_interp, vals_to_coords, construct_wstar_callable, save_wstar, load_wstar)
@@ -29,7 +30,8 @@ __all__ = ["SSY", "GCY", "rouwenhorst", "tauchen", "discretize_ssy", "discretize
            "KoopmansOperator", "ssy_operator", "gcy_operator", "T_ssy", "T_gcy",
            "successive_approx", "newton_solver", "anderson_solver",
            "fixed_point_via_gradient_decent", "solvers", "solver",
-           "default_tolerance", "default_max_iter", "wc_loglinear_factory", "loglinear_guess",
+           "default_tolerance", "default_max_iter", "test_compute_wc_ratio_ssy", "test_compute_wc_ratio_gcy",
+           "wc_loglinear_factory", "loglinear_guess",
            "ContinuousOperator", "build_grid", "T_fun_factory", "wc_ratio_continuous", "qnwnorm",
            "lin_interp", "vals_to_coords", "construct_wstar_callable", "save_wstar", "load_wstar",
            "DenseOperator", "compute_H_single_index", "discretize_single_index", "single_index_T",

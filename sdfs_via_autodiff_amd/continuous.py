@@ -236,23 +236,31 @@ def wc_ratio_continuous(model, *grid_sizes, num_std_devs=3.2, d=5, mc_draw_size=
 def save_wstar(filename, grids, w_star):
     """The reference's file: ``np.save(f, grids); np.save(f, w_star)`` in one stream
     (ssy_wc_ratio_continuous.py:291-295).  Equal-length grids give a 2-D float array exactly as the
-    reference writes; grids of different lengths (its defaults!) only round-trip through an object
-    array, which is what older numpy produced for ``np.save(f, grids)``."""
+    reference writes.  Grids of different lengths (its defaults!) cannot be one float array; they are
+    written without pickle as an int64 array of lengths followed by the concatenated grid values, so
+    the file never needs ``allow_pickle`` to be read back."""
     with open(filename, 'wb') as f:
         if len({len(g) for g in grids}) == 1:
-            np.save(f, np.asarray(grids))
+            np.save(f, np.asarray(grids, dtype=np.float64))
         else:
-            arr = np.empty(len(grids), dtype=object)
-            for i, g in enumerate(grids):
-                arr[i] = np.asarray(g)
-            np.save(f, arr, allow_pickle=True)
+            np.save(f, np.asarray([len(g) for g in grids], dtype=np.int64))
+            np.save(f, np.concatenate([np.asarray(g, dtype=np.float64).ravel() for g in grids]))
         np.save(f, np.asarray(w_star))
 
 
-def load_wstar(datafile='w_star_data.npy'):
+def load_wstar(datafile='w_star_data.npy', allow_pickle=False):
+    """Reads a result file written by ``save_wstar`` or by the reference.  ``allow_pickle=True`` is only
+    for files whose ragged grids were stored as a pickled object array (what old numpy made of the
+    reference's ``np.save(f, grids)``); it executes whatever the pickle holds, so it is opt-in."""
     with open(datafile, 'rb') as f:
-        grids = np.load(f, allow_pickle=True)
-        w_star_vals = np.load(f)
+        first = np.load(f, allow_pickle=allow_pickle)
+        if first.dtype.kind in "iu" and first.ndim == 1:          # lengths + flat values
+            flat = np.load(f, allow_pickle=False)
+            cuts = np.cumsum(first)[:-1]
+            grids = np.split(np.asarray(flat, dtype=np.float64), cuts)
+        else:
+            grids = first
+        w_star_vals = np.load(f, allow_pickle=False)
     return tuple(np.asarray(g, dtype=np.float64) for g in grids), w_star_vals
 
 

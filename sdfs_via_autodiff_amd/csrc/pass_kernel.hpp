@@ -68,7 +68,7 @@ struct PassDesc {
   // lets the planner treat that axis as unconditional (longer contiguous runs in the last pass)
   const double* a3;
   long long ntiles;
-  int ablate;                  // diagnostics only (SDFS_ABLATE): 1 = skip the powers, 2 = skip the contractions
+  int ablate;                  // -DSDFS_DIAG builds only (SDFS_ABLATE): 1 = skip the powers, 2 = skip the contractions
   long long ref_off;           // grid offset of the mid-grid point (reference of the fp32 c1 / c2 scaling)
 };
 
@@ -208,15 +208,18 @@ __device__ __forceinline__ double gather64b(double v, int byte_idx) {
   const int hi = __builtin_amdgcn_ds_bpermute(byte_idx, __double2hiint(v));
   return __hiloint2double(hi, lo);
 }
+// pow_fast_try: the straight-line path alone.  Returns (per lane) whether any of its N inputs needs the
+// full routine; `ehi` is y log2 x as the fast path saw it (the caller's fix-up test).
 template <bool HIPREC, int N>
-__device__ __forceinline__ void pow_fast_n(const double (&x)[N], double y, const PowLane& T, double (&res)[N]) {
+__device__ __forceinline__ bool pow_fast_try(const double (&x)[N], double y, const PowLane& T, double (&res)[N],
+                                             double (&ehi)[N]) {
   // every product below that must round on its own is written as a separate statement: the compiler
   // may not fuse it into a neighbouring add (y * hi fused into ehi - kk counts its rounding twice)
 #pragma clang fp contract(off)
   constexpr int OFFH = (int)(POW_OFF >> 32);
   constexpr double SHIFT = 0x1.8p46;
   int i4[N], ji[N];
-  double kd[N], z[N], invc[N], lchi[N], lclo[N], r[N], t1[N], q[N], ehi[N], elo[N], f[N], t[N], p[N];
+  double kd[N], z[N], invc[N], lchi[N], lclo[N], r[N], t1[N], q[N], elo[N], f[N], t[N], p[N];
   bool rare = false;
   SDFS_FORJ {
     const int hx = __double2hiint(x[j]);
@@ -274,6 +277,20 @@ __device__ __forceinline__ void pow_fast_n(const double (&x)[N], double y, const
     const double v = fma(t[j], p[j] * f[j], t[j]);
     res[j] = __hiloint2double(__double2hiint(v) + ((ji[j] >> 6) << 20), __double2loint(v));
   }
+  return rare;
+}
+
+// the full-range answer for one element (IEEE corner cases included): what a wave re-runs when
+// pow_fast_try flags a lane
+template <bool HIPREC>
+__device__ __forceinline__ double pow_full(double x, double y, const PowLane& T) {
+  return pow_fix(x, y, pow_core<HIPREC>(x, y, T));
+}
+
+template <bool HIPREC, int N>
+__device__ __forceinline__ void pow_fast_n(const double (&x)[N], double y, const PowLane& T, double (&res)[N]) {
+  double ehi[N];
+  const bool rare = pow_fast_try<HIPREC, N>(x, y, T, res, ehi);
   if (__builtin_expect(__builtin_amdgcn_ballot_w64(rare) != 0ULL, 0)) {
     SDFS_FORJ {
       const double c = pow_fix(x[j], y, pow_core<HIPREC>(x[j], y, T));
@@ -470,6 +487,13 @@ __device__ __forceinline__ void contract_step(double* __restrict__ lds, const Pa
 #undef SDFS_CC
 }
 
+// timing diagnostics (skip the powers / the contractions: results are WRONG) exist only in -DSDFS_DIAG builds
+#ifdef SDFS_DIAG
+#define SDFS_ABL(P, bit) (((P).ablate & (bit)) != 0)
+#else
+#define SDFS_ABL(P, bit) false
+#endif
+
 #ifdef SDFS_STAMP
 #define STAMP(slot)                                                                        \
   do {                                                                                     \
@@ -639,7 +663,7 @@ pass_kernel(const PassDesc P, const PassIO io) {
 
   // ---- prologue x = a1 w^theta, in place in LDS (each thread revisits its own units).
   //      Uniform trip count: pow_fast needs every lane of the wave active.
-  if (POWP && !(P.ablate & 1)) {
+  if (POWP && !SDFS_ABL(P, 1)) {
     Walker wk;
     wk.init(tid, B, m1, m2u);
 #pragma unroll 1
@@ -670,15 +694,15 @@ pass_kernel(const PassDesc P, const PassIO io) {
   STAMP(4);
 
   // ---- contractions ------------------------------------------------------------------
-  if (P.nsteps > 0 && !(P.ablate & 2)) { contract_step(lds, P, 0, lane, wave, nwaves); STAMP(5); __syncthreads(); }
+  if (P.nsteps > 0 && !SDFS_ABL(P, 2)) { contract_step(lds, P, 0, lane, wave, nwaves); STAMP(5); __syncthreads(); }
   STAMP(6);
-  if (P.nsteps > 1 && !(P.ablate & 2)) { contract_step(lds, P, 1, lane, wave, nwaves); STAMP(7); __syncthreads(); }
+  if (P.nsteps > 1 && !SDFS_ABL(P, 2)) { contract_step(lds, P, 1, lane, wave, nwaves); STAMP(7); __syncthreads(); }
   STAMP(8);
-  if (P.nsteps > 2 && !(P.ablate & 2)) { contract_step(lds, P, 2, lane, wave, nwaves); STAMP(9); __syncthreads(); }
+  if (P.nsteps > 2 && !SDFS_ABL(P, 2)) { contract_step(lds, P, 2, lane, wave, nwaves); STAMP(9); __syncthreads(); }
   STAMP(10);
 
   // ---- aggregator Tw = 1 + beta (K S)^(1/theta), in place in LDS (rolled, uniform) ------
-  if (CES && !(P.ablate & 1)) {
+  if (CES && !SDFS_ABL(P, 1)) {
     Walker wk;
     wk.init(tid, B, m1, m2u);
 #pragma unroll 1

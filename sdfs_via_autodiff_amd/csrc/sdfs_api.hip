@@ -20,6 +20,7 @@
 
 #include "../../include/sdfs_hip.h"
 #include "pass_kernel.hpp"
+#include "fast_kernels.hpp"
 #include "cont_kernel.hpp"
 #include "dense_kernel.hpp"
 #include "vec_kernels.hpp"
@@ -67,6 +68,30 @@ struct Plan {
 
 struct EventPair { hipEvent_t a, b; int counter; };
 
+// "pair plan" (fast_kernels.hpp): one slice pass over the two fastest axes, then one line pass per slower pair
+struct FastPass {
+  bool line = false;
+  int n = 0;
+  int ax0 = -1, ax1 = -1;      // the contracted pair (ax0 slower)
+  SliceDesc sd;
+  LineDesc ld;
+  double q_bytes = 0, flops = 0;
+  std::string label;
+};
+struct FastPlan {
+  bool ok = false;
+  std::vector<FastPass> passes;
+};
+
+// Diagnostic knobs (tools/README.md): read ONCE, when a handle is created -- never on a launch path
+struct Knobs {
+  int tile_budget = 0, filler_chunk = -1, force_waves = 0, no_occ_blocks = 0, no_pad = 0, no_vec2 = 0, no_vec4 = 0;
+  int no_dot_fusion = 0, no_slice_merge = 0, cont_no_tensor = 0, cont_lds_cap = 4000;
+  int pair_order = 0;          // SDFS_PAIR_ORDER=1: line passes slowest pair first (the last pass then walks the faster pair)
+  int plan = 0;                // SDFS_PLAN: 0 = automatic, 1 = "classic" (generic tiles only), 2 = "pair" (pair plan whenever legal)
+  int ablate = 0;              // SDFS_ABLATE, honoured only by -DSDFS_DIAG builds
+};
+
 }  // namespace
 
 struct sdfs_handle {
@@ -84,8 +109,12 @@ struct sdfs_handle {
   std::vector<double*> dev_allocs;
   AxisInfo ax[MAXD];
 
+  Knobs knobs;
+
   // plans: [0] full grid (or stage 0 of a sharded run), [1] stage 1 of a sharded run
   Plan plan[2];
+  FastPlan fast;                      // pair plan of the full grid, when the model admits it
+  std::vector<void*> misc_allocs;     // device index tables of the pair plan
   bool sharded = false;
   int axis_a = -1, axis_b = -1;
 
@@ -172,6 +201,29 @@ int env_int(const char* name, int dflt) {
   return (s && *s) ? atoi(s) : dflt;
 }
 
+Knobs read_knobs() {
+  Knobs k;
+  k.tile_budget = env_int("SDFS_TILE_BUDGET", 0);
+  k.filler_chunk = env_int("SDFS_FILLER_CHUNK", -1);
+  k.force_waves = env_int("SDFS_FORCE_WAVES", 0);
+  k.no_occ_blocks = env_int("SDFS_NO_OCC_BLOCKS", 0);
+  k.no_pad = env_int("SDFS_NO_PAD", 0);
+  k.no_vec2 = env_int("SDFS_NO_VEC2", 0);
+  k.no_vec4 = env_int("SDFS_NO_VEC4", 0);
+  k.no_dot_fusion = env_int("SDFS_NO_DOT_FUSION", 0);
+  k.no_slice_merge = env_int("SDFS_NO_SLICE_MERGE", 0);
+  k.cont_no_tensor = env_int("SDFS_CONT_NO_TENSOR", 0);
+  k.cont_lds_cap = env_int("SDFS_CONT_LDS_CAP", 4000);
+  k.pair_order = env_int("SDFS_PAIR_ORDER", 0);
+  const char* pl = getenv("SDFS_PLAN");
+  if (pl && !strcmp(pl, "classic")) k.plan = 1;
+  else if (pl && !strcmp(pl, "pair")) k.plan = 2;
+#ifdef SDFS_DIAG
+  k.ablate = env_int("SDFS_ABLATE", 0);
+#endif
+  return k;
+}
+
 // ---------------------------------------------------------------------------
 // Planner: group the axes into passes (legal order, LDS budget, coalesced runs).
 // `todo` = axes to contract in this plan (all, or a stage's subset); `done` = axes
@@ -186,7 +238,7 @@ int build_plan(sdfs_handle* h, Plan& plan, const std::vector<int>& todo_in, std:
     long long s = 1;
     for (int a = D - 1; a >= 0; --a) { stride[a] = s; s *= h->ax[a].nloc; }
   }
-  long long budget = env_int("SDFS_TILE_BUDGET", 0);
+  long long budget = h->knobs.tile_budget;
   if (budget <= 0) budget = std::max<long long>(256, std::min<long long>(8192, nloc / 128));
 
   std::vector<int> todo = todo_in;
@@ -243,7 +295,7 @@ int build_plan(sdfs_handle* h, Plan& plan, const std::vector<int>& todo_in, std:
       const bool want = (mincols < 16) || (nloc / e >= 512);
       if (e > budget || !want) break;
       tile = nt;
-      int fc = env_int("SDFS_FILLER_CHUNK", -1);
+      int fc = h->knobs.filler_chunk;
       if (fc < 0) {
         // automatic: a filler that makes the tile too big for more than two blocks per CU is taken in two
         // halves (GCY 20^6 last pass: 20x10x20 tiles, four 256-thread blocks per CU, 0.384 -> 0.363 ms)
@@ -310,7 +362,7 @@ int build_plan(sdfs_handle* h, Plan& plan, const std::vector<int>& todo_in, std:
     // LDS strides: pad the fastest stride to == 2 (mod 4) doubles when it is the
     // K dimension of an MFMA step (16 columns x 2 rows then hit 32 distinct b64 banks)
     int L1 = d.m[2];
-    if (contracts_fast_slot && d.m[1] * d.m[0] > 1 && env_int("SDFS_NO_PAD", 0) == 0) { while ((L1 & 3) != 2) ++L1; }
+    if (contracts_fast_slot && d.m[1] * d.m[0] > 1 && h->knobs.no_pad == 0) { while ((L1 & 3) != 2) ++L1; }
     d.L[2] = 1; d.L[1] = L1; d.L[0] = L1 * d.m[1];
     long long lds_elems = (long long)d.L[0] * d.m[0];
     lds_elems += lds_elems & 1;
@@ -335,12 +387,12 @@ int build_plan(sdfs_handle* h, Plan& plan, const std::vector<int>& todo_in, std:
         if (cost < best) { best = cost; w_mfma = w; }
       }
     }
-    int fw = env_int("SDFS_FORCE_WAVES", 0);
+    int fw = h->knobs.force_waves;
     int waves = std::max(w_elem, w_mfma);
     // Resident waves per CU are capped at 16 by the ~128 VGPRs of the kernel.  Where LDS would allow more
     // than two blocks per CU (tiles well under 80 KB), smaller blocks keep those 16 waves but put more
     // independent blocks -- in different phases -- on the CU (GCY 16^6: 3031 -> 3519 iterations/s).
-    if (env_int("SDFS_NO_OCC_BLOCKS", 0) == 0) {
+    if (h->knobs.no_occ_blocks == 0) {
       const int blocks_lds = (int)std::min<size_t>(8, (160 * 1024) / std::max<size_t>(P.lds_bytes, 1));
       if (blocks_lds > 2) {
         int w = 2;                                  // power of two: 16-column tiles split evenly over the waves
@@ -357,7 +409,7 @@ int build_plan(sdfs_handle* h, Plan& plan, const std::vector<int>& todo_in, std:
     // 16-byte accesses: runs along slot 2 must be even, contiguous and every base even
     bool v2 = (d.m[2] % 2 == 0) && d.gstride[2] == 1 && (d.L[1] % 2 == 0) && (d.L[0] % 2 == 0) &&
               (d.gstride[0] % 2 == 0 || d.m[0] == 1) && (d.gstride[1] % 2 == 0 || d.m[1] == 1) &&
-              env_int("SDFS_NO_VEC2", 0) == 0;
+              h->knobs.no_vec2 == 0;
     for (int k = 0; k < d.nfixed; ++k) if (d.fstride[k] % 2 != 0 && d.fext[k] > 1) v2 = false;
     P.vec2 = v2;
     P.ept2 = v2 ? units_per_thread(tot / 2) : P.ept1;
@@ -443,7 +495,7 @@ int launch_pass(sdfs_handle* h, Pass& P, int pro, int epi, const PassIO& io, int
   PassDesc d = P.d;
   d.pro = pro; d.epi = epi; d.minus_identity = minus_identity;
   d.theta = h->theta; d.inv_theta = 1.0 / h->theta; d.beta = h->beta;
-  d.ablate = env_int("SDFS_ABLATE", 0);
+  d.ablate = h->knobs.ablate;            // always 0 unless built with -DSDFS_DIAG
   d.a3 = (epi == EPI_CES || epi == EPI_CES_LIN) ? h->a3 : nullptr;
   d.ref_off = 0;
   if (!h->sharded) {                       // C-order offset of the mid-grid point
@@ -471,7 +523,7 @@ int launch_pass(sdfs_handle* h, Pass& P, int pro, int epi, const PassIO& io, int
   if (pro == PRO_MUL && epi == EPI_MUL) return fail(h, SDFS_ERR_UNSUPPORTED, "single-pass JVP not supported");
   const int block = P.block;
   const bool v4 = v2 && P.vec4 && prec == 1 && (mode == M_JFIRST || mode == M_MID || mode == M_JLAST) &&
-                  env_int("SDFS_NO_VEC4", 0) == 0;
+                  h->knobs.no_vec4 == 0;
   const int vec = v4 ? 4 : (v2 ? 2 : 1), ept = v4 ? P.ept4 : (v2 ? P.ept2 : P.ept1);
   pass_fn fn = pass_kernel_variant(ept, vec, mode, prec);
   if (!fn) return fail(h, SDFS_ERR_UNSUPPORTED, "no kernel variant for EPT %d VEC %d", ept, vec);
@@ -597,11 +649,181 @@ int run_dense(sdfs_handle* h, int mode, const double* in, double* out, const dou
   return 0;
 }
 
+// ---------------------------------------------------------------------------
+// Pair plan (fast_kernels.hpp).  Legal when every axis is unconditional (one n x n matrix per axis; the
+// current-state scale a3 then lives in a table), the axes pair up (D-2, D-1), (D-4, D-3), ... with equal
+// extents n in {16, 20, 24, 32}, and everything behind a line pass's pair is an even number of doubles.
+// Automatic use needs enough line tiles to fill the chip (6-D grids from 16^6 up); SDFS_PLAN=pair forces it
+// wherever it is legal (tests), SDFS_PLAN=classic switches it off.
+int upload_ints(sdfs_handle* h, const std::vector<int>& v, int** out) {
+  HIPCHK(h, hipMalloc((void**)out, std::max<size_t>(v.size(), 1) * sizeof(int)));
+  h->misc_allocs.push_back(*out);
+  HIPCHK(h, hipMemcpy(*out, v.data(), v.size() * sizeof(int), hipMemcpyHostToDevice));
+  return 0;
+}
+
+int build_fast_plan(sdfs_handle* h) {
+  h->fast.ok = false;
+  h->fast.passes.clear();
+  const int D = h->ndim;
+  if (h->knobs.plan == 1 || h->sharded || h->cont || h->dense || (D != 4 && D != 6) || h->a3 == nullptr) return 0;
+  if (h->N >= (1LL << 29)) return 0;                       // 32-bit byte offsets inside a tile
+  for (int a = 0; a < D; ++a) {
+    if (h->ax[a].qcount != 1) return 0;
+    for (int c = 0; c < D; ++c) if (h->ax[a].qs[c] != 0) return 0;
+    if (h->ax[a].a3s < 0 || h->ax[a].a3s >= (1 << 24)) return 0;
+  }
+  for (int a = 0; a < D; a += 2) {
+    const int n = h->shape[a];
+    if (n != h->shape[a + 1] || !(n == 16 || n == 20 || n == 24 || n == 32)) return 0;
+  }
+  long long stride[MAXD];
+  { long long st = 1; for (int a = D - 1; a >= 0; --a) { stride[a] = st; st *= h->shape[a]; } }
+  std::vector<FastPass> passes;
+  {
+    FastPass P;
+    const int n = h->shape[D - 1];
+    P.line = false; P.n = n; P.ax0 = D - 2; P.ax1 = D - 1;
+    memset(&P.sd, 0, sizeof P.sd);
+    P.sd.nslices = h->N / ((long long)n * n);
+    P.sd.Qf = h->ax[D - 1].Q; P.sd.Qe = h->ax[D - 2].Q; P.sd.theta = h->theta;
+    P.q_bytes = 2 * 8.0 * n * n; P.flops = 2.0 * (double)h->N * 2 * n;
+    P.label = std::string("slices[") + h->ax[D - 2].name + "," + h->ax[D - 1].name + "|wave-private " +
+              std::to_string(slice_tile_slices(n)) + "x" + std::to_string(n) + "x" + std::to_string(n) + "]";
+    passes.push_back(P);
+  }
+  long long min_tiles = 1LL << 60;
+  std::vector<int> line_axes;
+  for (int a = D - 4; a >= 0; a -= 2) line_axes.push_back(a);
+  if (h->knobs.pair_order == 1) std::reverse(line_axes.begin(), line_axes.end());
+  for (int a : line_axes) {
+    FastPass P;
+    const int n = h->shape[a];
+    P.line = true; P.n = n; P.ax0 = a; P.ax1 = a + 1;
+    memset(&P.ld, 0, sizeof P.ld);
+    LineDesc& L = P.ld;
+    L.lrest = stride[a + 1];
+    if (L.lrest % 2 != 0) return 0;
+    L.nchunks = (int)((L.lrest + LINE_R - 1) / LINE_R);
+    L.nouter = h->N / ((long long)n * n * L.lrest);
+    L.ntiles = L.nouter * L.nchunks;
+    if (L.ntiles >= (1LL << 31) || (long long)n * n * L.lrest * 8 >= (1LL << 32)) return 0;
+    L.Qx = h->ax[a].Q; L.Qy = h->ax[a + 1].Q;
+    L.inv_theta = 1.0 / h->theta; L.beta = h->beta;
+    L.a3x = h->ax[a].a3s; L.a3y = h->ax[a + 1].a3s;
+    min_tiles = std::min(min_tiles, L.ntiles);
+    P.q_bytes = 2 * 8.0 * n * n; P.flops = 2.0 * (double)h->N * 2 * n;
+    P.label = std::string("lines[") + h->ax[a].name + "," + h->ax[a + 1].name + "|" + std::to_string(n) + "x" +
+              std::to_string(n) + "x16 tile]";
+    passes.push_back(P);
+  }
+  if (h->knobs.plan != 2 && min_tiles < 2LL * h->num_cus) return 0;      // too few tiles to fill the chip
+  // index tables of the aggregator's a3 gather (last pass = the slowest pair): a3 index =
+  // out_idx[outer] + x a3s[X] + y a3s[Y] + rest_idx[position behind Y]
+  {
+    FastPass& P = passes.back();
+    const int a = P.ax0;
+    std::vector<int> outv((size_t)P.ld.nouter, 0), restv((size_t)P.ld.lrest, 0);
+    for (long long o = 0; o < P.ld.nouter; ++o) {
+      long long r = o; int idx = 0;
+      for (int c = a - 1; c >= 0; --c) { idx += (int)(r % h->shape[c]) * h->ax[c].a3s; r /= h->shape[c]; }
+      outv[(size_t)o] = idx;
+    }
+    for (long long q = 0; q < P.ld.lrest; ++q) {
+      long long r = q; int idx = 0;
+      for (int c = D - 1; c > a + 1; --c) { idx += (int)(r % h->shape[c]) * h->ax[c].a3s; r /= h->shape[c]; }
+      restv[(size_t)q] = idx;
+    }
+    int *od = nullptr, *rd = nullptr;
+    int rc;
+    if ((rc = upload_ints(h, outv, &od)) || (rc = upload_ints(h, restv, &rd))) return rc;
+    P.ld.a3 = h->a3; P.ld.out_idx = od; P.ld.rest_idx = rd;
+  }
+  // dynamic LDS above 64 KB has to be allowed per kernel variant
+  for (const FastPass& P : passes) {
+    if (!P.line) for (int m = 0; m < S_NMODES; ++m) {
+      slice_fn f = slice_variant(P.n, m);
+      if (!f) return 0;
+      hipFuncSetAttribute((const void*)f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)slice_lds_bytes(P.n));
+    } else for (int m = 0; m < L_NMODES; ++m) {
+      line_fn f = line_variant(P.n, m);
+      if (!f) return 0;
+      hipFuncSetAttribute((const void*)f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)line_lds_bytes(P.n));
+    }
+  }
+  h->fast.passes = passes;
+  h->fast.ok = true;
+  return 0;
+}
+
+int run_fast_plan(sdfs_handle* h, int mode, const double* in, double* out, const double* old,
+                  unsigned long long* resid, const unsigned long long* gate, double gate_tol, int minus_identity,
+                  double* dotp) {
+  int rc = ensure_tmp(h);
+  if (rc) return rc;
+  if (mode != MODE_T) { rc = ensure_lin(h); if (rc) return rc; }
+  const int np = (int)h->fast.passes.size();
+  const double n8 = 8.0 * (double)h->N;
+  const char* tag = (mode == MODE_JVP) ? "jvp" : (mode == MODE_T_LIN ? "Tlin" : "T");
+  for (int i = 0; i < np; ++i) {
+    FastPass& P = h->fast.passes[i];
+    const bool last = i == np - 1;
+    double bytes = 2 * n8 + P.q_bytes;
+    const double* pin = (i == 0) ? in : h->tmp;
+    double* pout = last ? out : h->tmp;
+    if (!P.line) {
+      SliceIO io;
+      memset(&io, 0, sizeof io);
+      io.in = pin; io.out = pout; io.gate = gate; io.gate_tol = gate_tol;
+      int sm = S_TFIRST;
+      if (mode == MODE_T_LIN) { sm = S_TFIRST_LIN; io.aux_out = h->c1; bytes += n8; }
+      else if (mode == MODE_JVP) { sm = S_JFIRST; io.aux_in = h->c1; bytes += n8; }
+      slice_fn fn = slice_variant(P.n, sm);
+      int cid = -1;
+      if (h->profiling) { char nm[48]; snprintf(nm, sizeof nm, "%s:%s", tag, P.label.c_str()); cid = counter_id(h, nm, bytes, P.flops); }
+      const long long ntile = (P.sd.nslices + slice_tile_slices(P.n) - 1) / slice_tile_slices(P.n);
+      const unsigned grid = (unsigned)((ntile + 3) / 4);
+      ProfScope ps(h, cid);
+      hipLaunchKernelGGL(fn, dim3(grid), dim3(256), slice_lds_bytes(P.n), h->stream, P.sd, io);
+    } else {
+      LineIO io;
+      memset(&io, 0, sizeof io);
+      io.in = pin; io.out = pout; io.gate = gate; io.gate_tol = gate_tol;
+      LineDesc d = P.ld;
+      d.minus_identity = minus_identity;
+      int lm = L_MID;
+      if (last) {
+        if (mode == MODE_T) { lm = L_TLAST; io.old = old; io.resid = resid; if (resid) bytes += n8; }
+        else if (mode == MODE_T_LIN) { lm = L_TLAST_LIN; io.old = old; io.resid = resid; io.aux_out = h->c2; bytes += n8; if (resid) bytes += n8; }
+        else { lm = L_JLAST; io.aux_in = h->c2; io.old = old; bytes += n8; if (minus_identity) { bytes += n8; io.dotp = dotp; } }
+      }
+      line_fn fn = line_variant(P.n, lm);
+      int cid = -1;
+      if (h->profiling) { char nm[48]; snprintf(nm, sizeof nm, "%s:%s", tag, P.label.c_str()); cid = counter_id(h, nm, bytes, P.flops); }
+      ProfScope ps(h, cid);
+      hipLaunchKernelGGL(fn, dim3((unsigned)d.ntiles), dim3(line_block(P.n)), line_lds_bytes(P.n), h->stream, d, io);
+    }
+    HIPCHK(h, hipGetLastError());
+  }
+  return 0;
+}
+
+// tiles of the last pass of a J.v application (per-block partial sums of the fused dots)
+long long jvp_last_tiles(sdfs_handle* h) {
+  if (h->cont || h->dense) return 0;
+  if (h->fast.ok && !h->krylov_f32) return h->fast.passes.back().ld.ntiles;
+  return h->plan[0].passes.empty() ? 0 : h->plan[0].passes.back().d.ntiles;
+}
+
 int run_plan(sdfs_handle* h, Plan& plan, int mode, bool has_first, bool has_last,
              const double* in, double* out, const double* old, unsigned long long* resid,
              const unsigned long long* gate, double gate_tol, int minus_identity, double* dotp = nullptr) {
   if (h->cont) return run_cont(h, mode, in, out, old, resid, gate, gate_tol, minus_identity);
   if (h->dense) return run_dense(h, mode, in, out, old, resid, gate, gate_tol, minus_identity);
+  // the pair plan serves the whole-grid operator in fp64; fp32 Krylov storage (and its linearisation, which
+  // writes c1 / c2 as scaled fp32) stays on the generic kernels
+  if (h->fast.ok && &plan == &h->plan[0] && has_first && has_last && !(h->krylov_f32 && mode != MODE_T))
+    return run_fast_plan(h, mode, in, out, old, resid, gate, gate_tol, minus_identity, dotp);
   int rc = ensure_tmp(h);
   if (rc) return rc;
   if (mode != MODE_T) { rc = ensure_lin(h); if (rc) return rc; }
@@ -711,17 +933,22 @@ int solve_sa(sdfs_handle* h, const sdfs_opts& o, double* w, int64_t* n_iter, int
     HIPCHK(h, hipMemcpyAsync(h->slots_host, h->slots, 8 * (size_t)count, hipMemcpyDeviceToHost, h->stream));
     return 0;
   };
-  const bool graph = o.use_graph && !h->profiling;
+  // hipStreamBeginCapture is illegal on the legacy NULL stream (sdfs_set_stream(h, NULL, 0)): plain launches there
+  const bool graph = o.use_graph && !h->profiling && h->stream != nullptr;
   if (graph && (h->sa_graph == nullptr || h->sa_graph_chunk != chunk || h->sa_graph_tol != o.tol)) {
     if (h->sa_graph) { hipGraphExecDestroy(h->sa_graph); h->sa_graph = nullptr; }
     hipGraph_t g = nullptr;
     HIPCHK(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
     rc = enqueue(0, chunk);
     hipError_t e = hipStreamEndCapture(h->stream, &g);
-    if (rc) return rc;
-    HIPCHK(h, e);
-    HIPCHK(h, hipGraphInstantiate(&h->sa_graph, g, nullptr, nullptr, 0));
+    if (rc || e != hipSuccess) {
+      if (g) hipGraphDestroy(g);
+      if (rc) return rc;
+      HIPCHK(h, e);
+    }
+    e = hipGraphInstantiate(&h->sa_graph, g, nullptr, nullptr, 0);
     hipGraphDestroy(g);
+    HIPCHK(h, e);
     h->sa_graph_chunk = chunk;
     h->sa_graph_tol = o.tol;
   }
@@ -792,9 +1019,9 @@ int bicgstab_dev_t(sdfs_handle* h, const sdfs_opts& o, int64_t* matvecs) {
       hipLaunchKernelGGL(k_bicg_s<T>, dim3(g), dim3(VEC_BLOCK), 0, st, r, (const T*)q, n, h->sc, h->partial);
       hipLaunchKernelGGL(k_bicg_s_finish, dim3(1), dim3(VEC_BLOCK), 0, st, h->partial, g, h->sc); }
     // <t, s> and <t, t> come out of the last J.v pass when its tiles fit the partial-sum buffer
-    const long long last_tiles = (h->cont || h->dense || h->plan[0].passes.empty()) ? 0 : h->plan[0].passes.back().d.ntiles;
+    const long long last_tiles = jvp_last_tiles(h);
     const bool fused_dots = last_tiles > 0 && 2 * last_tiles <= (long long)MAX_PARTIAL_BLOCKS * AND_MAX_M &&
-                            h->plan[0].passes.size() > 1 && env_int("SDFS_NO_DOT_FUSION", 0) == 0;
+                            (h->plan[0].passes.size() > 1 || (h->fast.ok && !h->krylov_f32)) && h->knobs.no_dot_fusion == 0;
     if ((rc = run_plan(h, h->plan[0], MODE_JVP, true, true, (const double*)r, (double*)t, (const double*)r, nullptr, nullptr, 0.0, 1,
                        fused_dots ? h->partial : nullptr))) return rc;
     { ProfScope ps(h, cvec);
@@ -1053,7 +1280,7 @@ int setup_model(sdfs_handle* h, int model, int ndim, const int64_t* shapes, cons
     for (int k = 0; k < nc; ++k) for (int K = 0; K < nc; ++K) qf[1][(size_t)k * nc + K] *= a2[k];
     // z_Q[i, :, :] the same matrix for every i (Rouwenhorst / Tauchen: it depends on (n, rho) only)?  Then
     // z is an unconditional axis with one matrix, and a3 stays a table the aggregator applies.
-    const bool z_same = slices_identical(qf[3].data(), nz, (size_t)nj * nj) && env_int("SDFS_NO_SLICE_MERGE", 0) == 0;
+    const bool z_same = slices_identical(qf[3].data(), nz, (size_t)nj * nj) && h->knobs.no_slice_merge == 0;
     if (z_same) qf[3].resize((size_t)nj * nj);
     else for (size_t r = 0; r < a3.size(); ++r) for (int J = 0; J < nj; ++J) qf[3][r * nj + J] *= a3[r];
     for (int a = 0; a < 4; ++a) {
@@ -1094,7 +1321,7 @@ int setup_model(sdfs_handle* h, int model, int ndim, const int64_t* shapes, cons
     for (int f = 0; f < nf; ++f) for (int F = 0; F < nf; ++F) qf[5][(size_t)f * nf + F] *= a1[F];
     for (int d = 0; d < nd; ++d) for (int D = 0; D < nd; ++D) qf[3][(size_t)d * nd + D] *= a2[d];
     // slice-identical conditional tensors become unconditional axes (see SSY above)
-    const bool merge = env_int("SDFS_NO_SLICE_MERGE", 0) == 0;
+    const bool merge = h->knobs.no_slice_merge == 0;
     const bool z_same = merge && slices_identical(qf[0].data(), nbp * nc * ne, (size_t)(na * na));
     const bool zpi_same = merge && slices_identical(qf[1].data(), ne, (size_t)(nbp * nbp));
     if (z_same) qf[0].resize((size_t)(na * na));
@@ -1136,6 +1363,7 @@ int create_common(int model, int ndim, const int64_t* shapes, const double* para
     return fail(nullptr, SDFS_ERR_HIP, "no HIP device available (libsdfs_hip has no CPU fallback)");
   if (device_id < 0 || device_id >= ndev) return fail(nullptr, SDFS_ERR_ARG, "device_id %d out of range (%d devices)", device_id, ndev);
   sdfs_handle* h = new sdfs_handle();
+  h->knobs = read_knobs();
   memset(&h->counters, 0, sizeof h->counters);
   h->device = device_id;
   auto bail = [&](int rc) { g_create_error = h->err; sdfs_destroy(h); return rc; };
@@ -1169,6 +1397,8 @@ int create_common(int model, int ndim, const int64_t* shapes, const double* para
   for (int a = 0; a < ndim; ++a) all.push_back(a);
   if (axis_a < 0) {
     rc = build_plan(h, h->plan[0], all, std::vector<bool>(ndim, false));
+    if (rc) return bail(rc);
+    rc = build_fast_plan(h);
     if (rc) return bail(rc);
   } else {
     if (axis_a >= ndim || axis_b < 0 || axis_b >= ndim || axis_a == axis_b)
@@ -1260,6 +1490,7 @@ int sdfs_create_continuous(int model, int ndim, const int64_t* shapes, const dou
     return fail(nullptr, SDFS_ERR_HIP, "no HIP device available (libsdfs_hip has no CPU fallback)");
   if (device_id < 0 || device_id >= ndev) return fail(nullptr, SDFS_ERR_ARG, "device_id %d out of range (%d devices)", device_id, ndev);
   sdfs_handle* h = new sdfs_handle();
+  h->knobs = read_knobs();
   memset(&h->counters, 0, sizeof h->counters);
   h->device = device_id;
   auto bail = [&](int rc) { g_create_error = h->err; sdfs_destroy(h); return rc; };
@@ -1331,7 +1562,7 @@ int sdfs_create_continuous(int model, int ndim, const int64_t* shapes, const dou
     for (int d = 0; d < ndim; ++d) pw *= c;
     if (pw == M) tq = c;
   }
-  if (tq && env_int("SDFS_CONT_NO_TENSOR", 0) == 0) {
+  if (tq && h->knobs.cont_no_tensor == 0) {
     long long st = 1;
     for (int d = 0; d < ndim && tq; ++d, st *= tq) {
       cd.tstride[d] = (int)st;
@@ -1360,7 +1591,7 @@ int sdfs_create_continuous(int model, int ndim, const int64_t* shapes, const dou
     vmax *= mext;
     if (d < ndim - 2) uomax *= mext;
   }
-  const int cap_limit = std::max(64, std::min(4000, env_int("SDFS_CONT_LDS_CAP", 4000)));   // doubles; 2 * cap * 8 < 64 KB
+  const int cap_limit = std::max(64, std::min(4000, h->knobs.cont_lds_cap));   // doubles; 2 * cap * 8 < 64 KB
   cd.cap = (int)std::min<long long>(vmax, cap_limit);
   cd.cap += cd.cap & 1;
   cd.tq = 0; cd.ucap = 0;
@@ -1385,6 +1616,7 @@ int sdfs_create_dense(int64_t N, const double* H, double beta, double theta, int
     return fail(nullptr, SDFS_ERR_HIP, "no HIP device available (libsdfs_hip has no CPU fallback)");
   if (device_id < 0 || device_id >= ndev) return fail(nullptr, SDFS_ERR_ARG, "device_id %d out of range (%d devices)", device_id, ndev);
   sdfs_handle* h = new sdfs_handle();
+  h->knobs = read_knobs();
   memset(&h->counters, 0, sizeof h->counters);
   h->device = device_id;
   auto bail = [&](int rc) { g_create_error = h->err; sdfs_destroy(h); return rc; };
@@ -1436,6 +1668,7 @@ void sdfs_destroy(sdfs_handle* h) {
   if (h->stream) hipStreamSynchronize(h->stream);
   if (h->sa_graph) hipGraphExecDestroy(h->sa_graph);
   for (double* p : h->dev_allocs) hipFree(p);
+  for (void* p : h->misc_allocs) hipFree(p);
   if (h->slots) hipFree(h->slots);
   if (h->slots_host) hipHostFree(h->slots_host);
   if (h->sc_host) hipHostFree(h->sc_host);
@@ -1635,7 +1868,7 @@ int sdfs_debug_pow(const double* x_host, double y, double* out_host, int64_t n, 
 int sdfs_describe_plan(const sdfs_handle* h, char* buf, int64_t cap) {
   if (!h || !buf || cap < 1) return SDFS_ERR_ARG;
   std::string s;
-  char line[256];
+  char line[384];
   if (h->dense) {
     snprintf(line, sizeof line, "dense single-index operator: N = %lld, one GEMV (8 N^2 = %.3g bytes) per application\n",
              h->N, 8.0 * (double)h->N * (double)h->N);
@@ -1645,6 +1878,24 @@ int sdfs_describe_plan(const sdfs_handle* h, char* buf, int64_t cap) {
     snprintf(line, sizeof line, "continuous operator: %d-D grid of %lld points x %d nodes, one 256-thread block per point, "
              "%d-corner multilinear gather + pow per node\n", h->cd.D, h->cd.N, h->cd.M, 1 << h->cd.D);
     s += line;
+  }
+  if (h->fast.ok) {
+    for (size_t i = 0; i < h->fast.passes.size(); ++i) {
+      const FastPass& P = h->fast.passes[i];
+      int occ = -1;
+      if (!P.line) {
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)slice_variant(P.n, S_TFIRST), 256, slice_lds_bytes(P.n));
+        const long long nt = (P.sd.nslices + slice_tile_slices(P.n) - 1) / slice_tile_slices(P.n);
+        snprintf(line, sizeof line, "pair plan pass %zu: %s lds %zu B block 256 (4 wave tiles) wave-tiles %lld blocks/CU %d\n", i,
+                 P.label.c_str(), slice_lds_bytes(P.n), nt, occ);
+      } else {
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)line_variant(P.n, L_MID), line_block(P.n), line_lds_bytes(P.n));
+        snprintf(line, sizeof line, "pair plan pass %zu: %s lds %zu B block %d tiles %lld (outer %lld x %d chunks of 128 B) blocks/CU %d\n", i,
+                 P.label.c_str(), line_lds_bytes(P.n), line_block(P.n), P.ld.ntiles, P.ld.nouter, P.ld.nchunks, occ);
+      }
+      s += line;
+    }
+    s += "generic plan (fp32 Krylov storage, sharded stages):\n";
   }
   for (int st = 0; st < 2; ++st) {
     const Plan& pl = h->plan[st];

@@ -14,8 +14,11 @@ the whole fixed-point loop on the device instead of calling back per iteration.
 All arithmetic happens in libsdfs_hip.so (hand-written HIP, gfx950); nothing here
 computes on the CPU.
 """
+import contextlib
 import ctypes as C
+import threading
 import weakref
+import zlib
 
 import numpy as np
 
@@ -25,6 +28,35 @@ from ._lib import lib, check
 
 def _as_f64(a):
     return np.ascontiguousarray(np.asarray(a, dtype=np.float64))
+
+
+# -- call tracing -----------------------------------------------------------------------------
+# The reference's drivers hand the solvers a plain closure, ``T = lambda w: T_ssy(w, shapes, params,
+# arrays)`` (ssy_wc_ratio.py:230, gcy_wc_ratio.py:333), and jax.jit / jax.jvp then see through it.
+# Here the solvers see through it by tracing: while a trace is open every operator application
+# records (operator, input object, output object), so ``solvers._resolve_operator`` can tell that a
+# foreign callable *is* one device operator applied to its argument and run the loop on the device.
+_trace = threading.local()
+
+
+@contextlib.contextmanager
+def trace_calls():
+    """Collects (operator, w_in, out) of every ``KoopmansOperator.__call__`` made in this thread while
+    the context is open (nested traces each see the calls made inside them)."""
+    stack = getattr(_trace, "stack", None)
+    if stack is None:
+        stack = _trace.stack = []
+    calls = []
+    stack.append(calls)
+    try:
+        yield calls
+    finally:
+        stack.pop()
+
+
+def _record_call(op, w_in, out):
+    for calls in getattr(_trace, "stack", None) or ():
+        calls.append((op, w_in, out))
 
 
 class KoopmansOperator:
@@ -74,9 +106,11 @@ class KoopmansOperator:
     # -- the reference's call shapes -----------------------------------------
     def __call__(self, w):
         """Tw = T(w); host ndarray in, new host ndarray out (inputs never mutated)."""
+        w_in = w
         w = self._host_in(w)
         out = np.empty_like(w)
         check(lib.sdfs_apply_T(self._h, w.ctypes.data, out.ctypes.data), self._h)
+        _record_call(self, w_in, out)
         return out
 
     def jvp(self, w, v):
@@ -171,17 +205,35 @@ _cache = {}
 _CACHE_MAX = 8
 
 
+def _fingerprint(a):
+    """Cheap content stamp of one model array: the reference's closure re-reads its arrays at every
+    call, so an array changed in place between two calls must not hit the cached device copy.  Small
+    arrays are hashed whole; the two big conditional tensors (25.6 MB at 20^6) by a strided sample
+    plus their sum."""
+    a = np.asarray(a)
+    flat = a.reshape(-1)
+    if flat.size <= 65536:
+        return (a.shape, zlib.crc32(np.ascontiguousarray(flat).view(np.uint8)))
+    step = flat.size // 4096
+    return (a.shape, zlib.crc32(np.ascontiguousarray(flat[::step]).view(np.uint8)), float(flat.sum()))
+
+
 def _cached(model, shapes, params, arrays):
     key = (model, tuple(int(s) for s in shapes), tuple(float(p) for p in params),
            tuple(id(a) for a in arrays))
-    op = _cache.get(key)
-    if op is None:
+    stamp = tuple(_fingerprint(a) for a in arrays)
+    hit = _cache.get(key)
+    if hit is not None and hit._stamp != stamp:       # same objects, new contents: rebuild
+        _cache.pop(key).close()
+        hit = None
+    if hit is None:
         if len(_cache) >= _CACHE_MAX:
             _cache.pop(next(iter(_cache))).close()
-        op = KoopmansOperator(model, shapes, params, arrays)
-        op._keepalive = list(arrays)     # the id()-based key stays valid while these live
-        _cache[key] = op
-    return op
+        hit = KoopmansOperator(model, shapes, params, arrays)
+        hit._keepalive = list(arrays)    # the id()-based key stays valid while these live
+        hit._stamp = stamp
+        _cache[key] = hit
+    return hit
 
 
 def T_ssy(w, shapes, params, arrays):

@@ -11,18 +11,90 @@ Fixed-point solvers with the reference's names, signatures, defaults and message
 When ``f`` is a ``KoopmansOperator`` the whole iteration runs on the GPU through
 ``sdfs_solve`` (device-resident iterates, fused residual reduction, hipGraph-replayed
 iteration chunks, on-device BiCGSTAB) and only the error trace comes back for
-printing.  Any other callable (for instance the reference-style closure
-``lambda w: T_ssy(w, shapes, params, arrays)``) is driven by the same loops on the
-host, one ``f(x)`` call per iteration, exactly as the reference does.
+printing.
+
+The reference's drivers do not pass an operator object but a closure,
+``T = lambda w: T_ssy(w, shapes, params, arrays)`` (ssy_wc_ratio.py:230,
+gcy_wc_ratio.py:333), and rely on jax.jit / jax.jvp seeing through it.  Here the solvers
+see through it by tracing one call (``_resolve_operator``): if ``f(x_init)`` turns out to be
+exactly one application of one device operator to ``x_init`` whose result is returned
+untouched, the loop runs on the device with that operator, and the same trace on the
+result confirms the equivalence before it is returned.  Anything else (a genuinely
+foreign callable) is driven by the same loops on the host, one ``f(x)`` call per
+iteration exactly as the reference does; Newton then uses ``f.jvp`` when the callable has
+one and a forward-difference directional derivative otherwise.
 """
 from textwrap import dedent
 
 import numpy as np
 
-from .operators import KoopmansOperator
+from .operators import KoopmansOperator, trace_calls
 
 default_tolerance = 1e-7
 default_max_iter = int(1e6)
+
+
+def _same_array(a, b):
+    if a is b:
+        return True
+    try:
+        a = np.asarray(a); b = np.asarray(b)
+        return a.shape == b.shape and np.array_equal(a, b)
+    except Exception:
+        return False
+
+
+def _traced_single_apply(f, x):
+    """Call f(x) under a trace.  Returns (y, op) where op is the device operator when the call
+    was exactly ``op(x)`` passed through unchanged, else None."""
+    with trace_calls() as calls:
+        y = f(x)
+    if len(calls) == 1:
+        op, w_in, out = calls[0]
+        if out is y and _same_array(w_in, x):
+            return y, op
+    return y, None
+
+
+def _resolve_operator(f, x_init):
+    """The device operator behind a callable, or None.  A ``KoopmansOperator`` is itself; a closure
+    over ``T_ssy`` / ``T_gcy`` / an operator object is recognised by tracing ``f(x_init)``."""
+    if isinstance(f, KoopmansOperator):
+        return f
+    try:
+        _, op = _traced_single_apply(f, x_init)
+    except Exception:
+        return None
+    return op
+
+
+def _confirm(f, op, x_star):
+    """After a device solve through a traced closure: f must still be that one operator at x_star."""
+    if f is op:
+        return True
+    _, op2 = _traced_single_apply(f, x_star)
+    return op2 is op
+
+
+def _on_device(f, x_init, algorithm, verbose, print_skip, max_iter, banner=False, **kw):
+    """Device-resident solve when ``f`` is (a closure over) a device operator.  Returns
+    (x, n) or None when f is foreign or failed the confirmation (the caller then runs its host loop)."""
+    op = _resolve_operator(f, x_init)
+    if op is None:
+        return None
+    if banner and verbose:
+        print("Beginning iteration\n\n")
+    x, n, info = op.solve(x_init, algorithm, record_errors=bool(verbose) and print_skip is not None,
+                          max_iter=int(max_iter), **kw)
+    if not _confirm(f, op, x):
+        print("Warning: the callable is not a pure closure over one device operator; "
+              "repeating the iteration on the host")
+        return None
+    if verbose and print_skip is not None:
+        for it in range(0, n, print_skip):
+            print("iter = {}, error = {}".format(it, info["errors"][it]))
+    _report(verbose, n, max_iter)
+    return x, n
 
 
 def _report(verbose, current_iter, max_iter):
@@ -37,14 +109,9 @@ def successive_approx(f, x_init, tol=default_tolerance, max_iter=default_max_ite
     "Uses successive approximation on f."
     if verbose:
         print("Beginning iteration\n\n")
-    if isinstance(f, KoopmansOperator):
-        x, n, info = f.solve(x_init, "successive_approx", record_errors=verbose, tol=tol,
-                             max_iter=int(max_iter), **device_opts)
-        if verbose:
-            for it in range(0, n, print_skip):
-                print("iter = {}, error = {}".format(it, info["errors"][it]))
-        _report(verbose, n, max_iter)
-        return x, n
+    done = _on_device(f, x_init, "successive_approx", verbose, print_skip, max_iter, tol=tol, **device_opts)
+    if done is not None:
+        return done
 
     current_iter = 0
     x = x_init
@@ -99,25 +166,31 @@ def newton_solver(f, x_init, tol=default_tolerance, max_iter=default_max_iter,
     BiCGSTAB for J(x)^{-1} g(x); the outer loop is successive approximation on
     q(x) = x - J(x)^{-1} g(x), as in the reference.
     """
-    if isinstance(f, KoopmansOperator):
-        if verbose:
-            print("Beginning iteration\n\n")
-        x, n, info = f.solve(x_init, "newton", record_errors=verbose, tol=tol,
-                             max_iter=int(max_iter), inner_atol=bicgstab_atol, **device_opts)
-        if verbose:
-            for it in range(0, n, print_skip):
-                print("iter = {}, error = {}".format(it, info["errors"][it]))
-        _report(verbose, n, max_iter)
-        return x, n
+    done = _on_device(f, x_init, "newton", verbose, print_skip, max_iter, banner=True, tol=tol,
+                      inner_atol=bicgstab_atol, **device_opts)
+    if done is not None:
+        return done
 
+    # foreign callable: the reference differentiates f with jax.jvp (code/solvers.py:87); here f.jvp when
+    # the callable brings one, else a forward difference along v (the usual Jacobian-free Newton-Krylov step)
     jvp = getattr(f, "jvp", None)
-    if jvp is None:
-        raise TypeError("newton_solver needs a KoopmansOperator or a callable with a "
-                        ".jvp(x, v) method (the reference differentiates f with jax.jvp)")
 
     def q(x):
-        gx = f(x) - x
-        return x - _host_bicgstab(lambda v: jvp(x, v) - v, gx, atol=bicgstab_atol)
+        x = np.asarray(x, dtype=np.float64)
+        fx = np.asarray(f(x), dtype=np.float64)
+        gx = fx - x
+        if jvp is not None:
+            mv = lambda v: np.asarray(jvp(x, v)) - v
+        else:
+            xn = float(np.linalg.norm(x.ravel()))
+
+            def mv(v):
+                vn = float(np.linalg.norm(v.ravel()))
+                if vn == 0.0:
+                    return np.zeros_like(v)
+                eps = np.sqrt(np.finfo(np.float64).eps) * (1.0 + xn) / vn
+                return (np.asarray(f(x + eps * v), dtype=np.float64) - fx) / eps - v
+        return x - _host_bicgstab(mv, gx, atol=bicgstab_atol)
 
     return successive_approx(q, x_init, tol, max_iter, verbose, print_skip)
 
@@ -127,11 +200,10 @@ def anderson_solver(f, x_init, tol=default_tolerance, max_iter=10000, verbose=Tr
     """Anderson acceleration with the reference's hard-coded jaxopt parameters
     (history 10, mixing frequency 4, beta 8, ridge 1e-6)."""
     m, mix, beta, ridge = 10, 4, 8.0, 1e-6
-    if isinstance(f, KoopmansOperator):
-        x, n, info = f.solve(x_init, "anderson", tol=tol, max_iter=int(max_iter),
-                             history=m, mixing_freq=mix, beta=beta, ridge=ridge, **device_opts)
-        _report(verbose, n, max_iter)
-        return x, n
+    done = _on_device(f, x_init, "anderson", verbose, None, max_iter, tol=tol,
+                      history=m, mixing_freq=mix, beta=beta, ridge=ridge, **device_opts)
+    if done is not None:
+        return done
 
     x_init = np.asarray(x_init, dtype=np.float64)
     shape = x_init.shape

@@ -1,0 +1,206 @@
+"""
+GPU parity tests of the pair plan (csrc/fast_kernels.hpp: slice_kernel + line_kernel), the kernels the
+headline grids (GCY 16^6, 20^6) run on.  Checked against
+ (1) the oracle (numpy restatement; the C twin at 6-D sizes) on the same seeded inputs,
+ (2) the generic-tile kernels on the same handle inputs (SDFS_PLAN=classic), an independent HIP route,
+ (3) solver-level behaviour: iteration counts, fixed points, the full-range power path.
+SDFS_PLAN is a create-time knob, so each operator is built under the environment it is meant for.
+Tolerance: 1e-12 relative per application (sums in a different order, powers within a few ulp).
+"""
+import contextlib
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+APPLY_RTOL = 1e-12
+
+
+@pytest.fixture(scope="module")
+def S():
+    import sdfs_via_autodiff_amd as S
+    return S
+
+
+@contextlib.contextmanager
+def plan_env(which):
+    old = os.environ.get("SDFS_PLAN")
+    os.environ["SDFS_PLAN"] = which
+    try:
+        yield
+    finally:
+        if old is None:
+            del os.environ["SDFS_PLAN"]
+        else:
+            os.environ["SDFS_PLAN"] = old
+
+
+def make_ops(S, model, shapes):
+    """(pair-plan operator, generic-plan operator, params, arrays)"""
+    if model == "ssy":
+        m = S.SSY(); arr = S.discretize_ssy(m, shapes)
+    else:
+        m = S.GCY(); arr = S.discretize_gcy(m, shapes)
+    with plan_env("pair"):
+        Tp = S.KoopmansOperator(model, shapes, m.params, arr)
+    with plan_env("classic"):
+        Tc = S.KoopmansOperator(model, shapes, m.params, arr)
+    assert "pair plan pass" in Tp.describe_plan(), Tp.describe_plan()
+    assert "pair plan pass" not in Tc.describe_plan()
+    return Tp, Tc, m.params, arr
+
+
+def oracle_ops(model, shapes):
+    from oracle import models, ssy, gcy
+    if model == "ssy":
+        p = models.ssy_params(); arr = ssy.discretize_ssy(p, shapes)
+        return (lambda w: ssy.T_ssy_factorised(w, shapes, p, arr),
+                lambda w, v: ssy.jvp_ssy(w, v, shapes, p, arr))
+    p = models.gcy_params(); arr = gcy.discretize_gcy(p, shapes)
+    return (lambda w: gcy.T_gcy_factorised(w, shapes, p, arr),
+            lambda w, v: gcy.jvp_gcy(w, v, shapes, p, arr))
+
+
+def wbench(shapes, seed=0):
+    return 400 + 500 * np.random.default_rng(seed).random(shapes)
+
+
+# every extent class of the kernels (16 / 20 / 24 / 32) as slice pair and as line pair
+SSY_SHAPES = [(16, 16, 16, 16), (20, 20, 20, 20), (24, 24, 24, 24), (32, 32, 32, 32),
+              (16, 16, 20, 20), (20, 20, 16, 16), (24, 24, 32, 32), (32, 32, 24, 24)]
+
+
+@pytest.mark.parametrize("shapes", SSY_SHAPES)
+def test_pair_plan_T_and_jvp_vs_oracle_4d(S, shapes):
+    Tp, Tc, _, _ = make_ops(S, "ssy", shapes)
+    oT, oJ = oracle_ops("ssy", shapes)
+    w = wbench(shapes)
+    want = oT(w)
+    got = Tp(w)
+    np.testing.assert_allclose(got, want, rtol=APPLY_RTOL)
+    r = np.max(np.abs(want - w))
+    assert abs(Tp.residual() - r) <= 1e-12 * r + 1e-9
+    np.testing.assert_allclose(got, Tc(w), rtol=APPLY_RTOL)            # independent HIP route
+    v = np.random.default_rng(1).standard_normal(shapes)
+    jw = oJ(w, v)
+    np.testing.assert_allclose(Tp.jvp(w, v), jw, rtol=1e-11, atol=1e-12 * np.max(np.abs(jw)))
+    np.testing.assert_array_equal(w, wbench(shapes))                    # inputs never mutated
+
+
+def test_pair_plan_not_chosen_where_it_is_illegal(S):
+    with plan_env("pair"):
+        for model, shapes in (("ssy", (15, 15, 15, 15)), ("ssy", (16, 16, 16, 20)), ("gcy", (6,) * 6)):
+            m = S.SSY() if model == "ssy" else S.GCY()
+            arr = (S.discretize_ssy if model == "ssy" else S.discretize_gcy)(m, shapes)
+            T = S.KoopmansOperator(model, shapes, m.params, arr)
+            assert "pair plan pass" not in T.describe_plan()
+        # conditional tensors whose slices differ keep the generic kernels
+        from oracle import models, ssy
+        shapes = (16, 16, 16, 16)
+        p = models.ssy_params(); arr = list(ssy.discretize_ssy(p, shapes))
+        q = np.random.default_rng(3).random(arr[7].shape) + 0.05
+        arr[7] = q / q.sum(axis=-1, keepdims=True)
+        T = S.ssy_operator(shapes, p, arr)
+        assert "pair plan pass" not in T.describe_plan()
+        w = wbench(shapes)
+        np.testing.assert_allclose(T(w), ssy.T_ssy_factorised(w, shapes, p, arr), rtol=APPLY_RTOL)
+
+
+def test_automatic_choice(S):
+    """Small 4-D grids have too few line tiles to fill the chip: generic kernels unless forced."""
+    os.environ.pop("SDFS_PLAN", None)
+    m = S.SSY(); shp = (20, 20, 20, 20)
+    T = S.ssy_operator(shp, m.params, S.discretize_ssy(m, shp))
+    assert "pair plan pass" not in T.describe_plan()
+    g = S.GCY(); shp = (16,) * 6
+    T = S.gcy_operator(shp, g.params, S.discretize_gcy(g, shp))
+    assert "pair plan pass" in T.describe_plan()
+
+
+@pytest.mark.parametrize("shapes", [(16,) * 6, (16, 16, 20, 20, 16, 16)])
+def test_pair_plan_gcy_6d_vs_c_oracle(S, shapes):
+    """Three passes (slices, middle lines, last lines with a3 index tables over four remainder axes)."""
+    from oracle.c_oracle import COperator
+    from oracle import models, gcy
+    Tp, Tc, _, _ = make_ops(S, "gcy", shapes)
+    p = models.gcy_params()
+    oc = COperator("gcy", shapes, p, gcy.discretize_gcy(p, shapes))
+    w = wbench(shapes)
+    want = oc(w)
+    got = Tp(w)
+    np.testing.assert_allclose(got, want, rtol=APPLY_RTOL)
+    r = np.max(np.abs(want - w))
+    assert abs(Tp.residual() - r) <= 1e-12 * r + 1e-9
+    v = np.random.default_rng(1).standard_normal(shapes)
+    jw = oc.jvp(w, v)
+    jp = Tp.jvp(w, v)
+    np.testing.assert_allclose(jp, jw, rtol=1e-11, atol=1e-12 * np.max(np.abs(jw)))
+    np.testing.assert_allclose(jp, Tc.jvp(w, v), rtol=1e-11, atol=1e-12 * np.max(np.abs(jw)))
+
+
+def test_pair_plan_full_range_power_path(S):
+    """w <= 0, NaN and huge values leave the straight-line power routine: the wave redoes its units with the
+    full routine and the results equal numpy's (NaN where the reference gives NaN, residual +inf)."""
+    shapes = (16, 16, 16, 16)
+    Tp, Tc, _, _ = make_ops(S, "ssy", shapes)
+    oT, _ = oracle_ops("ssy", shapes)
+    w = wbench(shapes)
+    w[3, 4, 5, 6] = -1.0            # negative base -> NaN in every point it reaches
+    w[0, 0, 0, 0] = 0.0             # 0^theta = inf (theta < 0)
+    w[9, 9, 9, 9] = 1e300           # y log2 x beyond the fast range: underflows to 0
+    with np.errstate(all="ignore"):
+        want = oT(w)
+    got = Tp(w)
+    assert np.array_equal(np.isnan(got), np.isnan(want))
+    ok = ~np.isnan(want)
+    np.testing.assert_allclose(got[ok], want[ok], rtol=APPLY_RTOL)
+    assert Tp.residual() == np.inf
+    gc = Tc(w)
+    assert np.array_equal(np.isnan(got), np.isnan(gc))
+    # tiny positive inputs (subnormal w^theta range is not reached, but w itself tiny is legal)
+    w2 = wbench(shapes) * 1e-3
+    np.testing.assert_allclose(Tp(w2), oT(w2), rtol=APPLY_RTOL)
+
+
+def test_pair_plan_solvers_match_generic_plan(S):
+    shapes = (16, 16, 16, 16)
+    Tp, Tc, _, _ = make_ops(S, "ssy", shapes)
+    w0 = np.full(shapes, 800.0)
+    xp, n_p, ip = Tp.solve(w0, "successive_approx", tol=1e-6, record_errors=True)
+    xc, n_c, ic = Tc.solve(w0, "successive_approx", tol=1e-6, record_errors=True)
+    assert n_p == n_c
+    np.testing.assert_allclose(ip["errors"], ic["errors"], rtol=1e-9, atol=1e-11)
+    np.testing.assert_allclose(xp, xc, rtol=0, atol=1e-9)
+    # Newton-Krylov (linearising T, J.v with the fused dots of the last line pass) and Anderson
+    xp, n_p, ip = Tp.solve(w0, "newton", tol=1e-10, inner_rtol=1e-8, inner_atol=0.0)
+    xc, n_c, ic = Tc.solve(w0, "newton", tol=1e-10, inner_rtol=1e-8, inner_atol=0.0)
+    assert n_p == n_c
+    np.testing.assert_allclose(xp, xc, rtol=0, atol=1e-8)
+    oT, oJ = oracle_ops("ssy", shapes)
+    from oracle import solvers as osol
+    xs = osol.newton_polish(oT, oJ, xp.copy())
+    assert np.max(np.abs(xp - xs)) < 1e-8
+    xa, n_a, _ = Tp.solve(w0, "anderson", tol=1e-7)
+    assert np.max(np.abs(xa - xs)) < 1e-5
+    # fp32 Krylov storage falls back to the generic kernels for the linearised part, same fixed point
+    xf, n_f, _ = Tp.solve(w0, "newton", tol=1e-10, inner_rtol=1e-8, inner_atol=0.0, krylov_f32=1)
+    assert np.max(np.abs(xf - xs)) < 1e-8
+
+
+def test_pair_plan_gcy16_newton_fixed_point(S):
+    """GCY 16^6 through the default (automatic) plan: Newton-Krylov to 1e-8, fixed point checked against the
+    C oracle: |T(x) - x| small on the full grid."""
+    from oracle.c_oracle import COperator
+    from oracle import models, gcy
+    os.environ.pop("SDFS_PLAN", None)
+    shapes = (16,) * 6
+    g = S.GCY()
+    T = S.gcy_operator(shapes, g.params, S.discretize_gcy(g, shapes))
+    assert "pair plan pass" in T.describe_plan()
+    x, n, info = T.solve(np.full(shapes, 800.0), "newton", tol=1e-8, inner_rtol=1e-6, inner_atol=0.0)
+    assert info["final_err"] <= 1e-8 and n < 25
+    p = models.gcy_params()
+    oc = COperator("gcy", shapes, p, gcy.discretize_gcy(p, shapes))
+    assert np.max(np.abs(oc(x) - x)) < 1e-8

@@ -27,6 +27,19 @@ __device__ __forceinline__ double fma_loop(int reps, double a, double b) {
   }
   return c0 + c1 + c2 + c3 + c4 + c5 + c6 + c7;
 }
+// 32 independent-ish integer VALU instructions per group (v_add_u32 / v_xor_b32 on 8 chains)
+__device__ __forceinline__ double int_loop(int reps, int a, int b) {
+  int c0 = a, c1 = b, c2 = a + 1, c3 = b + 1, c4 = a + 2, c5 = b + 2, c6 = a + 3, c7 = b + 3;
+  for (int i = 0; i < reps; ++i) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      asm volatile("v_add_u32 %0, %0, %8\n\tv_xor_b32 %1, %1, %9\n\tv_add_u32 %2, %2, %8\n\tv_xor_b32 %3, %3, %9\n\t"
+                   "v_add_u32 %4, %4, %8\n\tv_xor_b32 %5, %5, %9\n\tv_add_u32 %6, %6, %8\n\tv_xor_b32 %7, %7, %9"
+                   : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3), "+v"(c4), "+v"(c5), "+v"(c6), "+v"(c7) : "v"(a), "v"(b));
+    }
+  }
+  return (double)(c0 + c1 + c2 + c3 + c4 + c5 + c6 + c7);
+}
 __device__ __forceinline__ double mixed_loop(int reps, double a, double b) {
   v4d m0 = {0, 0, 0, 0}, m1 = {0, 0, 0, 0};
   double c0 = 0, c1 = 0, c2 = 0, c3 = 0, c4 = 0, c5 = 0, c6 = 0, c7 = 0;
@@ -56,6 +69,9 @@ __global__ void __launch_bounds__(512) probe(int mode, int reps, long long* cyc,
     r += fma_loop(reps, a, b);
   } else if (mode == 5) {
     r = mixed_loop(reps, a, b);
+  } else if (mode >= 6) {
+    if (((wave >> 2) & 1) == 0) { if (mode == 7) r = mfma_loop(reps, a, b); }
+    else r = int_loop(reps, threadIdx.x, threadIdx.x * 3 + 1);
   } else if (((wave >> 2) & 1) == 0) {
     if (mode & 1) r = mfma_loop(reps, a, b);
   } else {
@@ -71,8 +87,8 @@ int main() {
   const int blocks = 256, reps = 20000;
   long long* cyc; double* sink;
   hipMalloc(&cyc, blocks * sizeof(long long)); hipMalloc(&sink, blocks * 512 * sizeof(double));
-  const char* names[] = {"", "mfma only (waves 0-3)", "fma only (waves 4-7)", "mfma 0-3 + fma 4-7", "all waves: mfma then fma", "all waves: interleaved"};
-  for (int mode = 1; mode <= 5; ++mode) {
+  const char* names[] = {"", "mfma only (waves 0-3)", "fma only (waves 4-7)", "mfma 0-3 + fma 4-7", "all waves: mfma then fma", "all waves: interleaved", "int VALU only (waves 4-7)", "mfma 0-3 + int VALU 4-7"};
+  for (int mode = 1; mode <= 7; ++mode) {
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     probe<<<blocks, 512>>>(mode, 100, cyc, sink);
     hipDeviceSynchronize();
@@ -84,6 +100,6 @@ int main() {
     hipMemcpy(h.data(), cyc, blocks * sizeof(long long), hipMemcpyDeviceToHost);
     printf("mode %d %-28s  %8.3f ms   (memtime ticks block0 %lld)\n", mode, names[mode], ms, h[0]);
   }
-  printf("expected issue time per wave: mfma loop = reps*2*64 cycles, fma loop = reps*32*4 cycles (equal)\n");
+  printf("expected issue time per wave: mfma loop = reps*2*64 cycles, fma loop = reps*32*4 cycles (equal); int loop = reps*32 v_add/v_xor\n");
   return 0;
 }
