@@ -261,7 +261,8 @@ struct LineIO {
   unsigned long long* resid;
   const unsigned long long* gate;
   double gate_tol;
-  double* dotp;             // J.v with minus_identity: per-block partial sums <out, v>, <out, out>: [2][ntiles]
+  double* dotp;             // J.v with minus_identity: per-workgroup partial sums <out, v>, <out, out>: [2][gridDim.x]
+  unsigned* sched;          // persistent form: {next tile ticket, finished workgroups}, both zero between launches
 };
 
 template <int N> struct LineGeo {
@@ -274,15 +275,52 @@ template <int N> struct LineGeo {
   static_assert(N % W == 0, "column tiles split evenly over the waves");
 };
 
-template <int N, int MODE>
+// Per-tile addressing of a line tile: tile t -> (outer o, chunk); unit u = tid + k B sits in row u >> 3 at
+// double2 c2 = tid & 7; global byte offset = b0 + k * bstep against the tile's uniform base (X, Y adjacent
+// axes: row * lrest + position).
+struct LineTile {
+  long long tbase;          // element offset of the tile's first row, first double
+  unsigned o;
+  long long pos;            // this thread's position in the contiguous remainder behind Y
+  bool cok;                 // inside the remainder (a trailing chunk may be partial)
+};
+__device__ __forceinline__ LineTile line_tile(const LineDesc& P, unsigned t, int c2, int nn) {
+  LineTile T;
+  T.o = t / (unsigned)P.nchunks;
+  const int chunk = (int)(t - T.o * (unsigned)P.nchunks);
+  T.pos = (long long)chunk * LINE_R + 2 * c2;
+  T.cok = T.pos < P.lrest;
+  T.tbase = (long long)T.o * nn * P.lrest + (long long)chunk * LINE_R;
+  return T;
+}
+
+// Persistent: workgroup b starts on tile b and then draws tiles gridDim.x, gridDim.x + 1, ... from a ticket
+// counter (the host launches at most BPC workgroups per CU; 10000 tiles over 768 workgroups would otherwise
+// leave 752 of them idle during a fourteenth round).  The ticket for the tile after next is drawn by one lane
+// before the contractions and handed round through LDS behind their barriers; the last workgroup to leave
+// resets the two counters, so no memset sits between launches.  The epilogue of tile t -- in the last pass the long VALU phase, two powers per unit -- runs unit by
+// unit with a LOOK-unit window of global loads ahead of it: the unit's side streams (a3 and the residual's w,
+// or the J.v's c2 and v) and the same unit of tile t+1, which is parked in the LDS slot the unit has just
+// been read from.  So a workgroup has global requests in flight through every phase, the next tile is in
+// LDS when the epilogue ends, and nothing of it waits in registers (a whole prefetched tile, 52 VGPRs, next
+// to the power routine does not fit the 168 VGPRs of three workgroups per CU).  A thread's epilogue touches
+// only LDS slots it owns, so no barrier separates it from the parking.
+// PERSIST = false: one workgroup per tile (grid = ntiles, XCD-contiguous tile order), no look-ahead into a
+// next tile: the better form for the middle pass, whose epilogue is a plain store (measured: persistent
+// 0.24 ms vs 0.20 ms at GCY 20^6).
+// FULLC: the remainder behind Y is a multiple of 16 doubles, i.e. no tile has a partial chunk: loads need no
+// lane mask (a masked row of the last, partial unit reads unit 0's address instead) and the selects go away.
+template <int N, int MODE, bool PERSIST, bool FULLC>
 __global__ void __launch_bounds__(LineGeo<N>::B, LineGeo<N>::BPC * LineGeo<N>::B / 256)
 line_kernel(const LineDesc P, const LineIO io) {
   using Geo = LineGeo<N>;
   constexpr int B = Geo::B;
+  constexpr int EPT = Geo::EPT;
   constexpr bool CES = MODE == L_TLAST || MODE == L_TLAST_LIN;
   constexpr bool LINE = MODE == L_TLAST_LIN;
   constexpr bool MULE = MODE == L_JLAST;
   constexpr bool PARTIAL = Geo::UNITS % B != 0;
+  constexpr int LOOK = 4;                                         // units of look-ahead in the epilogue
   extern __shared__ double lds[];
   __shared__ double red[16];
   if (io.gate != nullptr) {
@@ -290,149 +328,182 @@ line_kernel(const LineDesc P, const LineIO io) {
     if (g <= (unsigned long long)__double_as_longlong(io.gate_tol)) return;
   }
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const unsigned t = (unsigned)xcd_remap((long long)blockIdx.x, P.ntiles);      // ntiles < 2^31 (host check)
-  const unsigned o = t / (unsigned)P.nchunks;
-  const int chunk = (int)(t - o * (unsigned)P.nchunks);
-  const int c2 = tid & 7;                                        // this thread's double2 inside the 16-double row
-  const long long pos = (long long)chunk * LINE_R + 2 * c2;     // position in the contiguous remainder
-  const bool cok = pos < P.lrest;                                // trailing partial chunk
-  // unit u = tid + k B: row = u >> 3 = (x, y), global offset = row * lrest + pos (X, Y adjacent axes)
-  // uniform 64-bit tile base + 32-bit byte offsets (the host checks that a tile spans < 4 GB)
-  const long long tbase = (long long)o * (N * N) * P.lrest + (long long)chunk * LINE_R;
-  const unsigned b0 = ((unsigned)(tid >> 3) * (unsigned)P.lrest + 2u * c2) * 8u;
-  const unsigned bstep = (unsigned)(B / 8) * (unsigned)P.lrest * 8u;
-  const char* const inb = reinterpret_cast<const char*>(io.in + tbase);
-  char* const outb = reinterpret_cast<char*>(io.out + tbase);
-  const char* const oldb = reinterpret_cast<const char*>(io.old + tbase);
-  const char* const auxb = reinterpret_cast<const char*>(io.aux_in + tbase);
-  char* const auxo = reinterpret_cast<char*>(io.aux_out + tbase);
-
-  double2 v[Geo::EPT];
-#pragma unroll
-  for (int k = 0; k < Geo::EPT; ++k) {
-    const bool ok = cok && (!PARTIAL || tid + k * B < Geo::UNITS);
-    v[k] = ok ? *reinterpret_cast<const double2*>(inb + (b0 + k * bstep)) : make_double2(0.0, 0.0);
-  }
-  QFrag<N> q;
-  q.load(P.Qx, lane);
-#pragma unroll
-  for (int k = 0; k < Geo::EPT; ++k)
-    if (!PARTIAL || tid + k * B < Geo::UNITS) *reinterpret_cast<double2*>(lds + 2 * (tid + k * B)) = v[k];
-  // the residual's w / the J.v's v: in flight across the contractions
-  constexpr bool EARLY_OLD = CES || MULE;
-  double2 oldv[EARLY_OLD ? Geo::EPT : 1];
-  const bool need_old = CES ? (io.resid != nullptr) : (MULE && P.minus_identity);
-  if (EARLY_OLD && need_old) {
-#pragma unroll
-    for (int k = 0; k < Geo::EPT; ++k) {
-      const bool ok = cok && (!PARTIAL || tid + k * B < Geo::UNITS);
-      oldv[EARLY_OLD ? k : 0] = ok ? *reinterpret_cast<const double2*>(oldb + (b0 + k * bstep)) : make_double2(0.0, 0.0);
-    }
-  }
-  __syncthreads();
-
   const int li = lane & 15, lk = lane >> 4;
-  // ---- contraction over X: column = (y, r) = LDS offset, row stride LX ---------------------------------
-  {
-    double* const p0 = lds + li + lk * Geo::LX;
-#pragma unroll
-    for (int j = 0; j < N / Geo::W; ++j) ctile<N, Geo::LX>(p0 + (wave + j * Geo::W) * 16, q);
-  }
-  q.load(P.Qy, lane);
-  __syncthreads();
-  // ---- contraction over Y: column = (x, r) at x * LX + r, row stride 16 --------------------------------
-  {
-    double* const p0 = lds + li + lk * LINE_R;
-#pragma unroll
-    for (int j = 0; j < N / Geo::W; ++j) ctile<N, LINE_R>(p0 + (wave + j * Geo::W) * Geo::LX, q);
-  }
-  __syncthreads();
+  const int c2 = tid & 7;                                        // this thread's double2 inside the 16-double row
+  const unsigned b0 = ((unsigned)(tid >> 3) * (unsigned)P.lrest + 2u * c2) * 8u;    // a tile spans < 4 GB (host check)
+  const unsigned bstep = (unsigned)(B / 8) * (unsigned)P.lrest * 8u;
+  const bool need_old = CES ? (io.resid != nullptr) : (MULE && P.minus_identity);
+  const unsigned ntiles = PERSIST ? (unsigned)P.ntiles : 0u, gstep = gridDim.x;
+  const char* const a3b = reinterpret_cast<const char*>(P.a3);
+  const unsigned a3x = (unsigned)P.a3x, a3y = (unsigned)P.a3y;   // < 2^24 (host check)
 
-  // ---- epilogue and store ---------------------------------------------------------------------------------
+  __shared__ unsigned next_tile[2];     // alternating slots: a slot is redrawn two tiles (six barriers) after its last read
+  int parity = 0;
+  unsigned t = PERSIST ? blockIdx.x : (unsigned)xcd_remap((long long)blockIdx.x, P.ntiles);   // gridDim.x <= ntiles
+  LineTile T = line_tile(P, t, c2, N * N);
+  {
+    // first tile: all loads in flight at once, then parked
+    double2 v[EPT];
+    const char* const inb = reinterpret_cast<const char*>(io.in + T.tbase);
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) {
+      const bool rowok = !PARTIAL || tid + k * B < Geo::UNITS;
+      if (FULLC) v[k] = *reinterpret_cast<const double2*>(inb + (rowok ? b0 + k * bstep : b0));
+      else v[k] = (T.cok && rowok) ? *reinterpret_cast<const double2*>(inb + (b0 + k * bstep)) : make_double2(0.0, 0.0);
+    }
+#pragma unroll
+    for (int k = 0; k < EPT; ++k)
+      if (!PARTIAL || tid + k * B < Geo::UNITS) *reinterpret_cast<double2*>(lds + 2 * (tid + k * B)) = v[k];
+  }
   double rmax = 0.0, dot_yv = 0.0, dot_yy = 0.0;
-  if (CES) {
-    const PowLane PT = pow_lane_init(lane);
-    // a3 index of this thread's two elements: outer part + remainder part (host tables), (x, y) part per unit
-    const unsigned ia3a = cok ? (unsigned)(P.out_idx[o] + P.rest_idx[pos]) : 0u;
-    const unsigned ia3b = cok ? (unsigned)(P.out_idx[o] + P.rest_idx[pos + 1]) : 0u;
-    const char* const a3b = reinterpret_cast<const char*>(P.a3);
-    // one unit of the aggregator: Tw = 1 + beta (a3 S)^(1/theta), c2 = beta u / S, |Tw - w|, store.
-    // FULL = false: the straight-line power (flags lanes it cannot serve); FULL = true: the full-range routine.
-    auto unit = [&](const int k, const double2 oldk, auto full_tag) -> bool {
-      constexpr bool FULL = decltype(full_tag)::value;
+  bool rnan = false;
+  PowLane PT;
+  if (CES) PT = pow_lane_init(lane);
+
+  for (;;) {
+    if (PERSIST && tid == 0)                                      // ticket of the tile after this one
+      next_tile[parity] = gstep + __hip_atomic_fetch_add(&io.sched[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    {
+      QFrag<N> q;
+      q.load(P.Qx, lane);
+      __syncthreads();
+      // ---- contraction over X: column = (y, r) = LDS offset, row stride LX -----------------------------
+      {
+        double* const p0 = lds + li + lk * Geo::LX;
+#pragma unroll
+        for (int j = 0; j < N / Geo::W; ++j) ctile<N, Geo::LX>(p0 + (wave + j * Geo::W) * 16, q);
+      }
+      q.load(P.Qy, lane);
+      __syncthreads();
+      // ---- contraction over Y: column = (x, r) at x * LX + r, row stride 16 ----------------------------
+      {
+        double* const p0 = lds + li + lk * LINE_R;
+#pragma unroll
+        for (int j = 0; j < N / Geo::W; ++j) ctile<N, LINE_R>(p0 + (wave + j * Geo::W) * Geo::LX, q);
+      }
+      __syncthreads();
+    }
+
+    const unsigned tn = PERSIST ? next_tile[parity] : 0u;        // written before the first of the three barriers above
+    const bool has_next = PERSIST && tn < ntiles;                // uniform over the workgroup
+    const LineTile Tn = line_tile(P, has_next ? tn : t, c2, N * N);
+    const bool cok = T.cok;
+    const char* const nxb = reinterpret_cast<const char*>(io.in + Tn.tbase);
+    const char* const oldb = reinterpret_cast<const char*>(io.old + T.tbase);
+    const char* const auxb = reinterpret_cast<const char*>(io.aux_in + T.tbase);
+    char* const outb = reinterpret_cast<char*>(io.out + T.tbase);
+    char* const auxo = reinterpret_cast<char*>(io.aux_out + T.tbase);
+    unsigned ia3a = 0u, ia3b = 0u;                               // a3 index of this thread's two elements, less (x, y)
+    if (CES && cok) {
+      ia3a = (unsigned)(P.out_idx[T.o] + P.rest_idx[T.pos]);
+      ia3b = (unsigned)(P.out_idx[T.o] + P.rest_idx[T.pos + 1]);
+    }
+
+    // ---- epilogue: unit k of tile t, with the loads of unit k + LOOK (and of tile t+1) ahead of it --------
+    double2 vw[LOOK], sw[LOOK], cw[LOOK];     // next tile's unit; side stream 1 (w / v); side stream 2 (a3 pair / c2)
+    auto issue = [&](const int k, double2& vn, double2& s1, double2& s2) {
+      const int u = tid + k * B;
+      const bool rowok = k < EPT && (!PARTIAL || u < Geo::UNITS);
+      const unsigned off = b0 + (unsigned)k * bstep;
+      if (FULLC) {
+        // every address of the tile is readable: masked rows read unit 0 (no exec branch, no zero fill)
+        const unsigned offc = rowok ? off : b0;
+        if (has_next) vn = *reinterpret_cast<const double2*>(nxb + offc);
+        if ((CES || MULE) && need_old) s1 = *reinterpret_cast<const double2*>(oldb + offc);
+        if (CES) {
+          const int row = rowok ? (u >> 3) : 0;
+          const int x = row / N, y = row - x * N;
+          const unsigned ixy = __umul24((unsigned)x, a3x) + __umul24((unsigned)y, a3y);
+          s2 = make_double2(*reinterpret_cast<const double*>(a3b + (ia3a + ixy) * 8u),
+                            *reinterpret_cast<const double*>(a3b + (ia3b + ixy) * 8u));
+        } else if (MULE) {
+          s2 = *reinterpret_cast<const double2*>(auxb + offc);
+        }
+        return;
+      }
+      vn = (has_next && rowok && Tn.cok) ? *reinterpret_cast<const double2*>(nxb + off) : make_double2(0.0, 0.0);
+      const bool ok = rowok && cok;
+      s1 = ((CES || MULE) && ok && need_old) ? *reinterpret_cast<const double2*>(oldb + off) : make_double2(0.0, 0.0);
+      if (CES) {
+        // unconditional gathers (index 0 when masked)
+        const int row = rowok ? (u >> 3) : 0;
+        const int x = row / N, y = row - x * N;
+        const unsigned ixy = __umul24((unsigned)x, a3x) + __umul24((unsigned)y, a3y);
+        s2 = make_double2(*reinterpret_cast<const double*>(a3b + (ok ? (ia3a + ixy) * 8u : 0u)),
+                          *reinterpret_cast<const double*>(a3b + (ok ? (ia3b + ixy) * 8u : 0u)));
+      } else if (MULE) {
+        s2 = ok ? *reinterpret_cast<const double2*>(auxb + off) : make_double2(0.0, 0.0);
+      }
+    };
+    auto unit = [&](const int k, const double2 vn, const double2 s1, const double2 s2) {
       const int u = tid + k * B;
       const bool rowok = !PARTIAL || u < Geo::UNITS;
-      const bool ok = cok && rowok;
-      const int row = rowok ? (u >> 3) : 0;
-      const int x = row / N, y = row - x * N;
-      const unsigned ixy = __umul24((unsigned)x, (unsigned)P.a3x) + __umul24((unsigned)y, (unsigned)P.a3y);   // strides < 2^24 (host check)
-      const double2 sv = rowok ? *reinterpret_cast<const double2*>(lds + 2 * u) : make_double2(1.0, 1.0);
-      double ks[2], uu[2], eh[2];
-      // unconditional gathers (index 0 when masked): no branch, so the loads of later units move up
-      const double k0 = *reinterpret_cast<const double*>(a3b + (ok ? (ia3a + ixy) * 8u : 0u));
-      const double k1 = *reinterpret_cast<const double*>(a3b + (ok ? (ia3b + ixy) * 8u : 0u));
-      ks[0] = ok ? k0 * sv.x : 1.0;
-      ks[1] = ok ? k1 * sv.y : 1.0;
-      bool rare = false;
-      if (FULL) { uu[0] = pow_full<false>(ks[0], P.inv_theta, PT); uu[1] = pow_full<false>(ks[1], P.inv_theta, PT); }
-      else rare = pow_fast_try<false, 2>(ks, P.inv_theta, PT, uu, eh);
-      const double2 y2 = make_double2(1.0 + P.beta * uu[0], 1.0 + P.beta * uu[1]);
-      if (ok) {
-        if (LINE) *reinterpret_cast<double2*>(auxo + (b0 + k * bstep)) =
-            make_double2(P.beta * uu[0] / sv.x, P.beta * uu[1] / sv.y);
-        if (need_old) {
-          double r0 = fabs(y2.x - oldk.x), r1 = fabs(y2.y - oldk.y);
-          if (!(r0 == r0)) r0 = __longlong_as_double(0x7ff0000000000000LL);   // NaN -> +inf
-          if (!(r1 == r1)) r1 = __longlong_as_double(0x7ff0000000000000LL);
-          rmax = fmax(rmax, fmax(r0, r1));
+      const bool ok = (FULLC || cok) && rowok;
+      const unsigned off = b0 + (unsigned)k * bstep;
+      double2* const slot = reinterpret_cast<double2*>(lds + 2 * (rowok ? u : tid));
+      const double2 sv = *slot;
+      if (CES) {
+        // Tw = 1 + beta (a3 S)^(1/theta), c2 = beta u / S, |Tw - w|.  Uniform trip: every lane runs the power
+        // (its table gathers need the whole wave); masked lanes feed it 1 (under FULLC: real values of the
+        // tile, whatever they are, the result is dropped).
+        const double ks[2] = {(FULLC || ok) ? s2.x * sv.x : 1.0, (FULLC || ok) ? s2.y * sv.y : 1.0};
+        double uu[2];
+        pow_fast_n<false, 2>(ks, P.inv_theta, PT, uu);
+        const double2 y2 = make_double2(1.0 + P.beta * uu[0], 1.0 + P.beta * uu[1]);
+        if (ok) {
+          if (LINE) *reinterpret_cast<double2*>(auxo + off) = make_double2(P.beta * uu[0] / sv.x, P.beta * uu[1] / sv.y);
+          if (need_old) {
+            // fmax drops NaNs: they are collected in a flag and turned into +inf after the last tile
+            const double r0 = fabs(y2.x - s1.x), r1 = fabs(y2.y - s1.y);
+            rnan |= (r0 != r0) | (r1 != r1);
+            rmax = fmax(rmax, fmax(r0, r1));
+          }
+          *reinterpret_cast<double2*>(outb + off) = y2;
         }
-        *reinterpret_cast<double2*>(outb + (b0 + k * bstep)) = y2;
-      }
-      return rare;
-    };
-    bool rare = false;
-#pragma unroll
-    for (int k = 0; k < Geo::EPT; ++k) rare |= unit(k, oldv[EARLY_OLD ? k : 0], std::false_type{});
-    // x <= 0, NaN, Inf, subnormal or out-of-range inputs anywhere in the wave: redo its units with the full
-    // routine (rolled, one copy; every lane stays active for the table gathers)
-    if (__builtin_expect(__builtin_amdgcn_ballot_w64(rare) != 0ULL, 0)) {
-      rmax = 0.0;
-#pragma unroll 1
-      for (int k = 0; k < Geo::EPT; ++k) {
-        const bool ok = cok && (!PARTIAL || tid + k * B < Geo::UNITS);
-        const double2 oldk = (ok && need_old) ? *reinterpret_cast<const double2*>(oldb + (b0 + k * bstep)) : make_double2(0.0, 0.0);
-        unit(k, oldk, std::true_type{});
-      }
-    }
-  } else {
-    double2 c2v[MULE ? Geo::EPT : 1];
-    if (MULE) {
-#pragma unroll
-      for (int k = 0; k < Geo::EPT; ++k) {
-        const bool ok = cok && (!PARTIAL || tid + k * B < Geo::UNITS);
-        c2v[MULE ? k : 0] = ok ? *reinterpret_cast<const double2*>(auxb + (b0 + k * bstep)) : make_double2(0.0, 0.0);
-      }
-    }
-#pragma unroll
-    for (int k = 0; k < Geo::EPT; ++k) {
-      const int u = tid + k * B;
-      const bool ok = cok && (!PARTIAL || u < Geo::UNITS);
-      if (ok) {
-        double2 y2 = *reinterpret_cast<const double2*>(lds + 2 * u);
+      } else if (ok) {
+        double2 y2 = sv;
         if (MULE) {
-          y2.x *= c2v[MULE ? k : 0].x; y2.y *= c2v[MULE ? k : 0].y;
+          y2.x *= s2.x; y2.y *= s2.y;
           if (P.minus_identity) {
-            const double2 ov = oldv[EARLY_OLD ? k : 0];
-            y2.x -= ov.x; y2.y -= ov.y;
-            dot_yv = fma(y2.x, ov.x, dot_yv); dot_yv = fma(y2.y, ov.y, dot_yv);
+            y2.x -= s1.x; y2.y -= s1.y;
+            dot_yv = fma(y2.x, s1.x, dot_yv); dot_yv = fma(y2.y, s1.y, dot_yv);
             dot_yy = fma(y2.x, y2.x, dot_yy); dot_yy = fma(y2.y, y2.y, dot_yy);
           }
         }
-        *reinterpret_cast<double2*>(outb + (b0 + k * bstep)) = y2;
+        *reinterpret_cast<double2*>(outb + off) = y2;
       }
+      if (has_next && rowok) *slot = vn;                         // park tile t+1's unit in the slot just read
+    };
+#pragma unroll
+    for (int j = 0; j < LOOK; ++j) issue(j, vw[j], sw[j], cw[j]);
+    int kk = 0;
+#pragma unroll 1
+    for (; kk + LOOK <= EPT; kk += LOOK) {
+#pragma unroll
+      for (int j = 0; j < LOOK; ++j) {
+        unit(kk + j, vw[j], sw[j], cw[j]);
+        issue(kk + j + LOOK, vw[j], sw[j], cw[j]);
+        __builtin_amdgcn_sched_barrier(0);                       // keep the window at LOOK units (register budget)
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < EPT % LOOK; ++j) unit(EPT - EPT % LOOK + j, vw[j], sw[j], cw[j]);
+
+    if (!has_next) break;
+    t = tn;
+    T = Tn;
+    parity ^= 1;
+  }
+  if (PERSIST && tid == 0) {
+    // last workgroup out clears the scheduler words for the next launch (kernel boundaries order the launches)
+    const unsigned d = __hip_atomic_fetch_add(&io.sched[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (d == gridDim.x - 1) {
+      __hip_atomic_store(&io.sched[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&io.sched[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
 
+  // per-workgroup reductions over all its tiles
   if (MULE && io.dotp != nullptr) {
 #pragma unroll
     for (int s = 32; s > 0; s >>= 1) { dot_yv += __shfl_xor(dot_yv, s); dot_yy += __shfl_xor(dot_yy, s); }
@@ -442,10 +513,11 @@ line_kernel(const LineDesc P, const LineIO io) {
       double a = 0.0, b = 0.0;
       for (int w = 0; w < Geo::W; ++w) { a += red[w]; b += red[8 + w]; }
       io.dotp[blockIdx.x] = a;
-      io.dotp[P.ntiles + blockIdx.x] = b;
+      io.dotp[gridDim.x + blockIdx.x] = b;
     }
   }
   if (CES && io.resid != nullptr) {
+    if (rnan) rmax = __longlong_as_double(0x7ff0000000000000LL);                // NaN -> +inf
 #pragma unroll
     for (int s = 32; s > 0; s >>= 1) rmax = fmax(rmax, __shfl_xor(rmax, s));
     if (lane == 0) red[wave] = rmax;
@@ -478,21 +550,26 @@ inline slice_fn slice_variant(int n, int mode) {
     default: return nullptr;
   }
 }
-template <int N> inline line_fn line_variant_n(int mode) {
+template <int N, bool PERSIST, bool FULLC> inline line_fn line_variant_n(int mode) {
   switch (mode) {
-    case L_MID: return (line_fn)line_kernel<N, L_MID>;
-    case L_TLAST: return (line_fn)line_kernel<N, L_TLAST>;
-    case L_TLAST_LIN: return (line_fn)line_kernel<N, L_TLAST_LIN>;
-    case L_JLAST: return (line_fn)line_kernel<N, L_JLAST>;
+    case L_MID: return (line_fn)line_kernel<N, L_MID, PERSIST, FULLC>;
+    case L_TLAST: return (line_fn)line_kernel<N, L_TLAST, PERSIST, FULLC>;
+    case L_TLAST_LIN: return (line_fn)line_kernel<N, L_TLAST_LIN, PERSIST, FULLC>;
+    case L_JLAST: return (line_fn)line_kernel<N, L_JLAST, PERSIST, FULLC>;
     default: return nullptr;
   }
 }
-inline line_fn line_variant(int n, int mode) {
+template <int N> inline line_fn line_variant_pf(int mode, bool persist, bool fullc) {
+  if (persist) return fullc ? line_variant_n<N, true, true>(mode) : line_variant_n<N, true, false>(mode);
+  return fullc ? line_variant_n<N, false, true>(mode) : line_variant_n<N, false, false>(mode);
+}
+// fullc: lrest % 16 == 0 (no partial chunk anywhere in the pass)
+inline line_fn line_variant(int n, int mode, bool persist, bool fullc) {
   switch (n) {
-    case 16: return line_variant_n<16>(mode);
-    case 20: return line_variant_n<20>(mode);
-    case 24: return line_variant_n<24>(mode);
-    case 32: return line_variant_n<32>(mode);
+    case 16: return line_variant_pf<16>(mode, persist, fullc);
+    case 20: return line_variant_pf<20>(mode, persist, fullc);
+    case 24: return line_variant_pf<24>(mode, persist, fullc);
+    case 32: return line_variant_pf<32>(mode, persist, fullc);
     default: return nullptr;
   }
 }
@@ -500,5 +577,6 @@ inline int slice_tile_slices(int n) { return n == 16 ? SliceGeo<16>::G : n == 20
 inline size_t slice_lds_bytes(int n) { return (size_t)slice_tile_slices(n) * n * n * 8 * 4; }
 inline int line_block(int n) { return n <= 20 ? 256 : 512; }
 inline size_t line_lds_bytes(int n) { return (size_t)n * n * LINE_R * 8; }
+inline int line_blocks_per_cu(int n) { return n <= 16 ? LineGeo<16>::BPC : n == 20 ? LineGeo<20>::BPC : n == 24 ? LineGeo<24>::BPC : LineGeo<32>::BPC; }
 
 }  // namespace sdfs

@@ -71,6 +71,7 @@ struct EventPair { hipEvent_t a, b; int counter; };
 // "pair plan" (fast_kernels.hpp): one slice pass over the two fastest axes, then one line pass per slower pair
 struct FastPass {
   bool line = false;
+  bool persist = false;        // line pass: persistent workgroups with look-ahead into the next tile
   int n = 0;
   int ax0 = -1, ax1 = -1;      // the contracted pair (ax0 slower)
   SliceDesc sd;
@@ -87,7 +88,8 @@ struct FastPlan {
 struct Knobs {
   int tile_budget = 0, filler_chunk = -1, force_waves = 0, no_occ_blocks = 0, no_pad = 0, no_vec2 = 0, no_vec4 = 0;
   int no_dot_fusion = 0, no_slice_merge = 0, cont_no_tensor = 0, cont_lds_cap = 4000;
-  int pair_order = 0;          // SDFS_PAIR_ORDER=1: line passes slowest pair first (the last pass then walks the faster pair)
+  int line_persist = 2;        // SDFS_LINE_PERSIST bit 0: middle line passes persistent, bit 1: last line pass persistent
+  int pair_order = 1;          // SDFS_PAIR_ORDER: 1 = line passes slowest pair first (the last pass then walks the faster pair), 0 = fastest first
   int plan = 0;                // SDFS_PLAN: 0 = automatic, 1 = "classic" (generic tiles only), 2 = "pair" (pair plan whenever legal)
   int ablate = 0;              // SDFS_ABLATE, honoured only by -DSDFS_DIAG builds
 };
@@ -114,6 +116,7 @@ struct sdfs_handle {
   // plans: [0] full grid (or stage 0 of a sharded run), [1] stage 1 of a sharded run
   Plan plan[2];
   FastPlan fast;                      // pair plan of the full grid, when the model admits it
+  unsigned* sched = nullptr;          // tile tickets of the persistent line pass (two words per pass, zero between launches)
   std::vector<void*> misc_allocs;     // device index tables of the pair plan
   bool sharded = false;
   int axis_a = -1, axis_b = -1;
@@ -214,7 +217,8 @@ Knobs read_knobs() {
   k.no_slice_merge = env_int("SDFS_NO_SLICE_MERGE", 0);
   k.cont_no_tensor = env_int("SDFS_CONT_NO_TENSOR", 0);
   k.cont_lds_cap = env_int("SDFS_CONT_LDS_CAP", 4000);
-  k.pair_order = env_int("SDFS_PAIR_ORDER", 0);
+  k.pair_order = env_int("SDFS_PAIR_ORDER", 1);
+  k.line_persist = env_int("SDFS_LINE_PERSIST", 2);
   const char* pl = getenv("SDFS_PLAN");
   if (pl && !strcmp(pl, "classic")) k.plan = 1;
   else if (pl && !strcmp(pl, "pair")) k.plan = 2;
@@ -745,15 +749,28 @@ int build_fast_plan(sdfs_handle* h) {
       slice_fn f = slice_variant(P.n, m);
       if (!f) return 0;
       hipFuncSetAttribute((const void*)f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)slice_lds_bytes(P.n));
-    } else for (int m = 0; m < L_NMODES; ++m) {
-      line_fn f = line_variant(P.n, m);
+    } else for (int m = 0; m < L_NMODES; ++m) for (int pe = 0; pe < 2; ++pe) {
+      line_fn f = line_variant(P.n, m, pe != 0, P.ld.lrest % LINE_R == 0);
       if (!f) return 0;
       hipFuncSetAttribute((const void*)f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)line_lds_bytes(P.n));
     }
   }
+  for (size_t i = 0; i < passes.size(); ++i)
+    if (passes[i].line) passes[i].persist = (h->knobs.line_persist >> (i + 1 == passes.size() ? 1 : 0)) & 1;
+  if (!h->sched) {
+    HIPCHK(h, hipMalloc((void**)&h->sched, 64));
+    h->misc_allocs.push_back(h->sched);
+    HIPCHK(h, hipMemset(h->sched, 0, 64));
+  }
   h->fast.passes = passes;
   h->fast.ok = true;
   return 0;
+}
+
+// persistent line kernel: at most its resident workgroups per CU, each walking tiles b, b + grid, ...
+unsigned line_grid(const sdfs_handle* h, const FastPass& P) {
+  if (!P.persist) return (unsigned)P.ld.ntiles;
+  return (unsigned)std::min<long long>(P.ld.ntiles, (long long)line_blocks_per_cu(P.n) * h->num_cus);
 }
 
 int run_fast_plan(sdfs_handle* h, int mode, const double* in, double* out, const double* old,
@@ -789,6 +806,7 @@ int run_fast_plan(sdfs_handle* h, int mode, const double* in, double* out, const
       LineIO io;
       memset(&io, 0, sizeof io);
       io.in = pin; io.out = pout; io.gate = gate; io.gate_tol = gate_tol;
+      io.sched = h->sched + 2 * i;
       LineDesc d = P.ld;
       d.minus_identity = minus_identity;
       int lm = L_MID;
@@ -797,11 +815,11 @@ int run_fast_plan(sdfs_handle* h, int mode, const double* in, double* out, const
         else if (mode == MODE_T_LIN) { lm = L_TLAST_LIN; io.old = old; io.resid = resid; io.aux_out = h->c2; bytes += n8; if (resid) bytes += n8; }
         else { lm = L_JLAST; io.aux_in = h->c2; io.old = old; bytes += n8; if (minus_identity) { bytes += n8; io.dotp = dotp; } }
       }
-      line_fn fn = line_variant(P.n, lm);
+      line_fn fn = line_variant(P.n, lm, P.persist, P.ld.lrest % LINE_R == 0);
       int cid = -1;
       if (h->profiling) { char nm[48]; snprintf(nm, sizeof nm, "%s:%s", tag, P.label.c_str()); cid = counter_id(h, nm, bytes, P.flops); }
       ProfScope ps(h, cid);
-      hipLaunchKernelGGL(fn, dim3((unsigned)d.ntiles), dim3(line_block(P.n)), line_lds_bytes(P.n), h->stream, d, io);
+      hipLaunchKernelGGL(fn, dim3(line_grid(h, P)), dim3(line_block(P.n)), line_lds_bytes(P.n), h->stream, d, io);
     }
     HIPCHK(h, hipGetLastError());
   }
@@ -811,7 +829,7 @@ int run_fast_plan(sdfs_handle* h, int mode, const double* in, double* out, const
 // tiles of the last pass of a J.v application (per-block partial sums of the fused dots)
 long long jvp_last_tiles(sdfs_handle* h) {
   if (h->cont || h->dense) return 0;
-  if (h->fast.ok && !h->krylov_f32) return h->fast.passes.back().ld.ntiles;
+  if (h->fast.ok && !h->krylov_f32) return line_grid(h, h->fast.passes.back());
   return h->plan[0].passes.empty() ? 0 : h->plan[0].passes.back().d.ntiles;
 }
 
@@ -1889,9 +1907,10 @@ int sdfs_describe_plan(const sdfs_handle* h, char* buf, int64_t cap) {
         snprintf(line, sizeof line, "pair plan pass %zu: %s lds %zu B block 256 (4 wave tiles) wave-tiles %lld blocks/CU %d\n", i,
                  P.label.c_str(), slice_lds_bytes(P.n), nt, occ);
       } else {
-        hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)line_variant(P.n, L_MID), line_block(P.n), line_lds_bytes(P.n));
-        snprintf(line, sizeof line, "pair plan pass %zu: %s lds %zu B block %d tiles %lld (outer %lld x %d chunks of 128 B) blocks/CU %d\n", i,
-                 P.label.c_str(), line_lds_bytes(P.n), line_block(P.n), P.ld.ntiles, P.ld.nouter, P.ld.nchunks, occ);
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)line_variant(P.n, L_MID, P.persist, P.ld.lrest % LINE_R == 0), line_block(P.n), line_lds_bytes(P.n));
+        snprintf(line, sizeof line, "pair plan pass %zu: %s lds %zu B block %d tiles %lld (outer %lld x %d chunks of 128 B) %s grid %u blocks/CU %d\n", i,
+                 P.label.c_str(), line_lds_bytes(P.n), line_block(P.n), P.ld.ntiles, P.ld.nouter, P.ld.nchunks,
+                 P.persist ? "persistent" : "one tile per workgroup", line_grid(h, P), occ);
       }
       s += line;
     }
