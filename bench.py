@@ -58,9 +58,12 @@ def cpu_baseline(model, shapes, params, arrays, w_host, budget_s=12.0):
         dt = time.perf_counter() - t0
         if dt > budget_s or n >= 50:
             break
+    # the port makes D axis sweeps and two power sweeps, each reading and writing the grid once (16 B / point)
+    sweep_bytes = 16.0 * (len(shapes) + 2) * float(np.prod(shapes))
     return {"value": n / dt, "unit": "iterations/s", "cores": num_threads(), "kind": "port",
             "sample": f"{n} applications of T on the same {'x'.join(map(str, shapes))} grid "
-                      f"(oracle/c/wc_oracle.c, factorised, OpenMP), {dt:.1f} s"}
+                      f"(oracle/c/wc_oracle.c, factorised, OpenMP), {dt:.1f} s",
+            "dram_GBps_of_its_own_sweeps": sweep_bytes * n / dt / 1e9}
 
 
 def spawn_ranks(n, backend):
@@ -163,13 +166,20 @@ def main():
     dom = max(counters, key=lambda c: c["total_ms"])
     avg_ms = dom["total_ms"] / max(dom["launches"], 1)
     achieved = dom["alg_bytes"] / (avg_ms * 1e-3) / 1e9
-    # HBM bytes per launch from the committed rocprofv3 PMC passes of this same command
-    # (profiles/: (2*FETCH_SIZE + WRITE_SIZE)*1024, gfx950 correction of MI355X_MICROARCH.md)
-    traffic = None
+    # HBM bytes per launch cannot be counted from inside this process (PMC counters need rocprofv3): the figure
+    # is taken from the committed PMC passes of this same command (profiles/: (2*FETCH_SIZE + WRITE_SIZE)*1024,
+    # gfx950 correction of MI355X_MICROARCH.md) and only if that profile was taken on the plan that ran here
+    traffic, traffic_source = None, "no committed PMC profile of this workload"
+    plan_now = op.describe_plan().strip().split("\n")
     try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", f"round1_{args.workload}_pmc.json")))
-        traffic = pmc["passes"][str(counters.index(dom))].get("hbm_traffic_bytes")
-    except (OSError, KeyError, ValueError):
+        pfile = os.path.join("profiles", f"round2_{args.workload}_pmc.json")
+        pmc = json.load(open(os.path.join(ROOT, pfile)))
+        if pmc.get("plan") != plan_now:
+            traffic_source = f"{pfile} was taken on a different kernel plan: dropped"
+        else:
+            traffic = pmc["kernels"][pmc["launch_order"][counters.index(dom)]]["hbm_traffic_bytes"]
+            traffic_source = f"{pfile} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, same plan)"
+    except (OSError, KeyError, ValueError, IndexError):
         pass
     kernels = [{"name": c["name"], "launches": c["launches"],
                 "avg_ms": c["total_ms"] / max(c["launches"], 1),
@@ -187,13 +197,15 @@ def main():
         "dtype": "f64", "data": "synthetic",
         "config": {"workload": f"{model.upper()} {'x'.join(map(str, shapes))} grid, successive-approximation "
                                f"step (T apply + fused sup-norm residual), default calibration, Rouwenhorst",
-                   "grid_points": N, "plan": op.describe_plan().strip().split("\n")},
+                   "grid_points": N, "plan": plan_now},
         "roofline": {"bound": "hbm", "kernel": dom["name"], "achieved": achieved, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                     "traffic_source": traffic_source,
                      "avg_launch_ms": avg_ms, "alg_bytes_per_launch": dom["alg_bytes"]},
-        # the kernels are fp64-pipe bound rather than HBM bound on this chip: fp64 MFMA and
-        # fp64 VALU share one datapath, 78.6 TFLOP/s.  Algorithmic flops = contraction MACs x 2 plus the
-        # two powers of the operator at the 31 fp64 instructions (~50 flops) the kernel spends on each.
+        # secondary bound: an fp64 MFMA holds its SIMD for its full 64 / 20 cycles and every VALU
+        # instruction of the same SIMD shares that issue slot, so a pass costs MFMA + VALU issue cycles; the
+        # nominal fp64 peak is 78.6 TFLOP/s.  Algorithmic flops = contraction MACs x 2 plus the two powers of
+        # the operator at the 31 fp64 instructions (~50 flops) the kernels spend on each.
         "fp64_pipe": {"peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                       "achieved": (sum(c["alg_flops"] for c in counters) + 2 * 50.0 * N) / (dt / args.steps) / 1e12,
                       "contraction_only": sum(c["alg_flops"] for c in counters) / (dt / args.steps) / 1e12},

@@ -70,6 +70,13 @@ static void contract_axis(const double* restrict x, double* restrict y, int D, c
   }
 }
 
+/* index of point p's row (its coordinates on all axes but the last) in a table with per-axis strides */
+static inline int64_t row_index(int64_t row, int D, const int64_t* n, const int64_t* ts) {
+  int64_t rem = row, idx = 0;
+  for (int a = D - 2; a >= 0; --a) { const int64_t c = rem % n[a]; rem /= n[a]; idx += c * ts[a]; }
+  return idx;
+}
+
 /*
  * Generic operator application.
  *   D, n[D]            grid
@@ -94,11 +101,15 @@ int wc_oracle_apply(int D, const int64_t* n, const int* order, const double* con
   const int npass = (mode == 1) ? 2 : 1;
   for (int pass = 0; pass < npass; ++pass) {
     /* pass 0: S = H0(a1 w^theta); pass 1 (jvp): dS = H0(a1 w^(theta-1) v) */
+    /* rows of the last axis: one index decode per row, not per point */
+    const int64_t nl = n[D - 1], nrows = N / nl;
 #pragma omp parallel for schedule(static)
-    for (int64_t p = 0; p < N; ++p) {
-      int64_t rem = p, i1 = 0;
-      for (int a = D - 1; a >= 0; --a) { const int64_t c = rem % n[a]; rem /= n[a]; i1 += c * a1s[a]; }
-      bufA[p] = (pass == 0) ? a1[i1] * pow(w[p], theta) : a1[i1] * pow(w[p], theta - 1.0) * v[p];
+    for (int64_t r = 0; r < nrows; ++r) {
+      const int64_t i1r = row_index(r, D, n, a1s);
+      for (int64_t j = 0; j < nl; ++j) {
+        const int64_t p = r * nl + j, i1 = i1r + j * a1s[D - 1];
+        bufA[p] = (pass == 0) ? a1[i1] * pow(w[p], theta) : a1[i1] * pow(w[p], theta - 1.0) * v[p];
+      }
     }
     double* src = bufA;
     double* dst = bufB;
@@ -114,19 +125,23 @@ int wc_oracle_apply(int D, const int64_t* n, const int* order, const double* con
       S = work + 2 * N;
       const double* dS = src;
 #pragma omp parallel for schedule(static)
-      for (int64_t p = 0; p < N; ++p) {
-        int64_t rem = p, i2 = 0, i3 = 0;
-        for (int a = D - 1; a >= 0; --a) { const int64_t c = rem % n[a]; rem /= n[a]; i2 += c * a2s[a]; i3 += c * a3s[a]; }
-        const double K = a2[i2] * a3[i3];
-        out[p] = beta * pow(K * S[p], 1.0 / theta - 1.0) * K * dS[p];
+      for (int64_t r = 0; r < nrows; ++r) {
+        const int64_t i2r = row_index(r, D, n, a2s), i3r = row_index(r, D, n, a3s);
+        for (int64_t j = 0; j < nl; ++j) {
+          const int64_t p = r * nl + j;
+          const double K = a2[i2r + j * a2s[D - 1]] * a3[i3r + j * a3s[D - 1]];
+          out[p] = beta * pow(K * S[p], 1.0 / theta - 1.0) * K * dS[p];
+        }
       }
     } else {
       const double* Sv = src;
 #pragma omp parallel for schedule(static)
-      for (int64_t p = 0; p < N; ++p) {
-        int64_t rem = p, i2 = 0, i3 = 0;
-        for (int a = D - 1; a >= 0; --a) { const int64_t c = rem % n[a]; rem /= n[a]; i2 += c * a2s[a]; i3 += c * a3s[a]; }
-        out[p] = 1.0 + beta * pow(a2[i2] * a3[i3] * Sv[p], 1.0 / theta);
+      for (int64_t r = 0; r < nrows; ++r) {
+        const int64_t i2r = row_index(r, D, n, a2s), i3r = row_index(r, D, n, a3s);
+        for (int64_t j = 0; j < nl; ++j) {
+          const int64_t p = r * nl + j;
+          out[p] = 1.0 + beta * pow(a2[i2r + j * a2s[D - 1]] * a3[i3r + j * a3s[D - 1]] * Sv[p], 1.0 / theta);
+        }
       }
     }
   }

@@ -88,7 +88,8 @@ struct FastPlan {
 struct Knobs {
   int tile_budget = 0, filler_chunk = -1, force_waves = 0, no_occ_blocks = 0, no_pad = 0, no_vec2 = 0, no_vec4 = 0;
   int no_dot_fusion = 0, no_slice_merge = 0, cont_no_tensor = 0, cont_lds_cap = 4000;
-  int line_persist = 2;        // SDFS_LINE_PERSIST bit 0: middle line passes persistent, bit 1: last line pass persistent
+  int line_persist = 0;        // SDFS_LINE_PERSIST bit 0: middle line passes persistent, bit 1: last line pass persistent
+                               // (measured equal to one tile per workgroup at GCY 20^6, tools/ab_plan.py: off by default)
   int pair_order = 1;          // SDFS_PAIR_ORDER: 1 = line passes slowest pair first (the last pass then walks the faster pair), 0 = fastest first
   int plan = 0;                // SDFS_PLAN: 0 = automatic, 1 = "classic" (generic tiles only), 2 = "pair" (pair plan whenever legal)
   int ablate = 0;              // SDFS_ABLATE, honoured only by -DSDFS_DIAG builds
@@ -218,7 +219,7 @@ Knobs read_knobs() {
   k.cont_no_tensor = env_int("SDFS_CONT_NO_TENSOR", 0);
   k.cont_lds_cap = env_int("SDFS_CONT_LDS_CAP", 4000);
   k.pair_order = env_int("SDFS_PAIR_ORDER", 1);
-  k.line_persist = env_int("SDFS_LINE_PERSIST", 2);
+  k.line_persist = env_int("SDFS_LINE_PERSIST", 0);
   const char* pl = getenv("SDFS_PLAN");
   if (pl && !strcmp(pl, "classic")) k.plan = 1;
   else if (pl && !strcmp(pl, "pair")) k.plan = 2;

@@ -10,8 +10,18 @@ per application, with A and B two axes no transition matrix is conditioned on
     stage 0   local   contract every axis but A on the A-sharded grid (prologue fused)
     exchange  RCCL    re-shard A -> B: each rank sends N/G * (G-1)/G doubles, N/G^2 per peer
     stage 1   local   contract A, aggregator fused, result B-sharded
-    exchange  RCCL    re-shard B -> A so iterates, residuals and Krylov vectors share one layout
     all-reduce        one double (MAX for the sup-norm step, SUM for inner products)
+
+MIRROR schedule (successive approximation): the next application starts from the B-sharded result
+with the roles of A and B swapped (a second pair of stage plans), so an iteration costs ONE
+exchange; the iterate alternates between the two layouts.  The reference's stopping quantity
+max|w_{k+1} - w_k| compares two consecutive iterates, which then live in different layouts;
+what is available without a second exchange is the two-step difference max|w_{k+1} - w_{k-1}|
+(fused into stage 1 against the iterate kept from two applications back).  The loop screens on
+that and finishes in the FIXED-layout form (second exchange B -> A per application, exact
+one-step error) once the screen gets within a factor of the tolerance -- the last ~2 % of the
+iterations at these models' contraction modulus (0.9988).  Krylov and Anderson vectors must
+share one layout across an operator application, so J.v and Anderson use the fixed-layout form.
 
 Local stages run through the C ABI (sdfs_create_sharded / sdfs_apply_stage_dev); the
 exchanges are torch.distributed all_to_all over RCCL ("nccl" backend) or point-to-point
@@ -20,6 +30,7 @@ pairs on gloo (CPU tests).  A stage backend is any object with
 the sharding algebra on CPU with world_size 2.
 """
 import ctypes as C
+import os
 import time
 
 import numpy as np
@@ -135,6 +146,25 @@ class ShardedKoopmans:
         self.local_shape = tuple(self.local_shape)
         self._use_a2a = dist.get_backend(group) == "nccl"
         self.n_exchanges = 0
+        # mirror orientation: input sharded on B, stage 0 contracts every axis but B, stage 1 contracts B and
+        # leaves the result sharded on A.  Needs A's own tensor to be unconditional (true for Rouwenhorst /
+        # Tauchen tensors, whose slices are identical); otherwise only the fixed-layout form is available.
+        self.backend_m = None
+        try:
+            if backend_factory is None:
+                self.backend_m = HipStages(model, shapes, params, arrays, self.axis_b, self.b_off[r], self.b_sizes[r],
+                                           self.axis_a, self.a_off[r], self.a_sizes[r], dev)
+            else:
+                self.backend_m = backend_factory(model, self.shapes, params, arrays, self.axis_b, self.b_off[r],
+                                                 self.b_sizes[r], self.axis_a, self.a_off[r], self.a_sizes[r])
+        except _lib.SdfsError:
+            self.backend_m = None
+        # every rank must agree (the legality test only looks at the model tensors, so it does)
+        flag = torch.tensor([1 if self.backend_m is not None else 0], dtype=torch.int32,
+                            device="cuda" if self._use_a2a else "cpu")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
+        if int(flag.item()) == 0:
+            self.backend_m = None
 
     # -- layout helpers -----------------------------------------------------------
     def scatter_from_full(self, w_full):
@@ -209,6 +239,24 @@ class ShardedKoopmans:
     def b_to_a(self, x):
         return self._reshard(x, self.axis_b, self.b_sizes, self.b_off, self.axis_a, self.a_sizes, self.a_off)
 
+    @property
+    def mirror_ok(self):
+        return self.backend_m is not None
+
+    def apply_mirror(self, w, orient, old=None):
+        """One application with ONE exchange.  orient 0: w sharded on A -> result sharded on B; orient 1 the
+        other way round.  `old`: an iterate in the OUTPUT layout (the one from two applications back); if given,
+        max|result - old| is fused into stage 1 and all-reduced.  Returns (result, residual tensor or None)."""
+        be = self.backend if orient == 0 else self.backend_m
+        y = be.run(0, MODE_T, w)
+        z = self.a_to_b(y) if orient == 0 else self.b_to_a(y)
+        if old is None:
+            return be.run(1, MODE_T, z), None
+        res = torch.zeros(1, dtype=torch.float64, device=w.device)
+        t = be.run(1, MODE_T, z, old=old, resid=res)
+        self.allreduce_max(res)
+        return t, res
+
     # -- operator -------------------------------------------------------------------
     def _apply(self, mode, x):
         y = self.backend.run(0, mode, x)
@@ -270,8 +318,36 @@ class ShardedKoopmans:
 # ---------------------------------------------------------------------------------------
 # distributed solvers (same stopping rules as code/solvers.py; see solvers.py for the
 # single-GPU device-resident versions)
-def successive_approx_sharded(op, w_loc, tol=1e-7, max_iter=1000000, errors=None):
-    it, err, w_b = 0, tol + 1, None
+SCREEN = 8.0      # mirror -> fixed-layout switch when max|w_{k+1} - w_{k-1}| <= SCREEN * tol
+
+
+def successive_approx_sharded(op, w_loc, tol=1e-7, max_iter=1000000, errors=None, mirror=True, stats=None):
+    """Successive approximation on a sharded grid, the reference's stopping rule (code/solvers.py:34-36).
+
+    Mirror phase (one exchange per iteration): the two-step difference is the screen; it bounds nothing by
+    itself, but with errors that shrink by less than a factor SCREEN/2 per iteration (contraction modulus
+    0.9988 here) it stays above SCREEN*tol for as long as the one-step error is above ~SCREEN/2*tol.  Exact
+    phase (two exchanges): the reference's loop verbatim.  `errors` receives the one-step error where it was
+    computed and the two-step screen (as a negative number) elsewhere."""
+    it, err = 0, tol + 1
+    if mirror and op.mirror_ok:
+        orient, prev, two = 0, None, None
+        w = w_loc
+        while it < max_iter:
+            w_next, res = op.apply_mirror(w, orient, old=prev)
+            it += 1
+            two = float(res.item()) if res is not None else None
+            if errors is not None:
+                errors.append(-two if two is not None else float("nan"))
+            prev, w, orient = w, w_next, 1 - orient
+            if two is not None and not (two > SCREEN * tol):       # also leaves on NaN / inf
+                break
+        if stats is not None:
+            stats["mirror_iters"] = it
+        w_loc = w if orient == 0 else op.b_to_a(w)                   # back to the A-sharded layout
+        if two is not None and not np.isfinite(two):
+            return w_loc, it
+    w_b = None
     while err > tol and it < max_iter:
         w_loc, res, w_b = op.apply_T_resid(w_loc, w_b)
         err = float(res.item())
@@ -349,16 +425,25 @@ def bench_sharded(S, model, shapes, params, arrays, args, rank, local_rank, worl
     w_full = torch.from_numpy(400 + 500 * np.random.default_rng(0).random(shapes))
     w = op.scatter_from_full(w_full).cuda()
     del w_full
-    state = {"w_b": None, "res": None}
+    state = {"w_b": None, "res": None, "prev": None, "orient": 0}
+    mirror = op.mirror_ok and os.environ.get("SDFS_BENCH_MIRROR", "1") != "0"
 
     def step(w):
+        if mirror:
+            # one exchange per iteration; residual = two-step difference, fused into stage 1 and all-reduced
+            w_new, res = op.apply_mirror(w, state["orient"], old=state["prev"])
+            state["prev"], state["orient"] = w, 1 - state["orient"]
+            if res is not None:
+                state["res"] = res
+            return w_new
         w_new, state["res"], state["w_b"] = op.apply_T_resid(w, state["w_b"])
         return w_new
 
     op.backend.set_profiling(True)
-    for _ in range(max(args.warmup, 1)):
+    for _ in range(max(args.warmup, 2)):
         w = step(w)
     op.backend.reset_counters()
+    x0 = op.n_exchanges
     dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -385,8 +470,11 @@ def bench_sharded(S, model, shapes, params, arrays, args, rank, local_rank, worl
         "dtype": "f64", "data": "synthetic",
         "config": {"workload": f"{model.upper()} {'x'.join(map(str, shapes))} grid, successive-approximation step "
                                f"(sharded T apply + all-reduced sup-norm residual), default calibration, Rouwenhorst",
-                   "grid_points": N, "parallelism": f"grid axis {op.axis_a} block-sharded over {world} ranks, "
-                                                    f"2 all-to-all re-shards + 1 all-reduce per iteration",
+                   "grid_points": N, "parallelism": f"grid block-sharded over {world} ranks (axes {op.axis_a} / {op.axis_b}, "
+                                                    f"{'mirror schedule' if mirror else 'fixed layout'}), "
+                                                    f"{(op.n_exchanges - x0) / max(args.steps, 1):.2f} all-to-all re-shards + 1 all-reduce "
+                                                    f"per iteration, backend {dist.get_backend()}",
+                   "ranks": world,
                    "shard_sizes": op.a_sizes,
                    "plan_rank0": op.backend.describe_plan().strip().split("\n")},
         "roofline": {"bound": "hbm", "kernel": dom["name"], "achieved": achieved, "peak": 8000.0, "unit": "GB/s",

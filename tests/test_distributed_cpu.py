@@ -25,10 +25,11 @@ def _free_port():
     return p
 
 
-def run_world2(model, shapes, backend, timeout=240, world=2):
+def run_world2(model, shapes, backend, timeout=240, world=2, plain=False):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
-           os.path.join(REPO, "tests", "sharded_worker.py"), model, ",".join(map(str, shapes)), backend]
+           os.path.join(REPO, "tests", "sharded_worker.py"), model, ",".join(map(str, shapes)), backend] + \
+          (["plain"] if plain else [])
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, cwd=REPO)
     lines = [l for l in r.stdout.splitlines() if l.startswith("RESULT ")]
     assert lines, f"no result (rc {r.returncode})\n{r.stdout[-2000:]}\n{r.stderr[-3000:]}"
@@ -56,6 +57,24 @@ def test_sharded_operator_world4_uneven_blocks():
     assert out["newton_err"] < 1e-8 and out["sa_iters"][0] == out["sa_iters"][1]
 
 
+@pytest.mark.parametrize("model,shapes,world", [("ssy", (4, 5, 3, 3), 2), ("gcy", (4, 2, 2, 5, 2, 3), 2),
+                                                ("gcy", (5, 2, 2, 6, 2, 3), 4)])
+def test_mirror_schedule_one_exchange_per_iteration(model, shapes, world):
+    """Unperturbed Rouwenhorst tensors: the mirror schedule (iterate alternating between the A- and the B-sharded
+    layout) runs successive approximation with ONE exchange per iteration, switches to the fixed-layout form for
+    the last iterations and stops on the reference's iteration with the reference's iterate."""
+    out = run_world2(model, shapes, "oracle", world=world, plain=True, timeout=400)
+    assert out["T"] < 1e-13 and out["Tlin"] < 1e-13 and out["jvp"] < 1e-12, out
+    assert out["mirror_ok"]
+    na, no = out["sa_iters"]
+    assert na == no and out["sa_err"] < 1e-9, out
+    m = out["sa_mirror_iters"]
+    assert m > 0.5 * na, out                                   # most iterations ran in mirror form
+    # mirror iterations: one exchange each; the switch back to layout A: at most one; exact iterations: two each
+    # (the first exact iteration re-shards w as well)
+    assert out["sa_exchanges"] <= m + 1 + 2 * (na - m) + 1, out
+
+
 def test_block_sizes():
     from sdfs_via_autodiff_amd.distributed import block_sizes, block_offsets
     assert block_sizes(20, 8) == [3, 3, 3, 3, 2, 2, 2, 2]
@@ -74,6 +93,21 @@ def test_sharded_hip_stages_world2(model, shapes):
     assert out["resid"] < 1e-8
     assert out["newton_err"] < 1e-8 and out["newton_iters"] < 20, out
     assert out["sa_iters"][0] == out["sa_iters"][1] and out["sa_err"] < 1e-8, out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("model,shapes", [("ssy", (5, 7, 6, 4)), ("gcy", (4, 3, 2, 5, 3, 6))])
+def test_sharded_hip_stages_plain_tensors_mirror(model, shapes):
+    """Default (slice-identical) tensors: the slice-merged stage plans (a3 as a table with block offsets) and the
+    mirror schedule on the real HIP stage kernels."""
+    out = run_world2(model, shapes, "hip", timeout=200, plain=True)
+    assert "newton_err" in out, out
+    assert out["T"] < 1e-12 and out["Tlin"] < 1e-12 and out["jvp"] < 1e-11, out
+    assert out["resid"] < 1e-8 and out["newton_err"] < 1e-8
+    assert out["mirror_ok"]
+    na, no = out["sa_iters"]
+    assert na == no and out["sa_err"] < 1e-8, out
+    assert out["sa_mirror_iters"] > 0.5 * na
 
 
 @pytest.mark.gpu

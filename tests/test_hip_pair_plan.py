@@ -140,6 +140,44 @@ def test_pair_plan_gcy_6d_vs_c_oracle(S, shapes):
     np.testing.assert_allclose(jp, Tc.jvp(w, v), rtol=1e-11, atol=1e-12 * np.max(np.abs(jw)))
 
 
+def test_persistent_line_kernel_variant(S):
+    """SDFS_LINE_PERSIST=3: the persistent form of the line kernel (ticket-scheduled tiles, next tile parked in
+    LDS during the epilogue).  Same numbers as one tile per workgroup, on T, the residual and the J.v dots path."""
+    shapes = (16, 16, 16, 16)
+    m = S.SSY(); arr = S.discretize_ssy(m, shapes)
+    with plan_env("pair"):
+        T0 = S.KoopmansOperator("ssy", shapes, m.params, arr)
+        os.environ["SDFS_LINE_PERSIST"] = "3"
+        try:
+            T3 = S.KoopmansOperator("ssy", shapes, m.params, arr)
+        finally:
+            del os.environ["SDFS_LINE_PERSIST"]
+    assert "persistent" in T3.describe_plan() and "persistent" not in T0.describe_plan()
+    w = wbench(shapes)
+    for _ in range(3):                      # the ticket counters must come back to zero after every launch
+        np.testing.assert_array_equal(T3(w), T0(w))
+        assert T3.residual() == T0.residual()
+    v = np.random.default_rng(1).standard_normal(shapes)
+    np.testing.assert_array_equal(T3.jvp(w, v), T0.jvp(w, v))
+    w0 = np.full(shapes, 800.0)
+    x3, n3, _ = T3.solve(w0, "newton", tol=1e-10, inner_rtol=1e-8, inner_atol=0.0)
+    x0, n0, _ = T0.solve(w0, "newton", tol=1e-10, inner_rtol=1e-8, inner_atol=0.0)
+    assert n3 == n0
+    np.testing.assert_allclose(x3, x0, rtol=0, atol=1e-9)
+    # 6-D: three passes, many tiles per persistent workgroup
+    g = S.GCY(); gs = (16,) * 6; garr = S.discretize_gcy(g, gs)
+    T0 = S.KoopmansOperator("gcy", gs, g.params, garr)
+    os.environ["SDFS_LINE_PERSIST"] = "3"
+    try:
+        T3 = S.KoopmansOperator("gcy", gs, g.params, garr)
+    finally:
+        del os.environ["SDFS_LINE_PERSIST"]
+    wg = wbench(gs)
+    for _ in range(2):
+        np.testing.assert_array_equal(T3(wg), T0(wg))
+        assert T3.residual() == T0.residual()
+
+
 def test_pair_plan_full_range_power_path(S):
     """w <= 0, NaN and huge values leave the straight-line power routine: the wave redoes its units with the
     full routine and the results equal numpy's (NaN where the reference gives NaN, residual +inf)."""

@@ -326,3 +326,43 @@ def test_header_is_plain_c_and_binds_from_c(tmp_path):
     r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(REPO, "include"),
                         "-c", str(src), "-o", str(tmp_path / "bind.o")], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
+
+
+def test_bench_gpus_flag_never_falls_back_to_one_gpu():
+    """`python bench.py --gpus N` without a launcher spawns its own ranks (as a child process) and must exit
+    non-zero -- never print an N = 1 line -- when fewer than N devices or ranks come up."""
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: covered by the rehearsal run")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode != 0 and "needs 2 devices" in r.stderr and '"metric"' not in r.stdout
+    # under a launcher whose world size disagrees with --gpus
+    env2 = dict(env, RANK="0", WORLD_SIZE="2", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29999")
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "4", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=300, env=env2)
+    assert r.returncode != 0 and "WORLD_SIZE 2" in r.stderr and '"metric"' not in r.stdout
+    # the spawn command line: one rank per GPU, rendezvous on 127.0.0.1, this script, the same arguments
+    sys.path.insert(0, REPO)
+    import bench
+    captured = {}
+
+    class R:
+        returncode = 7
+
+    def fake_run(cmd, env=None):
+        captured["cmd"], captured["env"] = cmd, env
+        return R()
+    old_run, old_cnt, old_argv = subprocess.run, torch.cuda.device_count, sys.argv
+    subprocess.run, torch.cuda.device_count, sys.argv = fake_run, (lambda: 8), ["bench.py", "--gpus", "4", "--steps", "3"]
+    try:
+        assert bench.spawn_ranks(4, "nccl") == 7
+    finally:
+        subprocess.run, torch.cuda.device_count, sys.argv = old_run, old_cnt, old_argv
+    cmd = captured["cmd"]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-4:] == ["--gpus", "4", "--steps", "3"]
+    assert captured["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"

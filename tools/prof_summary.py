@@ -94,6 +94,14 @@ for p_, d in out["passes"].items():
     if "FETCH_SIZE" in d and "WRITE_SIZE" in d:
         d["hbm_traffic_bytes"] = (2.0 * d["FETCH_SIZE"] + d["WRITE_SIZE"]) * 1024.0
         print(f"pass {p_}: HBM traffic per launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 = {d['hbm_traffic_bytes']/1e9:.3f} GB")
+# the plan the profiled bench ran on (bench.py compares it with its own before quoting these traffic figures)
+try:
+    for ln in open(os.path.join(root, "kt.log")):
+        if ln.startswith('{"metric"'):
+            out["plan"] = json.loads(ln)["config"]["plan"]
+            out["bench_line_of_kernel_trace_run"] = {k: v for k, v in json.loads(ln).items() if k in ("value", "ms_per_step", "kernels")}
+except OSError:
+    pass
 for nm, d in out["kernels"].items():
     if "FETCH_SIZE" in d and "WRITE_SIZE" in d:
         d["hbm_traffic_bytes"] = (2.0 * d["FETCH_SIZE"] + d["WRITE_SIZE"]) * 1024.0
