@@ -97,6 +97,19 @@ __device__ __forceinline__ void ctile(double* __restrict__ p, const QFrag<N>& q)
   for (int t = 0; t < S::N4; ++t) p[(16 * S::N16 + 4 * t) * RS] = d[t];
 }
 
+// fp32 storage of the linearisation (opts.krylov_f32, BASELINE config 5): c1 = w^(theta-1) is ~1e-50 and
+// c2 ~1e+50 at theta = -16 .. -36 -- outside fp32 -- while only their product matters.  Both are stored scaled
+// by an exact power of two taken from the point in the middle of the grid (c1 * 2^k, c2 * 2^-k,
+// k = -ilogb(w_mid^(theta-1)): the spread (w / w_mid)^(theta-1) then splits evenly over fp32's range); the
+// first pass reads w_mid from its input, the last pass from the grid it forms the residual against.
+__device__ __forceinline__ double lin_scale_of(double wref, double theta, const PowLane& PT, bool inverse) {
+  const double wr[1] = {wref};
+  double xr[1];
+  pow_fast_n<true, 1>(wr, theta, PT, xr);
+  const int k = -ilogb(xr[0] / wref);
+  return ldexp(1.0, inverse ? -k : k);
+}
+
 __device__ __forceinline__ void wave_lds_fence() {
   // LDS operations of one wave execute in issue order; this only keeps the compiler from moving
   // accesses of the wave-private region across a phase boundary
@@ -110,6 +123,7 @@ struct SliceDesc {
   const double* Qf;         // matrix of the fastest axis (n x n)
   const double* Qe;         // matrix of the second-fastest axis
   double theta;
+  long long ref_off;        // C-order offset of the mid-grid point (fp32 linearisation scale)
 };
 
 struct SliceIO {
@@ -128,16 +142,22 @@ template <int N> struct SliceGeo {
   static constexpr int EPT = (UNITS + 63) / 64;
   static constexpr int NCT = G * N / 16;                          // column tiles of either contraction
   static constexpr int WAVES = 4;
+  static constexpr int UNITS4 = TILE / 4;                         // float4 units (fp32 streams)
+  static constexpr int EPT4 = (UNITS4 + 63) / 64;
   static_assert((G * N) % 16 == 0, "whole column tiles");
 };
 
-template <int N, int MODE>
+// F32 (opts.krylov_f32): J.v -- every stream (v, c1, the result) holds floats, 16-byte units of four;
+// linearising T -- its own streams stay fp64, c1 is written as scaled floats.  Arithmetic stays fp64.
+template <int N, int MODE, bool F32>
 __global__ void __launch_bounds__(256, 3)
 slice_kernel(const SliceDesc P, const SliceIO io) {
   using Geo = SliceGeo<N>;
   constexpr bool POWP = MODE == S_TFIRST || MODE == S_TFIRST_LIN;
   constexpr bool LIN = MODE == S_TFIRST_LIN;
   constexpr bool MULP = MODE == S_JFIRST;
+  constexpr bool JV32 = F32 && MULP;
+  static_assert(!F32 || MODE != S_TFIRST, "plain T has no fp32 form");
   extern __shared__ double lds[];
   if (io.gate != nullptr) {
     const unsigned long long g = *io.gate;
@@ -148,45 +168,72 @@ slice_kernel(const SliceDesc P, const SliceIO io) {
   const long long tile = (long long)blockIdx.x * Geo::WAVES + wave;
   const long long s0 = tile * Geo::G;
   if (s0 >= P.nslices) return;                                   // no workgroup barrier below
-  const long long rem = (P.nslices - s0) * (N * N / 2);          // valid units of a trailing partial tile
+  const long long rem = (P.nslices - s0) * (N * N / 2);          // valid double2 units of a trailing partial tile
   const int nvalid = rem < Geo::UNITS ? (int)rem : Geo::UNITS;
   double* const wl = lds + wave * Geo::TILE;
   const long long gbase = s0 * (N * N);
-  // uniform 64-bit bases + one 32-bit byte offset per lane: global_load/store with an SGPR base
-  const char* const inb = reinterpret_cast<const char*>(io.in + gbase);
-  const char* const auxb = reinterpret_cast<const char*>(io.aux_in + gbase);
-  char* const outb = reinterpret_cast<char*>(io.out + gbase);
-  char* const auxo = reinterpret_cast<char*>(io.aux_out + gbase);
   const unsigned lb = (unsigned)lane * 16u;
 
-  // ---- loads (all in flight at once), Q fragments behind them --------------------------------------
-  double2 v[Geo::EPT];
-  double2 c1v[MULP ? Geo::EPT : 1];
+  if (JV32) {
+    // ---- fp32 streams: unit u = lane + 64 k holds elements 4u .. 4u+3 --------------------------------------
+    const int nvalid4 = nvalid / 2;
+    const char* const inb = reinterpret_cast<const char*>(reinterpret_cast<const float*>(io.in) + gbase);
+    const char* const auxb = reinterpret_cast<const char*>(reinterpret_cast<const float*>(io.aux_in) + gbase);
+    float4 v[Geo::EPT4], c1v[Geo::EPT4];
 #pragma unroll
-  for (int k = 0; k < Geo::EPT; ++k) {
-    const int u = lane + 64 * k;
-    if (u < nvalid) {
-      v[k] = *reinterpret_cast<const double2*>(inb + (lb + 1024u * k));
-      if (MULP) c1v[MULP ? k : 0] = *reinterpret_cast<const double2*>(auxb + (lb + 1024u * k));
-    } else {
-      v[k] = make_double2(1.0, 1.0);
-      if (MULP) c1v[MULP ? k : 0] = make_double2(0.0, 0.0);
+    for (int k = 0; k < Geo::EPT4; ++k) {
+      const int u = lane + 64 * k;
+      if (u < nvalid4) {
+        v[k] = *reinterpret_cast<const float4*>(inb + (lb + 1024u * k));
+        c1v[k] = *reinterpret_cast<const float4*>(auxb + (lb + 1024u * k));
+      } else {
+        v[k] = make_float4(0.f, 0.f, 0.f, 0.f); c1v[k] = v[k];
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < Geo::EPT4; ++k) {
+      const int u = lane + 64 * k;
+      if (Geo::UNITS4 % 64 == 0 || u < Geo::UNITS4) {
+        *reinterpret_cast<double2*>(wl + 4 * u) = make_double2((double)v[k].x * (double)c1v[k].x, (double)v[k].y * (double)c1v[k].y);
+        *reinterpret_cast<double2*>(wl + 4 * u + 2) = make_double2((double)v[k].z * (double)c1v[k].z, (double)v[k].w * (double)c1v[k].w);
+      }
+    }
+  } else {
+    // uniform 64-bit bases + one 32-bit byte offset per lane: global_load/store with an SGPR base
+    const char* const inb = reinterpret_cast<const char*>(io.in + gbase);
+    const char* const auxb = reinterpret_cast<const char*>(io.aux_in + gbase);
+    // ---- loads (all in flight at once) -----------------------------------------------------------------------
+    double2 v[Geo::EPT];
+    double2 c1v[MULP ? Geo::EPT : 1];
+#pragma unroll
+    for (int k = 0; k < Geo::EPT; ++k) {
+      const int u = lane + 64 * k;
+      if (u < nvalid) {
+        v[k] = *reinterpret_cast<const double2*>(inb + (lb + 1024u * k));
+        if (MULP) c1v[MULP ? k : 0] = *reinterpret_cast<const double2*>(auxb + (lb + 1024u * k));
+      } else {
+        v[k] = make_double2(1.0, 1.0);
+        if (MULP) c1v[MULP ? k : 0] = make_double2(0.0, 0.0);
+      }
+    }
+    // ---- park the tile in LDS (linear image of the global layout); J.v: x = c1 * v on the way ------------
+#pragma unroll
+    for (int k = 0; k < Geo::EPT; ++k) {
+      const int u = lane + 64 * k;
+      if (MULP) { v[k].x *= c1v[MULP ? k : 0].x; v[k].y *= c1v[MULP ? k : 0].y; }
+      if (Geo::UNITS % 64 == 0 || u < Geo::UNITS) *reinterpret_cast<double2*>(wl + 2 * u) = v[k];
     }
   }
   QFrag<N> qf;
   qf.load(P.Qf, lane);
-
-  // ---- park the tile in LDS (linear image of the global layout); J.v: x = c1 * v on the way ------------
-#pragma unroll
-  for (int k = 0; k < Geo::EPT; ++k) {
-    const int u = lane + 64 * k;
-    if (MULP) { v[k].x *= c1v[MULP ? k : 0].x; v[k].y *= c1v[MULP ? k : 0].y; }
-    if (Geo::UNITS % 64 == 0 || u < Geo::UNITS) *reinterpret_cast<double2*>(wl + 2 * u) = v[k];
-  }
   wave_lds_fence();
   // ---- prologue x = w^theta in place (rolled: one copy of the power routine; every lane stays active) --
   if (POWP) {
     const PowLane PT = pow_lane_init(lane);
+    double lin_scale = 1.0;
+    if (LIN && F32) lin_scale = lin_scale_of(io.in[P.ref_off], P.theta, PT, false);
+    char* const auxo = LIN ? (F32 ? reinterpret_cast<char*>(reinterpret_cast<float*>(io.aux_out) + gbase)
+                                  : reinterpret_cast<char*>(io.aux_out + gbase)) : nullptr;
 #pragma unroll 1
     for (int k = 0; k < Geo::EPT; ++k) {
       const int u = lane + 64 * k;
@@ -198,8 +245,11 @@ slice_kernel(const SliceDesc P, const SliceIO io) {
       pow_fast_n<true, 2>(xin, P.theta, PT, xw);
       if (in_tile) {
         *reinterpret_cast<double2*>(wl + lo) = make_double2(xw[0], xw[1]);
-        if (LIN && u < nvalid)                                    // c1 = w^(theta-1)
-          *reinterpret_cast<double2*>(auxo + (lb + 1024u * k)) = make_double2(xw[0] / xin[0], xw[1] / xin[1]);
+        if (LIN && u < nvalid) {                                  // c1 = w^(theta-1)
+          if (F32) *reinterpret_cast<float2*>(auxo + ((unsigned)lane * 8u + 512u * k)) =
+              make_float2((float)(xw[0] / xin[0] * lin_scale), (float)(xw[1] / xin[1] * lin_scale));
+          else *reinterpret_cast<double2*>(auxo + (lb + 1024u * k)) = make_double2(xw[0] / xin[0], xw[1] / xin[1]);
+        }
       }
     }
     wave_lds_fence();
@@ -226,10 +276,24 @@ slice_kernel(const SliceDesc P, const SliceIO io) {
   }
   wave_lds_fence();
   // ---- stream out -------------------------------------------------------------------------------------
+  if (JV32) {
+    const int nvalid4 = nvalid / 2;
+    char* const outb = reinterpret_cast<char*>(reinterpret_cast<float*>(io.out) + gbase);
 #pragma unroll
-  for (int k = 0; k < Geo::EPT; ++k) {
-    const int u = lane + 64 * k;
-    if (u < nvalid) *reinterpret_cast<double2*>(outb + (lb + 1024u * k)) = *reinterpret_cast<const double2*>(wl + 2 * u);
+    for (int k = 0; k < Geo::EPT4; ++k) {
+      const int u = lane + 64 * k;
+      if (u < nvalid4) {
+        const double2 a = *reinterpret_cast<const double2*>(wl + 4 * u), b = *reinterpret_cast<const double2*>(wl + 4 * u + 2);
+        *reinterpret_cast<float4*>(outb + (lb + 1024u * k)) = make_float4((float)a.x, (float)a.y, (float)b.x, (float)b.y);
+      }
+    }
+  } else {
+    char* const outb = reinterpret_cast<char*>(io.out + gbase);
+#pragma unroll
+    for (int k = 0; k < Geo::EPT; ++k) {
+      const int u = lane + 64 * k;
+      if (u < nvalid) *reinterpret_cast<double2*>(outb + (lb + 1024u * k)) = *reinterpret_cast<const double2*>(wl + 2 * u);
+    }
   }
 }
 
@@ -250,6 +314,7 @@ struct LineDesc {
   const int* rest_idx;
   int a3x, a3y;
   int minus_identity;
+  long long ref_off;        // C-order offset of the mid-grid point (fp32 linearisation scale)
 };
 
 struct LineIO {
@@ -272,6 +337,8 @@ template <int N> struct LineGeo {
   static constexpr int EPT = (UNITS + B - 1) / B;
   static constexpr int LX = N * LINE_R;                           // LDS stride of X (doubles); Y's is LINE_R
   static constexpr int BPC = N <= 16 ? 4 : (N == 20 ? 3 : (N == 24 ? 2 : 1));   // workgroups per CU (LDS)
+  static constexpr int UNITS4 = N * N * LINE_R / 4;               // float4 units per tile (fp32 streams)
+  static constexpr int EPT4 = (UNITS4 + B - 1) / B;
   static_assert(N % W == 0, "column tiles split evenly over the waves");
 };
 
@@ -310,12 +377,131 @@ __device__ __forceinline__ LineTile line_tile(const LineDesc& P, unsigned t, int
 // 0.24 ms vs 0.20 ms at GCY 20^6).
 // FULLC: the remainder behind Y is a multiple of 16 doubles, i.e. no tile has a partial chunk: loads need no
 // lane mask (a masked row of the last, partial unit reads unit 0's address instead) and the selects go away.
-template <int N, int MODE, bool PERSIST, bool FULLC>
+// F32 (opts.krylov_f32, needs FULLC): middle / last pass of J.v -- every stream holds floats, 16-byte units of
+// four, one tile per workgroup; last pass of a linearising T -- its own streams stay fp64, c2 is written as
+// scaled floats.  Arithmetic, LDS tile and reductions stay fp64.
+template <int N, int MODE, bool PERSIST, bool FULLC, bool F32>
 __global__ void __launch_bounds__(LineGeo<N>::B, LineGeo<N>::BPC * LineGeo<N>::B / 256)
 line_kernel(const LineDesc P, const LineIO io) {
   using Geo = LineGeo<N>;
   constexpr int B = Geo::B;
   constexpr int EPT = Geo::EPT;
+  static_assert(!F32 || (FULLC && !PERSIST && MODE != L_TLAST), "fp32 forms: whole chunks, one tile per workgroup");
+  if constexpr (F32 && (MODE == L_MID || MODE == L_JLAST)) {
+    constexpr bool MUL = MODE == L_JLAST;
+    constexpr int EPT4 = Geo::EPT4;
+    constexpr bool PART4 = Geo::UNITS4 % B != 0;
+    extern __shared__ double lds[];
+    __shared__ double red4[16];
+    if (io.gate != nullptr) {
+      const unsigned long long g = *io.gate;
+      if (g <= (unsigned long long)__double_as_longlong(io.gate_tol)) return;
+    }
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lk = lane >> 4;
+    const unsigned t = (unsigned)xcd_remap((long long)blockIdx.x, P.ntiles);
+    const unsigned o = t / (unsigned)P.nchunks;
+    const int chunk = (int)(t - o * (unsigned)P.nchunks);
+    const long long tbase = (long long)o * (N * N) * P.lrest + (long long)chunk * LINE_R;     // elements
+    // unit u = tid + k B: row u >> 2, float4 tid & 3 of its 16 elements; LDS doubles 4u .. 4u+3
+    const unsigned b0 = ((unsigned)(tid >> 2) * (unsigned)P.lrest + 4u * (tid & 3)) * 4u;
+    const unsigned bstep = (unsigned)(B / 4) * (unsigned)P.lrest * 4u;
+    const char* const inb = reinterpret_cast<const char*>(reinterpret_cast<const float*>(io.in) + tbase);
+    const char* const auxb = reinterpret_cast<const char*>(reinterpret_cast<const float*>(io.aux_in) + tbase);
+    const char* const oldb = reinterpret_cast<const char*>(reinterpret_cast<const float*>(io.old) + tbase);
+    char* const outb = reinterpret_cast<char*>(reinterpret_cast<float*>(io.out) + tbase);
+    const bool need_old = MUL && P.minus_identity;
+    float4 v[EPT4];
+#pragma unroll
+    for (int k = 0; k < EPT4; ++k) {
+      const bool rowok = !PART4 || tid + k * B < Geo::UNITS4;
+      v[k] = *reinterpret_cast<const float4*>(inb + (rowok ? b0 + k * bstep : b0));
+    }
+    QFrag<N> q;
+    q.load(P.Qx, lane);
+#pragma unroll
+    for (int k = 0; k < EPT4; ++k) {
+      const int u = tid + k * B;
+      if (!PART4 || u < Geo::UNITS4) {
+        *reinterpret_cast<double2*>(lds + 4 * u) = make_double2((double)v[k].x, (double)v[k].y);
+        *reinterpret_cast<double2*>(lds + 4 * u + 2) = make_double2((double)v[k].z, (double)v[k].w);
+      }
+    }
+    // side streams of the J.v epilogue: v travels across the contractions, c2 is fetched behind them (both
+    // at once, next to the Q fragments, do not fit the register budget of three workgroups per CU)
+    float4 c2v[MUL ? EPT4 : 1], oldv[MUL ? EPT4 : 1];
+    if (MUL && need_old) {
+#pragma unroll
+      for (int k = 0; k < EPT4; ++k) {
+        const bool rowok = !PART4 || tid + k * B < Geo::UNITS4;
+        oldv[MUL ? k : 0] = *reinterpret_cast<const float4*>(oldb + (rowok ? b0 + k * bstep : b0));
+      }
+    }
+    __syncthreads();
+    {
+      double* const p0 = lds + li + lk * Geo::LX;
+#pragma unroll
+      for (int j = 0; j < N / Geo::W; ++j) ctile<N, Geo::LX>(p0 + (wave + j * Geo::W) * 16, q);
+    }
+    q.load(P.Qy, lane);
+    __syncthreads();
+    {
+      double* const p0 = lds + li + lk * LINE_R;
+#pragma unroll
+      for (int j = 0; j < N / Geo::W; ++j) ctile<N, LINE_R>(p0 + (wave + j * Geo::W) * Geo::LX, q);
+    }
+    __syncthreads();
+    if (MUL) {
+#pragma unroll
+      for (int k = 0; k < EPT4; ++k) {
+        const bool rowok = !PART4 || tid + k * B < Geo::UNITS4;
+        c2v[MUL ? k : 0] = *reinterpret_cast<const float4*>(auxb + (rowok ? b0 + k * bstep : b0));
+      }
+    }
+    double dot_yv = 0.0, dot_yy = 0.0;
+#pragma unroll
+    for (int k = 0; k < EPT4; ++k) {
+      const int u = tid + k * B;
+      if (!PART4 || u < Geo::UNITS4) {
+        const double2 a = *reinterpret_cast<const double2*>(lds + 4 * u), b = *reinterpret_cast<const double2*>(lds + 4 * u + 2);
+        double y[4] = {a.x, a.y, b.x, b.y};
+        float yr[4];
+        if (MUL) {
+          const float4 c = c2v[MUL ? k : 0];
+          const float cc[4] = {c.x, c.y, c.z, c.w};
+          const float4 ov4 = need_old ? oldv[MUL ? k : 0] : make_float4(0.f, 0.f, 0.f, 0.f);
+          const float ov[4] = {ov4.x, ov4.y, ov4.z, ov4.w};
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            y[j] *= (double)cc[j];
+            if (need_old) {
+              y[j] -= (double)ov[j];
+              yr[j] = (float)y[j];                                // what gets stored is what the dots refer to
+              dot_yv = fma((double)yr[j], (double)ov[j], dot_yv);
+              dot_yy = fma((double)yr[j], (double)yr[j], dot_yy);
+            } else yr[j] = (float)y[j];
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) yr[j] = (float)y[j];
+        }
+        *reinterpret_cast<float4*>(outb + (b0 + k * bstep)) = make_float4(yr[0], yr[1], yr[2], yr[3]);
+      }
+    }
+    if (MUL && io.dotp != nullptr) {
+#pragma unroll
+      for (int s = 32; s > 0; s >>= 1) { dot_yv += __shfl_xor(dot_yv, s); dot_yy += __shfl_xor(dot_yy, s); }
+      if (lane == 0) { red4[wave] = dot_yv; red4[8 + wave] = dot_yy; }
+      __syncthreads();
+      if (tid == 0) {
+        double a = 0.0, b = 0.0;
+        for (int w = 0; w < Geo::W; ++w) { a += red4[w]; b += red4[8 + w]; }
+        io.dotp[blockIdx.x] = a;
+        io.dotp[gridDim.x + blockIdx.x] = b;
+      }
+    }
+    return;
+  }
   constexpr bool CES = MODE == L_TLAST || MODE == L_TLAST_LIN;
   constexpr bool LINE = MODE == L_TLAST_LIN;
   constexpr bool MULE = MODE == L_JLAST;
@@ -359,6 +545,8 @@ line_kernel(const LineDesc P, const LineIO io) {
   bool rnan = false;
   PowLane PT;
   if (CES) PT = pow_lane_init(lane);
+  double lin_scale = 1.0;                                        // fp32 c2 = beta u / S * 2^-k
+  if (LINE && F32) lin_scale = lin_scale_of(io.old[P.ref_off], 1.0 / P.inv_theta, PT, true);
 
   for (;;) {
     if (PERSIST && tid == 0)                                      // ticket of the tile after this one
@@ -393,6 +581,7 @@ line_kernel(const LineDesc P, const LineIO io) {
     const char* const auxb = reinterpret_cast<const char*>(io.aux_in + T.tbase);
     char* const outb = reinterpret_cast<char*>(io.out + T.tbase);
     char* const auxo = reinterpret_cast<char*>(io.aux_out + T.tbase);
+    char* const auxo32 = reinterpret_cast<char*>(reinterpret_cast<float*>(io.aux_out) + T.tbase);
     unsigned ia3a = 0u, ia3b = 0u;                               // a3 index of this thread's two elements, less (x, y)
     if (CES && cok) {
       ia3a = (unsigned)(P.out_idx[T.o] + P.rest_idx[T.pos]);
@@ -451,7 +640,11 @@ line_kernel(const LineDesc P, const LineIO io) {
         pow_fast_n<false, 2>(ks, P.inv_theta, PT, uu);
         const double2 y2 = make_double2(1.0 + P.beta * uu[0], 1.0 + P.beta * uu[1]);
         if (ok) {
-          if (LINE) *reinterpret_cast<double2*>(auxo + off) = make_double2(P.beta * uu[0] / sv.x, P.beta * uu[1] / sv.y);
+          if (LINE) {
+            if (F32) *reinterpret_cast<float2*>(auxo32 + (off >> 1)) =
+                make_float2((float)(P.beta * uu[0] / sv.x * lin_scale), (float)(P.beta * uu[1] / sv.y * lin_scale));
+            else *reinterpret_cast<double2*>(auxo + off) = make_double2(P.beta * uu[0] / sv.x, P.beta * uu[1] / sv.y);
+          }
           if (need_old) {
             // fmax drops NaNs: they are collected in a flag and turned into +inf after the last tile
             const double r0 = fabs(y2.x - s1.x), r1 = fabs(y2.y - s1.y);
@@ -533,43 +726,53 @@ line_kernel(const LineDesc P, const LineIO io) {
 typedef void (*slice_fn)(const SliceDesc, const SliceIO);
 typedef void (*line_fn)(const LineDesc, const LineIO);
 
-template <int N> inline slice_fn slice_variant_n(int mode) {
+template <int N> inline slice_fn slice_variant_n(int mode, bool f32) {
   switch (mode) {
-    case S_TFIRST: return (slice_fn)slice_kernel<N, S_TFIRST>;
-    case S_TFIRST_LIN: return (slice_fn)slice_kernel<N, S_TFIRST_LIN>;
-    case S_JFIRST: return (slice_fn)slice_kernel<N, S_JFIRST>;
+    case S_TFIRST: return f32 ? nullptr : (slice_fn)slice_kernel<N, S_TFIRST, false>;
+    case S_TFIRST_LIN: return f32 ? (slice_fn)slice_kernel<N, S_TFIRST_LIN, true> : (slice_fn)slice_kernel<N, S_TFIRST_LIN, false>;
+    case S_JFIRST: return f32 ? (slice_fn)slice_kernel<N, S_JFIRST, true> : (slice_fn)slice_kernel<N, S_JFIRST, false>;
     default: return nullptr;
   }
 }
-inline slice_fn slice_variant(int n, int mode) {
+// f32: fp32 storage of the J.v streams / of c1 (opts.krylov_f32)
+inline slice_fn slice_variant(int n, int mode, bool f32 = false) {
   switch (n) {
-    case 16: return slice_variant_n<16>(mode);
-    case 20: return slice_variant_n<20>(mode);
-    case 24: return slice_variant_n<24>(mode);
-    case 32: return slice_variant_n<32>(mode);
+    case 16: return slice_variant_n<16>(mode, f32);
+    case 20: return slice_variant_n<20>(mode, f32);
+    case 24: return slice_variant_n<24>(mode, f32);
+    case 32: return slice_variant_n<32>(mode, f32);
     default: return nullptr;
   }
 }
 template <int N, bool PERSIST, bool FULLC> inline line_fn line_variant_n(int mode) {
   switch (mode) {
-    case L_MID: return (line_fn)line_kernel<N, L_MID, PERSIST, FULLC>;
-    case L_TLAST: return (line_fn)line_kernel<N, L_TLAST, PERSIST, FULLC>;
-    case L_TLAST_LIN: return (line_fn)line_kernel<N, L_TLAST_LIN, PERSIST, FULLC>;
-    case L_JLAST: return (line_fn)line_kernel<N, L_JLAST, PERSIST, FULLC>;
+    case L_MID: return (line_fn)line_kernel<N, L_MID, PERSIST, FULLC, false>;
+    case L_TLAST: return (line_fn)line_kernel<N, L_TLAST, PERSIST, FULLC, false>;
+    case L_TLAST_LIN: return (line_fn)line_kernel<N, L_TLAST_LIN, PERSIST, FULLC, false>;
+    case L_JLAST: return (line_fn)line_kernel<N, L_JLAST, PERSIST, FULLC, false>;
     default: return nullptr;
   }
 }
-template <int N> inline line_fn line_variant_pf(int mode, bool persist, bool fullc) {
+template <int N> inline line_fn line_variant_f32(int mode) {
+  switch (mode) {
+    case L_MID: return (line_fn)line_kernel<N, L_MID, false, true, true>;
+    case L_TLAST_LIN: return (line_fn)line_kernel<N, L_TLAST_LIN, false, true, true>;
+    case L_JLAST: return (line_fn)line_kernel<N, L_JLAST, false, true, true>;
+    default: return nullptr;
+  }
+}
+template <int N> inline line_fn line_variant_pf(int mode, bool persist, bool fullc, bool f32) {
+  if (f32) return (fullc && !persist) ? line_variant_f32<N>(mode) : nullptr;
   if (persist) return fullc ? line_variant_n<N, true, true>(mode) : line_variant_n<N, true, false>(mode);
   return fullc ? line_variant_n<N, false, true>(mode) : line_variant_n<N, false, false>(mode);
 }
-// fullc: lrest % 16 == 0 (no partial chunk anywhere in the pass)
-inline line_fn line_variant(int n, int mode, bool persist, bool fullc) {
+// fullc: lrest % 16 == 0 (no partial chunk anywhere in the pass); f32: fp32 storage of the J.v streams / of c2
+inline line_fn line_variant(int n, int mode, bool persist, bool fullc, bool f32 = false) {
   switch (n) {
-    case 16: return line_variant_pf<16>(mode, persist, fullc);
-    case 20: return line_variant_pf<20>(mode, persist, fullc);
-    case 24: return line_variant_pf<24>(mode, persist, fullc);
-    case 32: return line_variant_pf<32>(mode, persist, fullc);
+    case 16: return line_variant_pf<16>(mode, persist, fullc, f32);
+    case 20: return line_variant_pf<20>(mode, persist, fullc, f32);
+    case 24: return line_variant_pf<24>(mode, persist, fullc, f32);
+    case 32: return line_variant_pf<32>(mode, persist, fullc, f32);
     default: return nullptr;
   }
 }

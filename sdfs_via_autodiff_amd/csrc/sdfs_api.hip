@@ -81,6 +81,7 @@ struct FastPass {
 };
 struct FastPlan {
   bool ok = false;
+  bool f32_ok = false;         // every line pass walks whole 16-element chunks: fp32 J.v forms exist
   std::vector<FastPass> passes;
 };
 
@@ -692,6 +693,7 @@ int build_fast_plan(sdfs_handle* h) {
     memset(&P.sd, 0, sizeof P.sd);
     P.sd.nslices = h->N / ((long long)n * n);
     P.sd.Qf = h->ax[D - 1].Q; P.sd.Qe = h->ax[D - 2].Q; P.sd.theta = h->theta;
+    for (int c = D - 1; c >= 0; --c) P.sd.ref_off += (long long)(h->shape[c] / 2) * stride[c];
     P.q_bytes = 2 * 8.0 * n * n; P.flops = 2.0 * (double)h->N * 2 * n;
     P.label = std::string("slices[") + h->ax[D - 2].name + "," + h->ax[D - 1].name + "|wave-private " +
               std::to_string(slice_tile_slices(n)) + "x" + std::to_string(n) + "x" + std::to_string(n) + "]";
@@ -716,6 +718,7 @@ int build_fast_plan(sdfs_handle* h) {
     L.Qx = h->ax[a].Q; L.Qy = h->ax[a + 1].Q;
     L.inv_theta = 1.0 / h->theta; L.beta = h->beta;
     L.a3x = h->ax[a].a3s; L.a3y = h->ax[a + 1].a3s;
+    for (int c = D - 1; c >= 0; --c) L.ref_off += (long long)(h->shape[c] / 2) * stride[c];
     min_tiles = std::min(min_tiles, L.ntiles);
     P.q_bytes = 2 * 8.0 * n * n; P.flops = 2.0 * (double)h->N * 2 * n;
     P.label = std::string("lines[") + h->ax[a].name + "," + h->ax[a + 1].name + "|" + std::to_string(n) + "x" +
@@ -750,12 +753,19 @@ int build_fast_plan(sdfs_handle* h) {
       slice_fn f = slice_variant(P.n, m);
       if (!f) return 0;
       hipFuncSetAttribute((const void*)f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)slice_lds_bytes(P.n));
+      slice_fn f32 = slice_variant(P.n, m, true);
+      if (f32) hipFuncSetAttribute((const void*)f32, hipFuncAttributeMaxDynamicSharedMemorySize, (int)slice_lds_bytes(P.n));
     } else for (int m = 0; m < L_NMODES; ++m) for (int pe = 0; pe < 2; ++pe) {
       line_fn f = line_variant(P.n, m, pe != 0, P.ld.lrest % LINE_R == 0);
       if (!f) return 0;
       hipFuncSetAttribute((const void*)f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)line_lds_bytes(P.n));
+      line_fn f32 = line_variant(P.n, m, false, true, true);
+      if (f32) hipFuncSetAttribute((const void*)f32, hipFuncAttributeMaxDynamicSharedMemorySize, (int)line_lds_bytes(P.n));
     }
   }
+  bool f32_ok = true;
+  for (const FastPass& P : passes) if (P.line && P.ld.lrest % LINE_R != 0) f32_ok = false;
+  h->fast.f32_ok = f32_ok;
   for (size_t i = 0; i < passes.size(); ++i)
     if (passes[i].line) passes[i].persist = (h->knobs.line_persist >> (i + 1 == passes.size() ? 1 : 0)) & 1;
   if (!h->sched) {
@@ -782,7 +792,10 @@ int run_fast_plan(sdfs_handle* h, int mode, const double* in, double* out, const
   if (mode != MODE_T) { rc = ensure_lin(h); if (rc) return rc; }
   const int np = (int)h->fast.passes.size();
   const double n8 = 8.0 * (double)h->N;
-  const char* tag = (mode == MODE_JVP) ? "jvp" : (mode == MODE_T_LIN ? "Tlin" : "T");
+  // fp32 Krylov storage: every stream of a J.v application holds floats; a linearising T keeps fp64 streams
+  // and writes only c1 (first pass) and c2 (last pass) as scaled floats
+  const bool f32 = h->krylov_f32 && mode != MODE_T;
+  const char* tag = (mode == MODE_JVP) ? (f32 ? "jvp32" : "jvp") : (mode == MODE_T_LIN ? "Tlin" : "T");
   for (int i = 0; i < np; ++i) {
     FastPass& P = h->fast.passes[i];
     const bool last = i == np - 1;
@@ -796,7 +809,8 @@ int run_fast_plan(sdfs_handle* h, int mode, const double* in, double* out, const
       int sm = S_TFIRST;
       if (mode == MODE_T_LIN) { sm = S_TFIRST_LIN; io.aux_out = h->c1; bytes += n8; }
       else if (mode == MODE_JVP) { sm = S_JFIRST; io.aux_in = h->c1; bytes += n8; }
-      slice_fn fn = slice_variant(P.n, sm);
+      slice_fn fn = slice_variant(P.n, sm, f32);
+      if (f32 && mode == MODE_JVP) bytes *= 0.5;
       int cid = -1;
       if (h->profiling) { char nm[48]; snprintf(nm, sizeof nm, "%s:%s", tag, P.label.c_str()); cid = counter_id(h, nm, bytes, P.flops); }
       const long long ntile = (P.sd.nslices + slice_tile_slices(P.n) - 1) / slice_tile_slices(P.n);
@@ -816,11 +830,14 @@ int run_fast_plan(sdfs_handle* h, int mode, const double* in, double* out, const
         else if (mode == MODE_T_LIN) { lm = L_TLAST_LIN; io.old = old; io.resid = resid; io.aux_out = h->c2; bytes += n8; if (resid) bytes += n8; }
         else { lm = L_JLAST; io.aux_in = h->c2; io.old = old; bytes += n8; if (minus_identity) { bytes += n8; io.dotp = dotp; } }
       }
-      line_fn fn = line_variant(P.n, lm, P.persist, P.ld.lrest % LINE_R == 0);
+      const bool lf32 = f32 && (mode == MODE_JVP || lm == L_TLAST_LIN);
+      line_fn fn = lf32 ? line_variant(P.n, lm, false, true, true) : line_variant(P.n, lm, P.persist, P.ld.lrest % LINE_R == 0);
+      if (!fn) return fail(h, SDFS_ERR_UNSUPPORTED, "no line kernel variant");
+      if (f32 && mode == MODE_JVP) bytes *= 0.5;
       int cid = -1;
       if (h->profiling) { char nm[48]; snprintf(nm, sizeof nm, "%s:%s", tag, P.label.c_str()); cid = counter_id(h, nm, bytes, P.flops); }
       ProfScope ps(h, cid);
-      hipLaunchKernelGGL(fn, dim3(line_grid(h, P)), dim3(line_block(P.n)), line_lds_bytes(P.n), h->stream, d, io);
+      hipLaunchKernelGGL(fn, dim3(lf32 ? (unsigned)d.ntiles : line_grid(h, P)), dim3(line_block(P.n)), line_lds_bytes(P.n), h->stream, d, io);
     }
     HIPCHK(h, hipGetLastError());
   }
@@ -830,6 +847,7 @@ int run_fast_plan(sdfs_handle* h, int mode, const double* in, double* out, const
 // tiles of the last pass of a J.v application (per-block partial sums of the fused dots)
 long long jvp_last_tiles(sdfs_handle* h) {
   if (h->cont || h->dense) return 0;
+  if (h->fast.ok && h->krylov_f32 && h->fast.f32_ok) return h->fast.passes.back().ld.ntiles;
   if (h->fast.ok && !h->krylov_f32) return line_grid(h, h->fast.passes.back());
   return h->plan[0].passes.empty() ? 0 : h->plan[0].passes.back().d.ntiles;
 }
@@ -839,9 +857,9 @@ int run_plan(sdfs_handle* h, Plan& plan, int mode, bool has_first, bool has_last
              const unsigned long long* gate, double gate_tol, int minus_identity, double* dotp = nullptr) {
   if (h->cont) return run_cont(h, mode, in, out, old, resid, gate, gate_tol, minus_identity);
   if (h->dense) return run_dense(h, mode, in, out, old, resid, gate, gate_tol, minus_identity);
-  // the pair plan serves the whole-grid operator in fp64; fp32 Krylov storage (and its linearisation, which
-  // writes c1 / c2 as scaled fp32) stays on the generic kernels
-  if (h->fast.ok && &plan == &h->plan[0] && has_first && has_last && !(h->krylov_f32 && mode != MODE_T))
+  // the pair plan serves the whole-grid operator; its fp32-storage forms need whole 16-element chunks in
+  // every line pass, otherwise fp32 Krylov storage (and its linearisation) stays on the generic kernels
+  if (h->fast.ok && &plan == &h->plan[0] && has_first && has_last && !(h->krylov_f32 && mode != MODE_T && !h->fast.f32_ok))
     return run_fast_plan(h, mode, in, out, old, resid, gate, gate_tol, minus_identity, dotp);
   int rc = ensure_tmp(h);
   if (rc) return rc;
@@ -1040,7 +1058,7 @@ int bicgstab_dev_t(sdfs_handle* h, const sdfs_opts& o, int64_t* matvecs) {
     // <t, s> and <t, t> come out of the last J.v pass when its tiles fit the partial-sum buffer
     const long long last_tiles = jvp_last_tiles(h);
     const bool fused_dots = last_tiles > 0 && 2 * last_tiles <= (long long)MAX_PARTIAL_BLOCKS * AND_MAX_M &&
-                            (h->plan[0].passes.size() > 1 || (h->fast.ok && !h->krylov_f32)) && h->knobs.no_dot_fusion == 0;
+                            (h->plan[0].passes.size() > 1 || (h->fast.ok && (!h->krylov_f32 || h->fast.f32_ok))) && h->knobs.no_dot_fusion == 0;
     if ((rc = run_plan(h, h->plan[0], MODE_JVP, true, true, (const double*)r, (double*)t, (const double*)r, nullptr, nullptr, 0.0, 1,
                        fused_dots ? h->partial : nullptr))) return rc;
     { ProfScope ps(h, cvec);

@@ -19,8 +19,8 @@ max|w_{k+1} - w_k| compares two consecutive iterates, which then live in differe
 what is available without a second exchange is the two-step difference max|w_{k+1} - w_{k-1}|
 (fused into stage 1 against the iterate kept from two applications back).  The loop screens on
 that and finishes in the FIXED-layout form (second exchange B -> A per application, exact
-one-step error) once the screen gets within a factor of the tolerance -- the last ~2 % of the
-iterations at these models' contraction modulus (0.9988).  Krylov and Anderson vectors must
+one-step error) once the screen gets within a factor 2.5 of the tolerance -- the last ~190
+iterations (1-2 % of a solve to 1e-8) at these models' contraction modulus (0.9988).  Krylov and Anderson vectors must
 share one layout across an operator application, so J.v and Anderson use the fixed-layout form.
 
 Local stages run through the C ABI (sdfs_create_sharded / sdfs_apply_stage_dev); the
@@ -318,16 +318,20 @@ class ShardedKoopmans:
 # ---------------------------------------------------------------------------------------
 # distributed solvers (same stopping rules as code/solvers.py; see solvers.py for the
 # single-GPU device-resident versions)
-SCREEN = 8.0      # mirror -> fixed-layout switch when max|w_{k+1} - w_{k-1}| <= SCREEN * tol
+# mirror -> fixed-layout switch when max|w_{k+1} - w_{k-1}| <= SCREEN * tol.  With one-step errors shrinking by a
+# factor rho per iteration the two-step difference is (1 + 1/rho) times the one-step error, so the switch happens at
+# a one-step error of SCREEN / (1 + 1/rho) * tol: above tol (no overshoot) for every rho > 2/3; the exact phase
+# then lasts ln(SCREEN / 2) / ln(1 / rho) iterations (~190 at rho = 0.9988, ~1-2 % of a solve to 1e-8).
+SCREEN = 2.5
 
 
 def successive_approx_sharded(op, w_loc, tol=1e-7, max_iter=1000000, errors=None, mirror=True, stats=None):
     """Successive approximation on a sharded grid, the reference's stopping rule (code/solvers.py:34-36).
 
-    Mirror phase (one exchange per iteration): the two-step difference is the screen; it bounds nothing by
-    itself, but with errors that shrink by less than a factor SCREEN/2 per iteration (contraction modulus
-    0.9988 here) it stays above SCREEN*tol for as long as the one-step error is above ~SCREEN/2*tol.  Exact
-    phase (two exchanges): the reference's loop verbatim.  `errors` receives the one-step error where it was
+    Mirror phase (one exchange per iteration): the two-step difference is the screen (see SCREEN: exact
+    stopping iteration for every map whose errors shrink by less than a factor 1.5 per iteration -- the
+    contraction modulus here is 0.9988; a faster map may run a few iterations past the reference's stop).
+    Exact phase (two exchanges): the reference's loop verbatim.  `errors` receives the one-step error where it was
     computed and the two-step screen (as a negative number) elsewhere."""
     it, err = 0, tol + 1
     if mirror and op.mirror_ok:

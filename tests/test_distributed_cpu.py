@@ -107,7 +107,7 @@ def test_sharded_hip_stages_plain_tensors_mirror(model, shapes):
     assert out["mirror_ok"]
     na, no = out["sa_iters"]
     assert na == no and out["sa_err"] < 1e-8, out
-    assert out["sa_mirror_iters"] > 0.5 * na
+    assert out["sa_mirror_iters"] > 0.5 * na, out
 
 
 @pytest.mark.gpu

