@@ -134,7 +134,13 @@ def main():
         from sdfs_via_autodiff_amd.distributed import bench_sharded
         line = bench_sharded(S, model, shapes, params, arrays, args, rank, local_rank, world)
         if rank == 0:
+            if not args.no_cpu:
+                # same bounded CPU sample as at N = 1 (rank 0's host cores; the other ranks wait at the barrier)
+                w_host = 400 + 500 * np.random.default_rng(0).random(shapes)
+                line["cpu_baseline"] = cpu_baseline(model, shapes, params, arrays, w_host)
+                line["gpu_over_cpu"] = line["value"] / line["cpu_baseline"]["value"]
             print(json.dumps(line), flush=True)
+        dist.barrier()
         dist.destroy_process_group()
         return
 
@@ -236,6 +242,28 @@ def main():
             sec["gcy20_newton_1e-8_krylov_f32"] = {"iterations": n, "operator_applies": info["n_apply"], "seconds": t,
                                                    "applies_per_s": info["n_apply"] / t, "final_err": info["final_err"]}
             del x, w800
+            # the conditional-tensor kernels at full size: Rouwenhorst tensors are slice-identical, so the headline
+            # runs the merged (unconditional) plan; SDFS_NO_SLICE_MERGE keeps z_Q (25.6 MB) / z_pi_Q conditional
+            os.environ["SDFS_NO_SLICE_MERGE"] = "1"
+            try:
+                opc = S.KoopmansOperator(model, shapes, params, arrays, device=local_rank)
+            finally:
+                del os.environ["SDFS_NO_SLICE_MERGE"]
+            opc.set_stream(stream.cuda_stream)
+            bc = [torch.from_numpy(w_host).cuda(), torch.empty(shapes, dtype=torch.float64, device="cuda")]
+            for i in range(20):
+                opc.apply_dev(bc[i & 1].data_ptr(), bc[(i + 1) & 1].data_ptr(), resid.data_ptr())
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(100):
+                opc.apply_dev(bc[i & 1].data_ptr(), bc[(i + 1) & 1].data_ptr(), resid.data_ptr())
+            torch.cuda.synchronize()
+            tc = (time.perf_counter() - t0) / 100
+            sec["gcy20_conditional_tensor_path"] = {"ms_per_step": tc * 1e3, "iterations_per_s": 1.0 / tc,
+                                                    "plan": opc.describe_plan().strip().split("\n")}
+            del bc
+            opc.close()
+            torch.cuda.empty_cache()
         m = S.SSY(); shp = (15,) * 4
         T = S.ssy_operator(shp, m.params, S.discretize_ssy(m, shp))
         for algo, kw in (("successive_approx", dict(tol=1e-8)),

@@ -482,7 +482,12 @@ def bench_sharded(S, model, shapes, params, arrays, args, rank, local_rank, worl
                    "shard_sizes": op.a_sizes,
                    "plan_rank0": op.backend.describe_plan().strip().split("\n")},
         "roofline": {"bound": "hbm", "kernel": dom["name"], "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
-                     "frac": achieved / 8000.0, "traffic": None, "avg_launch_ms": avg_ms,
-                     "alg_bytes_per_launch": dom["alg_bytes"], "note": "rank 0's local shard"},
-        "last_residual": float(state["res"].item()),
+                     "frac": achieved / 8000.0, "traffic": None,
+                     "traffic_source": "PMC counters need rocprofv3; no committed profile of the sharded stage kernels",
+                     "avg_launch_ms": avg_ms, "alg_bytes_per_launch": dom["alg_bytes"], "note": "rank 0's local shard"},
+        "exchange": {"per_iteration": (op.n_exchanges - x0) / max(args.steps, 1),
+                     "bytes_sent_per_rank_per_exchange": 8.0 * N / world * (world - 1) / world,
+                     "bytes_per_peer_link_per_exchange": 8.0 * N / world / world},
+        "last_residual": float(state["res"].item()) if state["res"] is not None else None,
+        "residual_kind": "two-step max|w_(k+1) - w_(k-1)| (mirror schedule)" if mirror else "one-step max|w_(k+1) - w_k|",
     }
