@@ -153,6 +153,14 @@ int sdfs_apply_jvp(sdfs_handle* h, const double* w_host, const double* v_host, d
 int sdfs_linearize_dev(sdfs_handle* h, const double* w_dev, double* Tw_dev);
 int sdfs_apply_jvp_dev(sdfs_handle* h, const double* v_dev, double* out_dev, int minus_identity);
 
+/* out = dT(w)^T [u], the vector-Jacobian product jax.grad needs for the reference's "gd" solver
+ * (loss = |f(x) - x|^2, code/solvers.py:127-140): gradient = 2 (dT(x)^T r - r), r = f(x) - x.  Same
+ * kernels as J.v with transposed matrices and the two diagonal scalings in each other's place; available
+ * when every transition tensor is unconditional (Rouwenhorst / Tauchen chains), SDFS_ERR_UNSUPPORTED
+ * otherwise.  The device form uses the linearisation cached by sdfs_linearize_dev. */
+int sdfs_apply_vjp(sdfs_handle* h, const double* w_host, const double* u_host, double* out_host);
+int sdfs_apply_vjp_dev(sdfs_handle* h, const double* u_dev, double* out_dev, int minus_identity);
+
 /* max|T(w) - w| of the most recent apply that computed it. */
 int sdfs_residual(sdfs_handle* h, double* sup_norm);
 

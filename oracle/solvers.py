@@ -153,6 +153,42 @@ def anderson_solver(f, x_init, tol=default_tolerance, max_iter=10000, verbose=Tr
     return x.reshape(shape), it
 
 
+def fixed_point_via_gradient_decent(f, x_init, vjp, maxiter=1000, tol=1e-4, maxls=15, decrease_factor=0.5):
+    """code/solvers.py:127-140: jaxopt.GradientDescent(fun=|f(x) - x|^2, maxiter=1000, tol=1e-4, stepsize=0.0).
+    jaxopt is not vendored (UNPINNED, restated from its documented behaviour): proximal gradient with the
+    identity prox, FISTA acceleration (its default) and, because stepsize <= 0, a backtracking line search per
+    iteration (sufficient decrease f(x+) <= f(y) + <g, x+ - y> + |x+ - y|^2 / (2 s), at most `maxls` halvings,
+    the next search starts from s / decrease_factor); error = |x+ - y| / s.  `vjp(x, u)` = dT(x)^T u.
+    Returns (x, iterations), the errors in ``fixed_point_via_gradient_decent.last_errors``."""
+    shape = np.asarray(x_init).shape
+    x = np.asarray(x_init, dtype=np.float64).copy()
+    y, t, s = x.copy(), 1.0, 1.0
+    errs = []
+    it = 0
+    while it < maxiter:
+        r = np.asarray(f(y), dtype=np.float64) - y
+        fy = float(np.vdot(r, r))
+        g = 2.0 * (np.asarray(vjp(y, r), dtype=np.float64) - r)
+        s = s / decrease_factor
+        for _ in range(maxls):
+            xn = y - s * g
+            rn = np.asarray(f(xn), dtype=np.float64) - xn
+            d = xn - y
+            if float(np.vdot(rn, rn)) <= fy + float(np.vdot(g, d)) + float(np.vdot(d, d)) / (2.0 * s):
+                break
+            s *= decrease_factor
+        err = float(np.sqrt(np.vdot(d, d))) / s
+        errs.append(err)
+        tn = 0.5 * (1.0 + np.sqrt(1.0 + 4.0 * t * t))
+        y = xn + (t - 1.0) / tn * (xn - x)
+        x, t = xn, tn
+        it += 1
+        if err <= tol:
+            break
+    fixed_point_via_gradient_decent.last_errors = errs
+    return x.reshape(shape), it
+
+
 solvers = {"newton": newton_solver,
            "anderson": anderson_solver,
            "successive_approx": successive_approx}

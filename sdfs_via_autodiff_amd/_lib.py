@@ -65,6 +65,8 @@ SYMBOLS = {
     "sdfs_apply_jvp": (C.c_int, [_P, _P, _P, _P]),
     "sdfs_linearize_dev": (C.c_int, [_P, _P, _P]),
     "sdfs_apply_jvp_dev": (C.c_int, [_P, _P, _P, C.c_int]),
+    "sdfs_apply_vjp": (C.c_int, [_P, _P, _P, _P]),
+    "sdfs_apply_vjp_dev": (C.c_int, [_P, _P, _P, C.c_int]),
     "sdfs_residual": (C.c_int, [_P, _D]),
     "sdfs_solve": (C.c_int, [_P, C.c_int, C.POINTER(sdfs_opts), _P, _I64, _I64, _D]),
     "sdfs_solve_dev": (C.c_int, [_P, C.c_int, C.POINTER(sdfs_opts), _P, _I64, _I64, _D]),

@@ -39,6 +39,7 @@ struct AxisInfo {
   int nloc = 1;         // local extent (== n unless this axis is sharded in this stage)
   int off = 0;          // global index of local index 0
   const double* Q = nullptr;   // device transition tensor [.., n, n]
+  const double* Qt = nullptr;  // its transpose, for unconditional tensors only (the vector-Jacobian product)
   int qs[MAXD] = {0, 0, 0, 0, 0, 0};  // matrix-index stride per conditioning axis
   long long qcount = 0;        // number of n x n matrices in Q
   int a3s = 0;                 // index stride of this axis in the a3 table (when it is kept as a table)
@@ -494,11 +495,16 @@ int vec_grid(long long n) {
 }
 
 // modes of one operator application
-enum { MODE_T = 0, MODE_JVP = 1, MODE_T_LIN = 2 };
+// MODE_VJP: u -> c1 .* H'^T (c2 .* u) (- u): the J.v kernels with transposed matrices and the two diagonal
+// scalings in each other's place.  Unconditional tensors only (a conditional tensor's transpose conditions on
+// indices that are summed over).
+enum { MODE_T = 0, MODE_JVP = 1, MODE_T_LIN = 2, MODE_VJP = 3 };
 
 int launch_pass(sdfs_handle* h, Pass& P, int pro, int epi, const PassIO& io, int minus_identity,
-                const char* tag, double bytes, int prec = 0) {
+                const char* tag, double bytes, int prec = 0, bool transposed = false) {
   PassDesc d = P.d;
+  if (transposed)
+    for (int s = 0; s < d.nsteps; ++s) d.Q[s] = h->ax[P.step_axes[s]].Qt;
   d.pro = pro; d.epi = epi; d.minus_identity = minus_identity;
   d.theta = h->theta; d.inv_theta = 1.0 / h->theta; d.beta = h->beta;
   d.ablate = h->knobs.ablate;            // always 0 unless built with -DSDFS_DIAG
@@ -787,6 +793,8 @@ unsigned line_grid(const sdfs_handle* h, const FastPass& P) {
 int run_fast_plan(sdfs_handle* h, int mode, const double* in, double* out, const double* old,
                   unsigned long long* resid, const unsigned long long* gate, double gate_tol, int minus_identity,
                   double* dotp) {
+  const bool vjp = mode == MODE_VJP;       // the J.v launches with transposed matrices and c1 / c2 swapped (fp64)
+  if (vjp) mode = MODE_JVP;
   int rc = ensure_tmp(h);
   if (rc) return rc;
   if (mode != MODE_T) { rc = ensure_lin(h); if (rc) return rc; }
@@ -794,8 +802,8 @@ int run_fast_plan(sdfs_handle* h, int mode, const double* in, double* out, const
   const double n8 = 8.0 * (double)h->N;
   // fp32 Krylov storage: every stream of a J.v application holds floats; a linearising T keeps fp64 streams
   // and writes only c1 (first pass) and c2 (last pass) as scaled floats
-  const bool f32 = h->krylov_f32 && mode != MODE_T;
-  const char* tag = (mode == MODE_JVP) ? (f32 ? "jvp32" : "jvp") : (mode == MODE_T_LIN ? "Tlin" : "T");
+  const bool f32 = !vjp && h->krylov_f32 && mode != MODE_T;
+  const char* tag = vjp ? "vjp" : (mode == MODE_JVP) ? (f32 ? "jvp32" : "jvp") : (mode == MODE_T_LIN ? "Tlin" : "T");
   for (int i = 0; i < np; ++i) {
     FastPass& P = h->fast.passes[i];
     const bool last = i == np - 1;
@@ -808,7 +816,9 @@ int run_fast_plan(sdfs_handle* h, int mode, const double* in, double* out, const
       io.in = pin; io.out = pout; io.gate = gate; io.gate_tol = gate_tol;
       int sm = S_TFIRST;
       if (mode == MODE_T_LIN) { sm = S_TFIRST_LIN; io.aux_out = h->c1; bytes += n8; }
-      else if (mode == MODE_JVP) { sm = S_JFIRST; io.aux_in = h->c1; bytes += n8; }
+      else if (mode == MODE_JVP) { sm = S_JFIRST; io.aux_in = vjp ? h->c2 : h->c1; bytes += n8; }
+      SliceDesc sd = P.sd;
+      if (vjp) { sd.Qf = h->ax[P.ax1].Qt; sd.Qe = h->ax[P.ax0].Qt; }
       slice_fn fn = slice_variant(P.n, sm, f32);
       if (f32 && mode == MODE_JVP) bytes *= 0.5;
       int cid = -1;
@@ -816,7 +826,7 @@ int run_fast_plan(sdfs_handle* h, int mode, const double* in, double* out, const
       const long long ntile = (P.sd.nslices + slice_tile_slices(P.n) - 1) / slice_tile_slices(P.n);
       const unsigned grid = (unsigned)((ntile + 3) / 4);
       ProfScope ps(h, cid);
-      hipLaunchKernelGGL(fn, dim3(grid), dim3(256), slice_lds_bytes(P.n), h->stream, P.sd, io);
+      hipLaunchKernelGGL(fn, dim3(grid), dim3(256), slice_lds_bytes(P.n), h->stream, sd, io);
     } else {
       LineIO io;
       memset(&io, 0, sizeof io);
@@ -824,11 +834,12 @@ int run_fast_plan(sdfs_handle* h, int mode, const double* in, double* out, const
       io.sched = h->sched + 2 * i;
       LineDesc d = P.ld;
       d.minus_identity = minus_identity;
+      if (vjp) { d.Qx = h->ax[P.ax0].Qt; d.Qy = h->ax[P.ax1].Qt; }
       int lm = L_MID;
       if (last) {
         if (mode == MODE_T) { lm = L_TLAST; io.old = old; io.resid = resid; if (resid) bytes += n8; }
         else if (mode == MODE_T_LIN) { lm = L_TLAST_LIN; io.old = old; io.resid = resid; io.aux_out = h->c2; bytes += n8; if (resid) bytes += n8; }
-        else { lm = L_JLAST; io.aux_in = h->c2; io.old = old; bytes += n8; if (minus_identity) { bytes += n8; io.dotp = dotp; } }
+        else { lm = L_JLAST; io.aux_in = vjp ? h->c1 : h->c2; io.old = old; bytes += n8; if (minus_identity) { bytes += n8; io.dotp = dotp; } }
       }
       const bool lf32 = f32 && (mode == MODE_JVP || lm == L_TLAST_LIN);
       line_fn fn = lf32 ? line_variant(P.n, lm, false, true, true) : line_variant(P.n, lm, P.persist, P.ld.lrest % LINE_R == 0);
@@ -855,12 +866,20 @@ long long jvp_last_tiles(sdfs_handle* h) {
 int run_plan(sdfs_handle* h, Plan& plan, int mode, bool has_first, bool has_last,
              const double* in, double* out, const double* old, unsigned long long* resid,
              const unsigned long long* gate, double gate_tol, int minus_identity, double* dotp = nullptr) {
+  if (mode == MODE_VJP) {
+    if (h->cont || h->dense) return fail(h, SDFS_ERR_UNSUPPORTED, "the vector-Jacobian product exists for the discretised operator only");
+    for (int a = 0; a < h->ndim; ++a)
+      if (!h->ax[a].Qt) return fail(h, SDFS_ERR_UNSUPPORTED, "the vector-Jacobian product needs unconditional transition tensors "
+                                    "(axis %s is conditional)", h->ax[a].name);
+  }
   if (h->cont) return run_cont(h, mode, in, out, old, resid, gate, gate_tol, minus_identity);
   if (h->dense) return run_dense(h, mode, in, out, old, resid, gate, gate_tol, minus_identity);
   // the pair plan serves the whole-grid operator; its fp32-storage forms need whole 16-element chunks in
   // every line pass, otherwise fp32 Krylov storage (and its linearisation) stays on the generic kernels
   if (h->fast.ok && &plan == &h->plan[0] && has_first && has_last && !(h->krylov_f32 && mode != MODE_T && !h->fast.f32_ok))
     return run_fast_plan(h, mode, in, out, old, resid, gate, gate_tol, minus_identity, dotp);
+  const bool vjp = mode == MODE_VJP;       // the J.v launches with transposed matrices and c1 / c2 swapped
+  if (vjp) mode = MODE_JVP;
   int rc = ensure_tmp(h);
   if (rc) return rc;
   if (mode != MODE_T) { rc = ensure_lin(h); if (rc) return rc; }
@@ -879,7 +898,7 @@ int run_plan(sdfs_handle* h, Plan& plan, int mode, bool has_first, bool has_last
     if (first) {
       if (mode == MODE_T) pro = PRO_POW;
       else if (mode == MODE_T_LIN) { pro = PRO_POW_LIN; io.aux_out = h->c1; bytes += n8; }
-      else { pro = PRO_MUL; io.aux_in = h->c1; bytes += n8; }
+      else { pro = PRO_MUL; io.aux_in = vjp ? h->c2 : h->c1; bytes += n8; }
     }
     if (last) {
       if (mode == MODE_T) { epi = EPI_CES; io.old = old; io.resid = resid; if (resid) bytes += n8; }
@@ -892,16 +911,16 @@ int run_plan(sdfs_handle* h, Plan& plan, int mode, bool has_first, bool has_last
       } else {
         epi = EPI_MUL; bytes += n8;
         if (first) return fail(h, SDFS_ERR_UNSUPPORTED, "single-pass JVP not supported");
-        io.aux_in = h->c2; io.old = old; if (minus_identity) bytes += n8;
+        io.aux_in = vjp ? h->c1 : h->c2; io.old = old; if (minus_identity) bytes += n8;
         if (minus_identity) io.dotp = dotp;
       }
     }
     // fp32 Krylov storage: every stream of a J.v application is fp32; a linearising T keeps fp64
     // streams and writes only c1 (first pass) and c2 (last pass) as fp32
-    const int prec = (h->krylov_f32 && (mode == MODE_JVP || (mode == MODE_T_LIN && (first || last)))) ? 1 : 0;
-    if (h->krylov_f32 && mode == MODE_JVP) bytes *= 0.5;
-    const char* tag = (mode == MODE_JVP) ? (h->krylov_f32 ? "jvp32" : "jvp") : (mode == MODE_T_LIN ? "Tlin" : "T");
-    rc = launch_pass(h, P, pro, epi, io, minus_identity, tag, bytes, prec);
+    const int prec = (!vjp && h->krylov_f32 && (mode == MODE_JVP || (mode == MODE_T_LIN && (first || last)))) ? 1 : 0;
+    if (prec && mode == MODE_JVP) bytes *= 0.5;
+    const char* tag = vjp ? "vjp" : (mode == MODE_JVP) ? (h->krylov_f32 ? "jvp32" : "jvp") : (mode == MODE_T_LIN ? "Tlin" : "T");
+    rc = launch_pass(h, P, pro, epi, io, minus_identity, tag, bytes, prec, vjp);
     if (rc) return rc;
   }
   return 0;
@@ -1414,6 +1433,17 @@ int create_common(int model, int ndim, const int64_t* shapes, const double* para
   }
   int rc = setup_model(h, model, ndim, shapes, params, nparams, arrays, sizes, narrays);
   if (rc) return bail(rc);
+  for (int a = 0; a < ndim; ++a) {                       // transposed copies of the unconditional matrices (VJP)
+    if (h->ax[a].qcount != 1) continue;
+    const int n = h->ax[a].n;
+    std::vector<double> q((size_t)n * n), qt((size_t)n * n);
+    if (hipMemcpy(q.data(), h->ax[a].Q, q.size() * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess)
+      return bail(fail(h, SDFS_ERR_HIP, "read-back of a transition matrix failed"));
+    for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) qt[(size_t)j * n + i] = q[(size_t)i * n + j];
+    double* d = nullptr;
+    if ((rc = upload(h, &d, qt.data(), qt.size()))) return bail(rc);
+    h->ax[a].Qt = d;
+  }
   // dynamic LDS above 64 KB has to be allowed per kernel variant (and per device)
   static unsigned long long attr_done = 0;
   if (device_id < 64 && !(attr_done & (1ULL << device_id))) {
@@ -1799,6 +1829,32 @@ int sdfs_apply_jvp(sdfs_handle* h, const double* w_host, const double* v_host, d
   HIPCHK(h, hipMemcpyAsync(h->hostio2, v_host, nb, hipMemcpyHostToDevice, h->stream));
   if ((rc = sdfs_linearize_dev(h, h->hostio, h->hostio3))) return rc;
   if ((rc = sdfs_apply_jvp_dev(h, h->hostio2, h->hostio3, 0))) return rc;
+  HIPCHK(h, hipMemcpyAsync(out_host, h->hostio3, nb, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+int sdfs_apply_vjp_dev(sdfs_handle* h, const double* u, double* out, int minus_identity) {
+  int rc = check(h); if (rc) return rc;
+  if (!u || !out) return fail(h, SDFS_ERR_ARG, "NULL grid pointer");
+  if (h->sharded) return fail(h, SDFS_ERR_ARG, "sharded handle: no vector-Jacobian product");
+  if (!h->c1 || !h->c2) return fail(h, SDFS_ERR_ARG, "sdfs_apply_vjp_dev before sdfs_linearize_dev");
+  const bool f32 = h->krylov_f32;
+  h->krylov_f32 = false;
+  rc = run_plan(h, h->plan[0], MODE_VJP, true, true, u, out, u, nullptr, nullptr, 0.0, minus_identity);
+  h->krylov_f32 = f32;
+  return rc;
+}
+
+int sdfs_apply_vjp(sdfs_handle* h, const double* w_host, const double* u_host, double* out_host) {
+  int rc = check(h); if (rc) return rc;
+  if (!w_host || !u_host || !out_host) return fail(h, SDFS_ERR_ARG, "NULL host pointer");
+  if ((rc = ensure_buf(h, &h->hostio)) || (rc = ensure_buf(h, &h->hostio2)) || (rc = ensure_buf(h, &h->hostio3))) return rc;
+  const size_t nb = sizeof(double) * (size_t)h->N;
+  HIPCHK(h, hipMemcpyAsync(h->hostio, w_host, nb, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipMemcpyAsync(h->hostio2, u_host, nb, hipMemcpyHostToDevice, h->stream));
+  if ((rc = sdfs_linearize_dev(h, h->hostio, h->hostio3))) return rc;
+  if ((rc = sdfs_apply_vjp_dev(h, h->hostio2, h->hostio3, 0))) return rc;
   HIPCHK(h, hipMemcpyAsync(out_host, h->hostio3, nb, hipMemcpyDeviceToHost, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
   return 0;

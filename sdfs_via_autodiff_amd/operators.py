@@ -121,6 +121,15 @@ class KoopmansOperator:
         check(lib.sdfs_apply_jvp(self._h, w.ctypes.data, v.ctypes.data, out.ctypes.data), self._h)
         return out
 
+    def vjp(self, w, u):
+        """dT(w)^T[u] -- what jax.vjp(T, w)[1](u) returns (the gradient path of the reference's "gd" solver).
+        Unconditional transition tensors only (Rouwenhorst / Tauchen chains)."""
+        w = self._host_in(w)
+        u = self._host_in(u, "u")
+        out = np.empty_like(w)
+        check(lib.sdfs_apply_vjp(self._h, w.ctypes.data, u.ctypes.data, out.ctypes.data), self._h)
+        return out
+
     def residual(self):
         """max|T(w) - w| of the most recent ``T(w)`` call."""
         r = C.c_double()
@@ -136,6 +145,9 @@ class KoopmansOperator:
 
     def jvp_dev(self, v_ptr, out_ptr, minus_identity=False):
         check(lib.sdfs_apply_jvp_dev(self._h, v_ptr, out_ptr, int(minus_identity)), self._h)
+
+    def vjp_dev(self, u_ptr, out_ptr, minus_identity=False):
+        check(lib.sdfs_apply_vjp_dev(self._h, u_ptr, out_ptr, int(minus_identity)), self._h)
 
     def synchronize(self):
         check(lib.sdfs_synchronize(self._h), self._h)

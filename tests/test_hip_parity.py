@@ -559,3 +559,63 @@ def test_sa_on_callers_default_stream(S):
     T.set_stream(None, use_own=True)
     x2, n2, _ = T.solve(np.full(shapes, 800.0), "successive_approx", tol=1e-8)
     assert n2 == n and np.array_equal(x, x2)
+
+
+def test_vjp_and_gd(S):
+    """sdfs_apply_vjp: dT(w)^T u against the transpose of the oracle's Jacobian (built column by column from its
+    J.v on a small grid) and the adjoint identity <u, J v> = <J^T u, v> at a larger one, on both kernel families;
+    then the registry's "gd" on the device against the oracle's restatement (same algorithm, unpinned jaxopt)."""
+    import os
+    from oracle import solvers as osol
+    shapes = (3, 2, 3, 2)
+    T, _, _ = make_op(S, "ssy", shapes)
+    oT, oJ = oracle_T("ssy", shapes)
+    w = wbench(shapes)
+    n = int(np.prod(shapes))
+    J = np.stack([oJ(w, e.reshape(shapes)).ravel() for e in np.eye(n)], axis=1)      # J[:, j] = dT(w)[e_j]
+    u = np.random.default_rng(3).standard_normal(shapes)
+    np.testing.assert_allclose(T.vjp(w, u).ravel(), J.T @ u.ravel(), rtol=1e-10, atol=1e-13 * np.abs(J.T @ u.ravel()).max())
+    for model, shp, plan in (("gcy", (3, 2, 2, 3, 2, 4), None), ("ssy", (16, 16, 16, 16), "pair"), ("ssy", (16, 16, 16, 16), "classic")):
+        if plan:
+            os.environ["SDFS_PLAN"] = plan
+        try:
+            Tm, _, _ = make_op(S, model, shp)
+        finally:
+            os.environ.pop("SDFS_PLAN", None)
+        wm = wbench(shp)
+        rng = np.random.default_rng(4)
+        uu, vv = rng.standard_normal(shp), rng.standard_normal(shp)
+        lhs, rhs = float(np.vdot(uu, Tm.jvp(wm, vv))), float(np.vdot(Tm.vjp(wm, uu), vv))
+        assert abs(lhs - rhs) <= 1e-10 * max(abs(lhs), abs(rhs)), (model, shp, plan, lhs, rhs)
+    # conditional tensors whose slices differ have no VJP: loud error
+    from oracle import models, ssy
+    p = models.ssy_params(); arr = list(ssy.discretize_ssy(p, (4, 5, 6, 7)))
+    q = np.random.default_rng(5).random(arr[7].shape) + 0.05
+    arr[7] = q / q.sum(axis=-1, keepdims=True)
+    Tc = S.ssy_operator((4, 5, 6, 7), p, arr)
+    with pytest.raises(S.SdfsError, match="unconditional"):
+        Tc.vjp(wbench((4, 5, 6, 7)), wbench((4, 5, 6, 7)))
+    # gd: device loop == oracle loop (first 25 iterations; the method itself crawls on this problem)
+    w0 = np.full(shapes, 800.0)
+    xg, st = S.fixed_point_via_gradient_decent(lambda x: S.T_ssy(x, shapes, *_ssy_model_args(S, shapes)), w0, maxiter=25)
+    xo, no = osol.fixed_point_via_gradient_decent(oT, w0, lambda x, r: (J_at(oJ, x, shapes).T @ r.ravel()).reshape(shapes), maxiter=25)
+    assert st["iter_num"] == no == 25
+    np.testing.assert_allclose(xg, xo, rtol=1e-9)
+    np.testing.assert_allclose(st["errors"], osol.fixed_point_via_gradient_decent.last_errors, rtol=1e-6)
+    r0 = oT(w0) - w0
+    rg = oT(xg) - xg
+    assert np.vdot(rg, rg) < np.vdot(r0, r0)
+
+
+def _ssy_model_args(S, shapes):
+    m = S.SSY()
+    if not hasattr(_ssy_model_args, "cache"):
+        _ssy_model_args.cache = {}
+    if shapes not in _ssy_model_args.cache:
+        _ssy_model_args.cache[shapes] = (m.params, S.discretize_ssy(m, shapes))
+    return _ssy_model_args.cache[shapes]
+
+
+def J_at(oJ, x, shapes):
+    n = int(np.prod(shapes))
+    return np.stack([oJ(x, e.reshape(shapes)).ravel() for e in np.eye(n)], axis=1)

@@ -205,8 +205,31 @@ def test_solver_front_end_fallback_and_registry(capsys):
     out = capsys.readouterr().out
     assert "Algorithm no-such-algorithm not found." in out
     assert "Falling back to successive approximation." in out
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(TypeError, match="vjp"):                  # "gd" differentiates the loss: needs a VJP
         S.solver(f, np.zeros(3), algorithm="gd")
+
+
+def test_gd_host_path_matches_oracle_restatement():
+    """Registry entry "gd" (code/solvers.py:127-140) on a foreign callable that brings its own vjp: the host loop
+    equals the oracle's restatement of jaxopt.GradientDescent (FISTA + backtracking; unpinned third party)."""
+    import sdfs_via_autodiff_amd as S
+    from oracle import solvers as osol
+    A = np.array([[0.5, 0.2, 0.0], [0.1, 0.4, 0.1], [0.0, 0.3, 0.5]])
+    b = np.array([1.0, 2.0, 3.0])
+
+    class F:
+        def __call__(self, x):
+            return A @ x + b
+
+        def vjp(self, x, u):
+            return A.T @ u
+    f = F()
+    x, state = S.fixed_point_via_gradient_decent(f, np.zeros(3))
+    xo, no = osol.fixed_point_via_gradient_decent(f, np.zeros(3), f.vjp)
+    assert state["iter_num"] == no and no < 1000
+    np.testing.assert_allclose(x, xo, rtol=0, atol=1e-12)
+    np.testing.assert_allclose(x, np.linalg.solve(np.eye(3) - A, b), atol=1e-3)
+    np.testing.assert_allclose(S.solver(f, np.zeros(3), algorithm="gd"), xo, atol=1e-12)
 
 
 def test_max_iter_warning(capsys):
