@@ -16,6 +16,7 @@
 #include <cstring>
 #include <limits>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/sdfs_hip.h"
@@ -164,6 +165,9 @@ struct sdfs_handle {
   std::vector<hipEvent_t> event_pool;
 
   // graph cache for the SA chunk
+  hipGraphExec_t bicg_graph[2] = {nullptr, nullptr};   // one BiCGSTAB iteration (fp64 / fp32 Krylov storage)
+  unsigned long long* bicg_gate = nullptr;             // device flag the iteration's kernels are gated on
+  unsigned long long* bicg_gate_host = nullptr;        // pinned mirror
   hipGraphExec_t sa_graph = nullptr;
   int sa_graph_chunk = 0;
   double sa_graph_tol = 0;   // the gate tolerance is baked into the captured kernel arguments
@@ -1052,48 +1056,82 @@ int bicgstab_dev_t(sdfs_handle* h, const sdfs_opts& o, int64_t* matvecs) {
   const int g = vec_grid(n);
   hipStream_t st = h->stream;
   const int cvec = h->profiling ? counter_id(h, "bicgstab_blas1", 0, 0) : -1;
+  int rc;
+  // gate word: non-zero while the inner solve runs, 0 once converged / broken down (vec_kernels.hpp); an
+  // allocation of its own, never moved: its address is baked into the captured iteration graph
+  if (!h->bicg_gate) {
+    HIPCHK(h, hipMalloc((void**)&h->bicg_gate, 64));
+    h->misc_allocs.push_back(h->bicg_gate);
+    HIPCHK(h, hipHostMalloc((void**)&h->bicg_gate_host, 64));
+  }
+  unsigned long long* gate = h->bicg_gate;
   {
     ProfScope ps(h, cvec);
     hipLaunchKernelGGL(k_bicg_init<T>, dim3(g), dim3(VEC_BLOCK), 0, st, b, r, rhat, p, q, x, n);
-    hipLaunchKernelGGL(k_dot<T>, dim3(g), dim3(VEC_BLOCK), 0, st, (const T*)r, (const T*)r, n, h->partial);
-    hipLaunchKernelGGL(k_bicg_init_finish, dim3(1), dim3(VEC_BLOCK), 0, st, h->partial, g, h->sc, o.inner_rtol, o.inner_atol);
+    hipLaunchKernelGGL(k_dot<T>, dim3(g), dim3(VEC_BLOCK), 0, st, (const T*)r, (const T*)r, n, h->partial, (const unsigned long long*)nullptr);
+    hipLaunchKernelGGL(k_bicg_init_finish, dim3(1), dim3(VEC_BLOCK), 0, st, h->partial, g, h->sc, o.inner_rtol, o.inner_atol, gate);
   }
-  HIPCHK(h, hipMemcpyAsync(h->sc_host, h->sc, sizeof(double) * SC_COUNT, hipMemcpyDeviceToHost, st));
-  HIPCHK(h, hipStreamSynchronize(st));
-  const double atol2 = h->sc_host[SC_ATOL2];
-  double rr = h->sc_host[SC_RR];
   const long long maxit = o.inner_max_iter > 0 ? o.inner_max_iter : 10 * n;
-  long long k = 0;
-  while (rr > atol2 && k < maxit) {
-    int rc;
+  // <t, s> and <t, t> come out of the last J.v pass when its tiles fit the partial-sum buffer
+  const long long last_tiles = jvp_last_tiles(h);
+  const bool fused_dots = last_tiles > 0 && 2 * last_tiles <= (long long)MAX_PARTIAL_BLOCKS * AND_MAX_M &&
+                          (h->plan[0].passes.size() > 1 || (h->fast.ok && (!h->krylov_f32 || h->fast.f32_ok))) && h->knobs.no_dot_fusion == 0;
+  // one BiCGSTAB iteration, every launch gated on the device flag
+  auto iteration = [&]() -> int {
+    int rc2;
     { ProfScope ps(h, cvec);
-      hipLaunchKernelGGL(k_bicg_update_p<T>, dim3(g), dim3(VEC_BLOCK), 0, st, (const T*)r, p, (const T*)q, n, h->sc); }
-    if ((rc = run_plan(h, h->plan[0], MODE_JVP, true, true, (const double*)p, (double*)q, (const double*)p, nullptr, nullptr, 0.0, 1))) return rc;
+      hipLaunchKernelGGL(k_bicg_update_p<T>, dim3(g), dim3(VEC_BLOCK), 0, st, (const T*)r, p, (const T*)q, n, h->sc, (const unsigned long long*)gate); }
+    if ((rc2 = run_plan(h, h->plan[0], MODE_JVP, true, true, (const double*)p, (double*)q, (const double*)p, nullptr, gate, 0.0, 1))) return rc2;
     { ProfScope ps(h, cvec);
-      hipLaunchKernelGGL(k_dot<T>, dim3(g), dim3(VEC_BLOCK), 0, st, (const T*)rhat, (const T*)q, n, h->partial);
-      hipLaunchKernelGGL(k_bicg_alpha_finish, dim3(1), dim3(VEC_BLOCK), 0, st, h->partial, g, h->sc);
-      hipLaunchKernelGGL(k_bicg_s<T>, dim3(g), dim3(VEC_BLOCK), 0, st, r, (const T*)q, n, h->sc, h->partial);
-      hipLaunchKernelGGL(k_bicg_s_finish, dim3(1), dim3(VEC_BLOCK), 0, st, h->partial, g, h->sc); }
-    // <t, s> and <t, t> come out of the last J.v pass when its tiles fit the partial-sum buffer
-    const long long last_tiles = jvp_last_tiles(h);
-    const bool fused_dots = last_tiles > 0 && 2 * last_tiles <= (long long)MAX_PARTIAL_BLOCKS * AND_MAX_M &&
-                            (h->plan[0].passes.size() > 1 || (h->fast.ok && (!h->krylov_f32 || h->fast.f32_ok))) && h->knobs.no_dot_fusion == 0;
-    if ((rc = run_plan(h, h->plan[0], MODE_JVP, true, true, (const double*)r, (double*)t, (const double*)r, nullptr, nullptr, 0.0, 1,
-                       fused_dots ? h->partial : nullptr))) return rc;
+      hipLaunchKernelGGL(k_dot<T>, dim3(g), dim3(VEC_BLOCK), 0, st, (const T*)rhat, (const T*)q, n, h->partial, (const unsigned long long*)gate);
+      hipLaunchKernelGGL(k_bicg_alpha_finish, dim3(1), dim3(VEC_BLOCK), 0, st, h->partial, g, h->sc, (const unsigned long long*)gate);
+      hipLaunchKernelGGL(k_bicg_s<T>, dim3(g), dim3(VEC_BLOCK), 0, st, r, (const T*)q, n, h->sc, h->partial, (const unsigned long long*)gate);
+      hipLaunchKernelGGL(k_bicg_s_finish, dim3(1), dim3(VEC_BLOCK), 0, st, h->partial, g, h->sc, (const unsigned long long*)gate); }
+    if ((rc2 = run_plan(h, h->plan[0], MODE_JVP, true, true, (const double*)r, (double*)t, (const double*)r, nullptr, gate, 0.0, 1,
+                        fused_dots ? h->partial : nullptr))) return rc2;
     { ProfScope ps(h, cvec);
-      if (!fused_dots) hipLaunchKernelGGL(k_dot2<T>, dim3(g), dim3(VEC_BLOCK), 0, st, (const T*)t, (const T*)r, n, h->partial);
-      hipLaunchKernelGGL(k_bicg_omega_finish, dim3(1), dim3(VEC_BLOCK), 0, st, h->partial, fused_dots ? (int)last_tiles : g, h->sc);
-      hipLaunchKernelGGL(k_bicg_update_xr<T>, dim3(g), dim3(VEC_BLOCK), 0, st, x, r, (const T*)p, (const T*)t, (const T*)rhat, n, h->sc, h->partial);
-      hipLaunchKernelGGL(k_bicg_iter_finish, dim3(1), dim3(VEC_BLOCK), 0, st, h->partial, g, h->sc); }
-    *matvecs += 2;
-    HIPCHK(h, hipGetLastError());
-    HIPCHK(h, hipMemcpyAsync(h->sc_host, h->sc, sizeof(double) * SC_COUNT, hipMemcpyDeviceToHost, st));
-    HIPCHK(h, hipStreamSynchronize(st));
-    rr = h->sc_host[SC_RR];
-    if (h->sc_host[SC_BREAK] != 0.0) break;
-    if (!(rr == rr)) break;
-    ++k;
+      if (!fused_dots) hipLaunchKernelGGL(k_dot2<T>, dim3(g), dim3(VEC_BLOCK), 0, st, (const T*)t, (const T*)r, n, h->partial, (const unsigned long long*)gate);
+      hipLaunchKernelGGL(k_bicg_omega_finish, dim3(1), dim3(VEC_BLOCK), 0, st, h->partial, fused_dots ? (int)last_tiles : g, h->sc, (const unsigned long long*)gate);
+      hipLaunchKernelGGL(k_bicg_update_xr<T>, dim3(g), dim3(VEC_BLOCK), 0, st, x, r, (const T*)p, (const T*)t, (const T*)rhat, n, h->sc, h->partial, (const unsigned long long*)gate);
+      hipLaunchKernelGGL(k_bicg_iter_finish, dim3(1), dim3(VEC_BLOCK), 0, st, h->partial, g, h->sc, gate); }
+    return 0;
+  };
+  // Small grids are launch- and sync-bound: the iteration is captured once into a hipGraph (pointers, scalars
+  // and the gate are fixed device addresses) and replayed; `chunk` iterations go out per host synchronisation.
+  // Large grids (an iteration is milliseconds) keep one iteration per sync so that nothing runs past the
+  // breakdown / convergence test for long.
+  const int chunk = (int)std::min<long long>(maxit, n <= (1LL << 22) ? 8 : 1);
+  const int gslot = std::is_same<T, float>::value ? 1 : 0;
+  const bool graph = o.use_graph && !h->profiling && st != nullptr && chunk > 1;
+  if (graph && h->bicg_graph[gslot] == nullptr) {
+    hipGraph_t gr = nullptr;
+    HIPCHK(h, hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+    rc = iteration();
+    hipError_t e = hipStreamEndCapture(st, &gr);
+    if (rc || e != hipSuccess) {
+      if (gr) hipGraphDestroy(gr);
+      if (rc) return rc;
+      HIPCHK(h, e);
+    }
+    e = hipGraphInstantiate(&h->bicg_graph[gslot], gr, nullptr, nullptr, 0);
+    hipGraphDestroy(gr);
+    HIPCHK(h, e);
   }
+  long long k = 0;
+  for (;;) {
+    HIPCHK(h, hipMemcpyAsync(h->sc_host, h->sc, sizeof(double) * SC_COUNT, hipMemcpyDeviceToHost, st));
+    HIPCHK(h, hipMemcpyAsync(h->bicg_gate_host, gate, 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(h, hipStreamSynchronize(st));
+    k = (long long)h->sc_host[SC_ITERS];
+    if (h->bicg_gate_host[0] == 0ULL || k >= maxit) break;       // converged, broken down, NaN, or out of iterations
+    const int todo = (int)std::min<long long>(chunk, maxit - k);
+    for (int i = 0; i < todo; ++i) {
+      if (graph) { HIPCHK(h, hipGraphLaunch(h->bicg_graph[gslot], st)); }
+      else if ((rc = iteration())) return rc;
+    }
+    HIPCHK(h, hipGetLastError());
+  }
+  *matvecs += 2 * k;
   return 0;
 }
 
@@ -1734,12 +1772,14 @@ void sdfs_destroy(sdfs_handle* h) {
   hipSetDevice(h->device);
   if (h->stream) hipStreamSynchronize(h->stream);
   if (h->sa_graph) hipGraphExecDestroy(h->sa_graph);
+  for (int i = 0; i < 2; ++i) if (h->bicg_graph[i]) hipGraphExecDestroy(h->bicg_graph[i]);
   for (double* p : h->dev_allocs) hipFree(p);
   for (void* p : h->misc_allocs) hipFree(p);
   if (h->slots) hipFree(h->slots);
   if (h->slots_host) hipHostFree(h->slots_host);
   if (h->sc_host) hipHostFree(h->sc_host);
   if (h->gram_row_host) hipHostFree(h->gram_row_host);
+  if (h->bicg_gate_host) hipHostFree(h->bicg_gate_host);
   for (auto& p : h->pending) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
   for (auto e : h->event_pool) hipEventDestroy(e);
   if (h->own_stream) hipStreamDestroy(h->own_stream);
@@ -1769,6 +1809,7 @@ int sdfs_set_stream(sdfs_handle* h, void* s, int use_own) {
   int rc = check(h); if (rc) return rc;
   hipStream_t ns = use_own ? h->own_stream : (hipStream_t)s;     // s == NULL is the device's default stream
   if (ns != h->stream && h->sa_graph) { hipGraphExecDestroy(h->sa_graph); h->sa_graph = nullptr; }
+  if (ns != h->stream) for (int i = 0; i < 2; ++i) if (h->bicg_graph[i]) { hipGraphExecDestroy(h->bicg_graph[i]); h->bicg_graph[i] = nullptr; }
   h->stream = ns;
   return 0;
 }

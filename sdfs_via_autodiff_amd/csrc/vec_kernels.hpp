@@ -18,8 +18,14 @@ constexpr int MAX_PARTIAL_BLOCKS = 2048;
 // device scalar block of the BiCGSTAB recurrence
 enum {
   SC_RHO = 0, SC_ALPHA, SC_OMEGA, SC_RHO_NEW, SC_BETA, SC_RHAT_Q, SC_SS, SC_TS, SC_TT,
-  SC_RR, SC_BB, SC_ATOL2, SC_EARLY, SC_BREAK, SC_STEPMAX, SC_COUNT = 16
+  SC_RR, SC_BB, SC_ATOL2, SC_EARLY, SC_BREAK, SC_STEPMAX, SC_ITERS, SC_COUNT = 16
 };
+
+// Gate of the BiCGSTAB kernels: a device word that is non-zero while the inner solve runs and 0 once it has
+// converged or broken down (set by k_bicg_iter_finish).  Every kernel of an iteration returns at once when
+// it reads 0, so the host can enqueue several iterations per synchronisation (or replay them from a hipGraph)
+// and the launches behind the last real iteration are no-ops: same iterates as one sync per iteration.
+#define SDFS_GATED(gate) do { if ((gate) != nullptr && *(gate) == 0ULL) return; } while (0)
 
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
@@ -151,7 +157,9 @@ k_bicg_init(const double* __restrict__ b, T* __restrict__ r, T* __restrict__ rha
 // partial sums of <a, b>
 template <typename T>
 __global__ void __launch_bounds__(VEC_BLOCK)
-k_dot(const T* __restrict__ a, const T* __restrict__ b, long long n, double* __restrict__ partial) {
+k_dot(const T* __restrict__ a, const T* __restrict__ b, long long n, double* __restrict__ partial,
+      const unsigned long long* gate = nullptr) {
+  SDFS_GATED(gate);
   double acc[1] = {0.0};
 #define BODY(W_) { double x_[W_], y_[W_]; LDx<W_>(a, e, x_); LDx<W_>(b, e, y_); \
                    _Pragma("unroll") for (int j = 0; j < W_; ++j) acc[0] += x_[j] * y_[j]; }
@@ -164,9 +172,12 @@ k_dot(const T* __restrict__ a, const T* __restrict__ b, long long n, double* __r
 // rho_new = <rhat, r> = bb; beta = rho_new/rho * alpha/omega; rr = bb
 __global__ void __launch_bounds__(VEC_BLOCK)
 k_bicg_init_finish(const double* __restrict__ partial, int nb, double* __restrict__ sc,
-                   double rtol, double atol) {
+                   double rtol, double atol, unsigned long long* gate) {
   const double bb = finish_sum(partial, nb, 0);
   if (threadIdx.x == 0) {
+    const double a2 = fmax(rtol * rtol * bb, atol * atol);
+    sc[SC_ITERS] = 0.0;
+    if (gate != nullptr) *gate = (bb > a2) ? ~0ULL : 0ULL;          // NaN: not greater -> closed (the host loop's test)
     sc[SC_BB] = bb;
     sc[SC_ATOL2] = fmax(rtol * rtol * bb, atol * atol);
     sc[SC_RHO] = 1.0; sc[SC_ALPHA] = 1.0; sc[SC_OMEGA] = 1.0;
@@ -181,7 +192,8 @@ k_bicg_init_finish(const double* __restrict__ partial, int nb, double* __restric
 template <typename T>
 __global__ void __launch_bounds__(VEC_BLOCK)
 k_bicg_update_p(const T* __restrict__ r, T* __restrict__ p, const T* __restrict__ q,
-                long long n, const double* __restrict__ sc) {
+                long long n, const double* __restrict__ sc, const unsigned long long* gate = nullptr) {
+  SDFS_GATED(gate);
   const double beta = sc[SC_BETA], omega = sc[SC_OMEGA];
 #define BODY(W_) { double r_[W_], p_[W_], q_[W_]; LDx<W_>(r, e, r_); LDx<W_>((const T*)p, e, p_); LDx<W_>(q, e, q_); \
                    _Pragma("unroll") for (int j = 0; j < W_; ++j) p_[j] = r_[j] + beta * (p_[j] - omega * q_[j]); \
@@ -192,7 +204,9 @@ k_bicg_update_p(const T* __restrict__ r, T* __restrict__ p, const T* __restrict_
 
 // alpha = rho_new / <rhat, q>
 __global__ void __launch_bounds__(VEC_BLOCK)
-k_bicg_alpha_finish(const double* __restrict__ partial, int nb, double* __restrict__ sc) {
+k_bicg_alpha_finish(const double* __restrict__ partial, int nb, double* __restrict__ sc,
+                    const unsigned long long* gate = nullptr) {
+  SDFS_GATED(gate);
   const double d = finish_sum(partial, nb, 0);
   if (threadIdx.x == 0) { sc[SC_RHAT_Q] = d; sc[SC_ALPHA] = sc[SC_RHO_NEW] / d; }
 }
@@ -201,7 +215,8 @@ k_bicg_alpha_finish(const double* __restrict__ partial, int nb, double* __restri
 template <typename T>
 __global__ void __launch_bounds__(VEC_BLOCK)
 k_bicg_s(T* __restrict__ r, const T* __restrict__ q, long long n,
-         const double* __restrict__ sc, double* __restrict__ partial) {
+         const double* __restrict__ sc, double* __restrict__ partial, const unsigned long long* gate = nullptr) {
+  SDFS_GATED(gate);
   const double alpha = sc[SC_ALPHA];
   double acc[1] = {0.0};
 #define BODY(W_) { double r_[W_], q_[W_]; LDx<W_>((const T*)r, e, r_); LDx<W_>(q, e, q_); \
@@ -213,7 +228,9 @@ k_bicg_s(T* __restrict__ r, const T* __restrict__ q, long long n,
 }
 
 __global__ void __launch_bounds__(VEC_BLOCK)
-k_bicg_s_finish(const double* __restrict__ partial, int nb, double* __restrict__ sc) {
+k_bicg_s_finish(const double* __restrict__ partial, int nb, double* __restrict__ sc,
+                const unsigned long long* gate = nullptr) {
+  SDFS_GATED(gate);
   const double ss = finish_sum(partial, nb, 0);
   if (threadIdx.x == 0) { sc[SC_SS] = ss; sc[SC_EARLY] = (ss < sc[SC_ATOL2]) ? 1.0 : 0.0; }
 }
@@ -221,7 +238,9 @@ k_bicg_s_finish(const double* __restrict__ partial, int nb, double* __restrict__
 // partial sums of <t,s> and <t,t>
 template <typename T>
 __global__ void __launch_bounds__(VEC_BLOCK)
-k_dot2(const T* __restrict__ t, const T* __restrict__ s, long long n, double* __restrict__ partial) {
+k_dot2(const T* __restrict__ t, const T* __restrict__ s, long long n, double* __restrict__ partial,
+       const unsigned long long* gate = nullptr) {
+  SDFS_GATED(gate);
   double acc[2] = {0.0, 0.0};
 #define BODY(W_) { double t_[W_], s_[W_]; LDx<W_>(t, e, t_); LDx<W_>(s, e, s_); \
                    _Pragma("unroll") for (int j = 0; j < W_; ++j) { acc[0] += t_[j] * s_[j]; acc[1] += t_[j] * t_[j]; } }
@@ -231,7 +250,9 @@ k_dot2(const T* __restrict__ t, const T* __restrict__ s, long long n, double* __
 }
 
 __global__ void __launch_bounds__(VEC_BLOCK)
-k_bicg_omega_finish(const double* __restrict__ partial, int nb, double* __restrict__ sc) {
+k_bicg_omega_finish(const double* __restrict__ partial, int nb, double* __restrict__ sc,
+                    const unsigned long long* gate = nullptr) {
+  SDFS_GATED(gate);
   const double ts = finish_sum(partial, nb, 0);
   const double tt = finish_sum(partial, nb, 1);
   if (threadIdx.x == 0) { sc[SC_TS] = ts; sc[SC_TT] = tt; sc[SC_OMEGA] = ts / tt; }
@@ -243,7 +264,8 @@ template <typename T>
 __global__ void __launch_bounds__(VEC_BLOCK)
 k_bicg_update_xr(T* __restrict__ x, T* __restrict__ r, const T* __restrict__ p,
                  const T* __restrict__ t, const T* __restrict__ rhat, long long n,
-                 const double* __restrict__ sc, double* __restrict__ partial) {
+                 const double* __restrict__ sc, double* __restrict__ partial, const unsigned long long* gate = nullptr) {
+  SDFS_GATED(gate);
   const double alpha = sc[SC_ALPHA];
   const bool early = sc[SC_EARLY] != 0.0;
   const double omega = early ? 0.0 : sc[SC_OMEGA];
@@ -263,7 +285,9 @@ k_bicg_update_xr(T* __restrict__ x, T* __restrict__ r, const T* __restrict__ p,
 
 // rr, next rho/beta and JAX's breakdown flags (k = -10 / -11 in its while_loop)
 __global__ void __launch_bounds__(VEC_BLOCK)
-k_bicg_iter_finish(const double* __restrict__ partial, int nb, double* __restrict__ sc) {
+k_bicg_iter_finish(const double* __restrict__ partial, int nb, double* __restrict__ sc,
+                   unsigned long long* gate = nullptr) {
+  SDFS_GATED(gate);
   const double rr = finish_sum(partial, nb, 0);
   const double rho_next = finish_sum(partial, nb, 1);
   if (threadIdx.x == 0) {
@@ -276,6 +300,9 @@ k_bicg_iter_finish(const double* __restrict__ partial, int nb, double* __restric
     sc[SC_RHO] = rho_new;
     sc[SC_RHO_NEW] = rho_next;
     sc[SC_BETA] = rho_next / rho_new * alpha / omega;
+    sc[SC_ITERS] += 1.0;
+    // the inner solve goes on while |r|^2 > atol2 and nothing broke down (a NaN |r|^2 fails the comparison)
+    if (gate != nullptr && !(rr > sc[SC_ATOL2] && brk == 0.0)) *gate = 0ULL;
   }
 }
 
