@@ -331,7 +331,7 @@ struct LineIO {
 };
 
 template <int N> struct LineGeo {
-  static constexpr int B = N <= 20 ? 256 : 512;                   // threads per workgroup
+  static constexpr int B = N <= 24 ? 256 : 512;                   // threads per workgroup (N = 24: 18 units per thread, two workgroups per CU)
   static constexpr int W = B / 64;
   static constexpr int UNITS = N * N * LINE_R / 2;                // double2 units per tile
   static constexpr int EPT = (UNITS + B - 1) / B;
@@ -778,7 +778,7 @@ inline line_fn line_variant(int n, int mode, bool persist, bool fullc, bool f32 
 }
 inline int slice_tile_slices(int n) { return n == 16 ? SliceGeo<16>::G : n == 20 ? SliceGeo<20>::G : n == 24 ? SliceGeo<24>::G : SliceGeo<32>::G; }
 inline size_t slice_lds_bytes(int n) { return (size_t)slice_tile_slices(n) * n * n * 8 * 4; }
-inline int line_block(int n) { return n <= 20 ? 256 : 512; }
+inline int line_block(int n) { return n <= 24 ? 256 : 512; }
 inline size_t line_lds_bytes(int n) { return (size_t)n * n * LINE_R * 8; }
 inline int line_blocks_per_cu(int n) { return n <= 16 ? LineGeo<16>::BPC : n == 20 ? LineGeo<20>::BPC : n == 24 ? LineGeo<24>::BPC : LineGeo<32>::BPC; }
 

@@ -224,8 +224,8 @@ __device__ __forceinline__ bool pow_fast_try(const double (&x)[N], double y, con
   SDFS_FORJ {
     const int hx = __double2hiint(x[j]);
     const int tmph = hx - OFFH;
-    rare |= (unsigned)(hx - 0x00100000) >= 0x7fe00000u;
-    i4[j] = (tmph >> 12) & 0xfc;
+    rare |= !__builtin_amdgcn_class(x[j], 0x100);      // anything but a positive normal number (one v_cmp_class_f64)
+    i4[j] = tmph >> 12;                                // table index * 4; ds_bpermute uses address bits [7:2] only
     kd[j] = (double)(tmph >> 20);
     z[j] = __hiloint2double(hx - (tmph & (int)0xfff00000), __double2loint(x[j]));
   }
@@ -267,7 +267,7 @@ __device__ __forceinline__ bool pow_fast_try(const double (&x)[N], double y, con
     kk -= SHIFT;
     f[j] = (ehi[j] - kk) + elo[j];
   }
-  SDFS_FORJ t[j] = gather64b(T.e2t, (ji[j] & 63) << 2);
+  SDFS_FORJ t[j] = gather64b(T.e2t, ji[j] << 2);          // lane = (address / 4) mod 64: no mask needed
   SDFS_FORJ p[j] = fma_sc(f[j], POW_E6, POW_E5);
   SDFS_FORJ p[j] = fma_sc(p[j], f[j], POW_E4);
   SDFS_FORJ p[j] = fma_sc(p[j], f[j], POW_E3);
@@ -839,8 +839,7 @@ inline pass_fn pass_kernel_variant_m(int ept, int vec) {
         case 1: return (pass_fn)pass_kernel<1, 4, MODE, PREC>;
         case 2: return (pass_fn)pass_kernel<2, 4, MODE, PREC>;
         case 4: return (pass_fn)pass_kernel<4, 4, MODE, PREC>;
-        case 8: return (pass_fn)pass_kernel<8, 4, MODE, PREC>;
-        default: return nullptr;
+        default: return nullptr;          // eight float4 units + their scaling stream spill: the planner stops at four
       }
     }
   }
@@ -851,7 +850,11 @@ inline pass_fn pass_kernel_variant_m(int ept, int vec) {
     case 2: return SDFS_V(2);
     case 4: return SDFS_V(4);
     case 8: return SDFS_V(8);
-    case 16: return SDFS_V(16);
+    case 16:
+      // sixteen double2 units spill in the J.v roles (tile + scaling stream in flight); the planner widens the
+      // block instead, so only the 8-byte form exists there
+      if constexpr (MODE == M_JFIRST || MODE == M_JLAST) return vec == 2 ? nullptr : (pass_fn)pass_kernel<16, 1, MODE, PREC>;
+      else return SDFS_V(16);
     default: return nullptr;
   }
 #undef SDFS_V

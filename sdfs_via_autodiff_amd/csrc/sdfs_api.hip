@@ -415,6 +415,9 @@ int build_plan(sdfs_handle* h, Plan& plan, const std::vector<int>& todo_in, std:
     auto round_ept = [](long long e) { int r = 1; while (r < e) r <<= 1; return r; };
     auto units_per_thread = [&](long long units) { return round_ept((units + P.block - 1) / P.block); };
     while (units_per_thread(tot) > 16 && P.block < 512) P.block += 64;
+    // 16 double2 units per thread spill in the J.v roles (the tile and its scaling stream are both in flight:
+    // 128 of the 128 VGPRs): widen the block instead
+    while (units_per_thread(tot / 2) > 8 && P.block < 512) P.block += 64;
     P.ept1 = units_per_thread(tot);
     if (P.ept1 > 16) return fail(h, SDFS_ERR_UNSUPPORTED, "tile too large for one block");
     // 16-byte accesses: runs along slot 2 must be even, contiguous and every base even
@@ -426,7 +429,7 @@ int build_plan(sdfs_handle* h, Plan& plan, const std::vector<int>& todo_in, std:
     P.ept2 = v2 ? units_per_thread(tot / 2) : P.ept1;
     bool v4 = v2 && (d.m[2] % 4 == 0) && (d.gstride[0] % 4 == 0 || d.m[0] == 1) && (d.gstride[1] % 4 == 0 || d.m[1] == 1);
     for (int k = 0; k < d.nfixed; ++k) if (d.fstride[k] % 4 != 0 && d.fext[k] > 1) v4 = false;
-    P.vec4 = v4 && units_per_thread(tot / 4) <= 8;
+    P.vec4 = v4 && units_per_thread(tot / 4) <= 4;        // eight float4 units + their scaling stream spill
     P.ept4 = P.vec4 ? units_per_thread(tot / 4) : P.ept2;
     char lab[96];
     int o = snprintf(lab, sizeof lab, "expect[");
