@@ -133,6 +133,7 @@ struct SliceIO {
   double* aux_out;          // T + linearise: c1 = w^(theta-1)
   const unsigned long long* gate;
   double gate_tol;
+  unsigned long long* zero; // if non-null: cleared by workgroup 0 (the residual word the last pass will atomicMax into)
 };
 
 template <int N> struct SliceGeo {
@@ -165,6 +166,7 @@ slice_kernel(const SliceDesc P, const SliceIO io) {
   }
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);     // wave-uniform: addresses below stay scalar
+  if (io.zero != nullptr && blockIdx.x == 0 && threadIdx.x == 0) *io.zero = 0ULL;   // ordered before the last pass by the launches in between
   const long long tile = (long long)blockIdx.x * Geo::WAVES + wave;
   const long long s0 = tile * Geo::G;
   if (s0 >= P.nslices) return;                                   // no workgroup barrier below

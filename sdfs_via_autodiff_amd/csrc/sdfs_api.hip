@@ -821,6 +821,7 @@ int run_fast_plan(sdfs_handle* h, int mode, const double* in, double* out, const
       SliceIO io;
       memset(&io, 0, sizeof io);
       io.in = pin; io.out = pout; io.gate = gate; io.gate_tol = gate_tol;
+      io.zero = (mode != MODE_JVP) ? resid : nullptr;        // the first pass clears the word the last pass maximises into
       int sm = S_TFIRST;
       if (mode == MODE_T_LIN) { sm = S_TFIRST_LIN; io.aux_out = h->c1; bytes += n8; }
       else if (mode == MODE_JVP) { sm = S_JFIRST; io.aux_in = vjp ? h->c2 : h->c1; bytes += n8; }
@@ -1827,7 +1828,8 @@ int sdfs_apply_T_dev(sdfs_handle* h, const double* w, double* Tw, double* resid_
   int rc = check(h); if (rc) return rc;
   if (!w || !Tw) return fail(h, SDFS_ERR_ARG, "NULL grid pointer");
   if (h->sharded) return fail(h, SDFS_ERR_ARG, "sharded handle: use sdfs_apply_stage_dev");
-  if (resid_dev) HIPCHK(h, hipMemsetAsync(resid_dev, 0, 8, h->stream));
+  // (the pair plan's first kernel clears the residual word itself: one launch less per step)
+  if (resid_dev && !(h->fast.ok && !h->cont && !h->dense)) HIPCHK(h, hipMemsetAsync(resid_dev, 0, 8, h->stream));
   return apply_T_dev(h, w, Tw, (unsigned long long*)resid_dev, nullptr, 0.0);
 }
 

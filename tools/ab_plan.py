@@ -14,8 +14,8 @@ import torch  # noqa: E402
 import sdfs_via_autodiff_amd as S  # noqa: E402
 
 VARIANTS = {
-    "pair o1 p2 (default)": {},
-    "pair o1 p0": {"SDFS_LINE_PERSIST": "0"},
+    "pair o1 p0 (default)": {},
+    "pair o1 p2": {"SDFS_LINE_PERSIST": "2"},
     "pair o1 p3": {"SDFS_LINE_PERSIST": "3"},
     "pair o0 p2": {"SDFS_PAIR_ORDER": "0"},
     "pair o0 p0": {"SDFS_PAIR_ORDER": "0", "SDFS_LINE_PERSIST": "0"},
