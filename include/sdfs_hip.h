@@ -184,6 +184,21 @@ int64_t sdfs_error_trace(sdfs_handle* h, double* out, int64_t cap);
 int sdfs_apply_stage_dev(sdfs_handle* h, int stage, int mode, const double* in_dev,
                          double* out_dev, const double* w_old_dev, double* resid_dev);
 
+/* Multi-GPU Krylov building blocks: the fused BLAS-1 kernels of the single-GPU BiCGSTAB / Newton loops
+ * (jax.scipy.sparse.linalg.bicgstab inside code/solvers.py:91-93) on caller-owned device vectors of `n` LOCAL
+ * elements -- this rank's shard -- with the scalar recurrences in the handle's device block.  A step either
+ * leaves the rank's partial sums in `sums_dev` (the caller all-reduces them, SUM; MAX for the Newton step) or
+ * consumes the all-reduced values from it.  v = {b, r, rhat, p, q, t, x} (b fp64; the others fp64, or fp32 when
+ * f32 != 0).  Sequence per solve:  INIT -> [all-reduce 1] -> INIT_FIN;  per iteration:  UPDATE_P, (q = J p - p by
+ * the caller), DOT_RQ -> [1] -> ALPHA_S -> [1] -> S_FIN, (t = J s - s, s lives in r), DOT_TS -> [2] -> OMEGA_XR
+ * -> [2] -> ITER_FIN; sdfs_krylov_scalars reads the block back (one synchronisation per iteration). */
+enum { SDFS_KS_INIT = 0, SDFS_KS_INIT_FIN, SDFS_KS_UPDATE_P, SDFS_KS_DOT_RQ, SDFS_KS_ALPHA_S, SDFS_KS_S_FIN,
+       SDFS_KS_DOT_TS, SDFS_KS_OMEGA_XR, SDFS_KS_ITER_FIN, SDFS_KS_SUB_DOT, SDFS_KS_NEWTON_UPDATE };
+enum { SDFS_SC_RR = 9, SDFS_SC_BB = 10, SDFS_SC_ATOL2 = 11, SDFS_SC_BREAK = 13, SDFS_SC_ITERS = 15 };   /* indices into the scalar block */
+int sdfs_krylov_step(sdfs_handle* h, int step, int64_t n, int f32, void* const* v, double* sums_dev,
+                     double rtol, double atol);
+int sdfs_krylov_scalars(sdfs_handle* h, double* out16_host);
+
 /* Profiling: when enabled every kernel launch is bracketed by HIP events on the
  * handle's stream; sdfs_get_counters synchronises and sums them. */
 int sdfs_set_profiling(sdfs_handle* h, int on);

@@ -1548,6 +1548,66 @@ int check(sdfs_handle* h) {
 
 }  // namespace
 
+namespace {
+template <typename T>
+int krylov_step_t(sdfs_handle* h, int step, long long n, void* const* v, double* sums, double rtol, double atol) {
+  const double* b = (const double*)v[0];
+  T *r = (T*)v[1], *rhat = (T*)v[2], *p = (T*)v[3], *q = (T*)v[4], *t = (T*)v[5], *x = (T*)v[6];
+  const int g = vec_grid(n);
+  hipStream_t st = h->stream;
+  const unsigned long long* nog = nullptr;
+  switch (step) {
+    case SDFS_KS_INIT:
+      hipLaunchKernelGGL(k_bicg_init<T>, dim3(g), dim3(VEC_BLOCK), 0, st, b, r, rhat, p, q, x, n);
+      hipLaunchKernelGGL(k_dot<T>, dim3(g), dim3(VEC_BLOCK), 0, st, (const T*)r, (const T*)r, n, h->partial, nog);
+      hipLaunchKernelGGL(k_presum, dim3(1), dim3(VEC_BLOCK), 0, st, (const double*)h->partial, g, 1, sums, nog);
+      break;
+    case SDFS_KS_INIT_FIN:
+      hipLaunchKernelGGL(k_bicg_init_finish, dim3(1), dim3(VEC_BLOCK), 0, st, (const double*)sums, 0, h->sc, rtol, atol, (unsigned long long*)nullptr);
+      break;
+    case SDFS_KS_UPDATE_P:
+      hipLaunchKernelGGL(k_bicg_update_p<T>, dim3(g), dim3(VEC_BLOCK), 0, st, (const T*)r, p, (const T*)q, n, h->sc, nog);
+      break;
+    case SDFS_KS_DOT_RQ:
+      hipLaunchKernelGGL(k_dot<T>, dim3(g), dim3(VEC_BLOCK), 0, st, (const T*)rhat, (const T*)q, n, h->partial, nog);
+      hipLaunchKernelGGL(k_presum, dim3(1), dim3(VEC_BLOCK), 0, st, (const double*)h->partial, g, 1, sums, nog);
+      break;
+    case SDFS_KS_ALPHA_S:
+      hipLaunchKernelGGL(k_bicg_alpha_finish, dim3(1), dim3(VEC_BLOCK), 0, st, (const double*)sums, 0, h->sc, nog);
+      hipLaunchKernelGGL(k_bicg_s<T>, dim3(g), dim3(VEC_BLOCK), 0, st, r, (const T*)q, n, h->sc, h->partial, nog);
+      hipLaunchKernelGGL(k_presum, dim3(1), dim3(VEC_BLOCK), 0, st, (const double*)h->partial, g, 1, sums, nog);
+      break;
+    case SDFS_KS_S_FIN:
+      hipLaunchKernelGGL(k_bicg_s_finish, dim3(1), dim3(VEC_BLOCK), 0, st, (const double*)sums, 0, h->sc, nog);
+      break;
+    case SDFS_KS_DOT_TS:
+      hipLaunchKernelGGL(k_dot2<T>, dim3(g), dim3(VEC_BLOCK), 0, st, (const T*)t, (const T*)r, n, h->partial, nog);
+      hipLaunchKernelGGL(k_presum, dim3(1), dim3(VEC_BLOCK), 0, st, (const double*)h->partial, g, 2, sums, nog);
+      break;
+    case SDFS_KS_OMEGA_XR:
+      hipLaunchKernelGGL(k_bicg_omega_finish, dim3(1), dim3(VEC_BLOCK), 0, st, (const double*)sums, 0, h->sc, nog);
+      hipLaunchKernelGGL(k_bicg_update_xr<T>, dim3(g), dim3(VEC_BLOCK), 0, st, x, r, (const T*)p, (const T*)t, (const T*)rhat, n, h->sc, h->partial, nog);
+      hipLaunchKernelGGL(k_presum, dim3(1), dim3(VEC_BLOCK), 0, st, (const double*)h->partial, g, 2, sums, nog);
+      break;
+    case SDFS_KS_ITER_FIN:
+      hipLaunchKernelGGL(k_bicg_iter_finish, dim3(1), dim3(VEC_BLOCK), 0, st, (const double*)sums, 0, h->sc, (unsigned long long*)nullptr);
+      break;
+    case SDFS_KS_SUB_DOT:        // v[0] = out g (fp64), v[1] = a, v[2] = b (fp64): g = a - b, sums[0] = <g, g> (local)
+      hipLaunchKernelGGL(k_sub_dot, dim3(g), dim3(VEC_BLOCK), 0, st, (const double*)v[1], (const double*)v[2], (double*)v[0], n, h->partial);
+      hipLaunchKernelGGL(k_presum, dim3(1), dim3(VEC_BLOCK), 0, st, (const double*)h->partial, g, 1, sums, nog);
+      break;
+    case SDFS_KS_NEWTON_UPDATE:  // v[0] = x (fp64, in place), v[6] = step (T); sums[0] = max|step| of this rank (NaN -> inf)
+      HIPCHK(h, hipMemsetAsync(sums, 0, 8, st));
+      hipLaunchKernelGGL(k_newton_update<T>, dim3(g), dim3(VEC_BLOCK), 0, st, (const double*)v[0], (const T*)x, (double*)v[0], n, (unsigned long long*)sums);
+      break;
+    default:
+      return fail(h, SDFS_ERR_ARG, "unknown Krylov step %d", step);
+  }
+  HIPCHK(h, hipGetLastError());
+  return 0;
+}
+}  // namespace
+
 // ===========================================================================
 extern "C" {
 
@@ -1961,6 +2021,24 @@ int sdfs_apply_stage_dev(sdfs_handle* h, int stage, int mode, const double* in, 
   return run_plan(h, h->plan[stage], mode, stage == 0, stage == 1, in, out, old,
                   stage == 1 ? (unsigned long long*)resid_dev : nullptr, nullptr, 0.0,
                   (mode == MODE_JVP && old) ? 1 : 0);
+}
+
+int sdfs_krylov_step(sdfs_handle* h, int step, int64_t n, int f32, void* const* v, double* sums_dev, double rtol, double atol) {
+  int rc = check(h); if (rc) return rc;
+  if (!v || !sums_dev || n < 1) return fail(h, SDFS_ERR_ARG, "bad argument");
+  if ((rc = ensure_scalars(h))) return rc;
+  return f32 ? krylov_step_t<float>(h, step, (long long)n, v, sums_dev, rtol, atol)
+             : krylov_step_t<double>(h, step, (long long)n, v, sums_dev, rtol, atol);
+}
+
+int sdfs_krylov_scalars(sdfs_handle* h, double* out) {
+  int rc = check(h); if (rc) return rc;
+  if (!out) return fail(h, SDFS_ERR_ARG, "NULL pointer");
+  if ((rc = ensure_scalars(h))) return rc;
+  HIPCHK(h, hipMemcpyAsync(h->sc_host, h->sc, sizeof(double) * SC_COUNT, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  memcpy(out, h->sc_host, sizeof(double) * SC_COUNT);
+  return 0;
 }
 
 int sdfs_set_profiling(sdfs_handle* h, int on) {

@@ -60,7 +60,9 @@ __device__ __forceinline__ void block_partials(const double (&v)[NV], double* __
 }
 
 // sum `nb` partials of stream k inside ONE block (finishing kernels)
+// nb <= 0: `partial` already holds the finished (multi-GPU: all-reduced) sums, one per stream
 __device__ __forceinline__ double finish_sum(const double* __restrict__ partial, int nb, int k) {
+  if (nb <= 0) return partial[k];
   __shared__ double sm[VEC_BLOCK / 64];
   double s = 0.0;
   for (int i = threadIdx.x; i < nb; i += blockDim.x) s += partial[i + (size_t)k * nb];
@@ -71,6 +73,18 @@ __device__ __forceinline__ double finish_sum(const double* __restrict__ partial,
   double t = 0.0;
   for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += sm[w];
   return t;
+}
+
+// one block: out[k] = sum of partial stream k (the local sums a rank hands to the all-reduce)
+__global__ void __launch_bounds__(VEC_BLOCK)
+k_presum(const double* __restrict__ partial, int nb, int nsums, double* __restrict__ out,
+         const unsigned long long* gate = nullptr) {
+  SDFS_GATED(gate);
+  for (int k = 0; k < nsums; ++k) {
+    const double s = finish_sum(partial, nb, k);
+    if (threadIdx.x == 0) out[k] = s;
+    __syncthreads();
+  }
 }
 
 // ---- generic helpers --------------------------------------------------------

@@ -361,11 +361,89 @@ def successive_approx_sharded(op, w_loc, tol=1e-7, max_iter=1000000, errors=None
     return w_loc, it
 
 
+KS_INIT, KS_INIT_FIN, KS_UPDATE_P, KS_DOT_RQ, KS_ALPHA_S, KS_S_FIN, KS_DOT_TS, KS_OMEGA_XR, KS_ITER_FIN, KS_SUB_DOT, \
+    KS_NEWTON_UPDATE = range(11)
+SC_RR, SC_BB, SC_ATOL2, SC_BREAK, SC_ITERS = 9, 10, 11, 13, 15
+
+
+class HipKrylov:
+    """The fused BLAS-1 kernels of the single-GPU BiCGSTAB / Newton loops (csrc/vec_kernels.hpp) on this rank's
+    shard, through sdfs_krylov_step: the scalar recurrences stay on the device, each fused group of inner products
+    is one all-reduce of a two-double device tensor, and the only host-visible step of an iteration is reading the
+    scalar block back."""
+
+    def __init__(self, op):
+        self.op = op
+        self.h = op.backend._h
+        self.sums = None
+
+    def _step(self, step, n, vecs, rtol=0.0, atol=0.0):
+        arr = (C.c_void_p * 7)(*[(v.data_ptr() if v is not None else None) for v in vecs])
+        check(lib.sdfs_krylov_step(self.h, step, n, 0, arr, self.sums.data_ptr(), rtol, atol), self.h)
+
+    def scalars(self):
+        out = (C.c_double * 16)()
+        check(lib.sdfs_krylov_scalars(self.h, out), self.h)
+        return list(out)
+
+    def bicgstab(self, b, tol, atol, maxiter, stats=None):
+        op = self.op
+        if self.sums is None:
+            self.sums = torch.zeros(2, dtype=torch.float64, device=b.device)
+        n = b.numel()
+        r, rhat, p, q, t, x = (torch.empty_like(b) for _ in range(6))
+        V = [b, r, rhat, p, q, t, x]
+        self._step(KS_INIT, n, V)
+        op.allreduce_sum(self.sums[:1])
+        self._step(KS_INIT_FIN, n, V, tol, atol)
+        sc = self.scalars()
+        k = 0
+        while sc[SC_RR] > sc[SC_ATOL2] and k < maxiter:
+            self._step(KS_UPDATE_P, n, V)
+            q.copy_(op.jvp(p).sub_(p))
+            self._step(KS_DOT_RQ, n, V)
+            op.allreduce_sum(self.sums[:1])
+            self._step(KS_ALPHA_S, n, V)                 # alpha, s = r - alpha q (in r), local <s, s>
+            op.allreduce_sum(self.sums[:1])
+            self._step(KS_S_FIN, n, V)
+            t.copy_(op.jvp(r).sub_(r))
+            self._step(KS_DOT_TS, n, V)
+            op.allreduce_sum(self.sums[:2])
+            self._step(KS_OMEGA_XR, n, V)                # omega, x and r updates, local <r, r>, <rhat, r>
+            op.allreduce_sum(self.sums[:2])
+            self._step(KS_ITER_FIN, n, V)
+            sc = self.scalars()                          # the one host-visible step of the iteration
+            if stats is not None:
+                stats["matvecs"] = stats.get("matvecs", 0) + 2
+            if sc[SC_BREAK] != 0.0 or not np.isfinite(sc[SC_RR]):
+                break
+            k += 1
+        return x
+
+    def residual(self, Tw, w):
+        """g = T(w) - w"""
+        g = torch.empty_like(w)
+        self._step(KS_SUB_DOT, w.numel(), [g, Tw, w, None, None, None, None])
+        return g
+
+    def newton_update(self, w, step):
+        """w -= step in place; returns the all-reduced max|step| (NaN -> inf)"""
+        self._step(KS_NEWTON_UPDATE, w.numel(), [w, None, None, None, None, None, step])
+        m = self.sums[:1]
+        self.op.allreduce_max(m)
+        return float(m.item())
+
+
 def bicgstab_sharded(op, b, tol=1e-5, atol=0.0, maxiter=None, stats=None):
     """BiCGSTAB for (dT(w) - I) x = b on sharded vectors, JAX stopping rule, x0 = 0."""
     n_global = int(np.prod(op.shapes))
     maxiter = 10 * n_global if maxiter is None else maxiter
     maxiter = min(maxiter, 100000)
+    if isinstance(op.backend, HipStages):
+        if getattr(op, "_krylov", None) is None:
+            op._krylov = HipKrylov(op)
+        return op._krylov.bicgstab(b, tol, atol, maxiter, stats)
+    # CPU rehearsal (numpy-oracle stage backend): the same recurrences with torch arithmetic
     mv = lambda u: op.jvp(u) - u
     (bb,) = op.dots([(b, b)])
     atol2 = max(tol * tol * bb, atol * atol)
@@ -407,15 +485,25 @@ def bicgstab_sharded(op, b, tol=1e-5, atol=0.0, maxiter=None, stats=None):
 def newton_sharded(op, w_loc, tol=1e-7, max_iter=1000000, inner_rtol=1e-5, inner_atol=1e-4,
                    errors=None, stats=None):
     it, err = 0, tol + 1
+    hip = isinstance(op.backend, HipStages)
+    if hip:
+        if getattr(op, "_krylov", None) is None:
+            op._krylov = HipKrylov(op)
+        w_loc = w_loc.clone()
+        op._krylov.sums = torch.zeros(2, dtype=torch.float64, device=w_loc.device)
     while err > tol and it < max_iter:
         Tw = op.linearize(w_loc)
-        step = bicgstab_sharded(op, Tw - w_loc, tol=inner_rtol, atol=inner_atol, stats=stats)
-        m = step.abs().max().reshape(1)
-        m = torch.where(torch.isnan(m), torch.full_like(m, float("inf")), m)
-        err = float(op.allreduce_max(m).item())
+        if hip:
+            step = bicgstab_sharded(op, op._krylov.residual(Tw, w_loc), tol=inner_rtol, atol=inner_atol, stats=stats)
+            err = op._krylov.newton_update(w_loc, step)
+        else:
+            step = bicgstab_sharded(op, Tw - w_loc, tol=inner_rtol, atol=inner_atol, stats=stats)
+            m = step.abs().max().reshape(1)
+            m = torch.where(torch.isnan(m), torch.full_like(m, float("inf")), m)
+            err = float(op.allreduce_max(m).item())
+            w_loc = w_loc - step
         if errors is not None:
             errors.append(err)
-        w_loc = w_loc - step
         it += 1
         if not np.isfinite(err):
             break
