@@ -198,6 +198,11 @@ enum { SDFS_SC_RR = 9, SDFS_SC_BB = 10, SDFS_SC_ATOL2 = 11, SDFS_SC_BREAK = 13, 
 int sdfs_krylov_step(sdfs_handle* h, int step, int64_t n, int f32, void* const* v, double* sums_dev,
                      double rtol, double atol);
 int sdfs_krylov_scalars(sdfs_handle* h, double* out16_host);
+/* Sharded handles: fp32 storage of the J.v streams and of the linearisation (opts.krylov_f32 of the single-GPU
+ * solve) for the stage calls that follow.  `w_ref`: one positive value shared by all ranks (e.g. the geometric
+ * mean of the all-reduced min and max of the iterate) from which every rank and both stages derive the same
+ * power-of-two scale of c1 / c2. */
+int sdfs_set_krylov_f32(sdfs_handle* h, int on, double w_ref);
 
 /* Profiling: when enabled every kernel launch is bracketed by HIP events on the
  * handle's stream; sdfs_get_counters synchronises and sums them. */

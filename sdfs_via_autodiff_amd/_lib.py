@@ -74,6 +74,7 @@ SYMBOLS = {
     "sdfs_apply_stage_dev": (C.c_int, [_P, C.c_int, C.c_int, _P, _P, _P, _P]),
     "sdfs_krylov_step": (C.c_int, [_P, C.c_int, C.c_int64, C.c_int, C.POINTER(_P), _P, C.c_double, C.c_double]),
     "sdfs_krylov_scalars": (C.c_int, [_P, _P]),
+    "sdfs_set_krylov_f32": (C.c_int, [_P, C.c_int, C.c_double]),
     "sdfs_set_profiling": (C.c_int, [_P, C.c_int]),
     "sdfs_reset_counters": (C.c_int, [_P]),
     "sdfs_get_counters": (C.c_int, [_P, C.POINTER(sdfs_counters)]),

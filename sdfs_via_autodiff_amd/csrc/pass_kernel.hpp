@@ -70,6 +70,8 @@ struct PassDesc {
   long long ntiles;
   int ablate;                  // -DSDFS_DIAG builds only (SDFS_ABLATE): 1 = skip the powers, 2 = skip the contractions
   long long ref_off;           // grid offset of the mid-grid point (reference of the fp32 c1 / c2 scaling)
+  double lin_ref;              // > 0: use this value as the reference instead (sharded handles: every rank and
+                               // both stages must derive the same power of two, sdfs_set_krylov_f32)
 };
 
 struct PassIO {
@@ -654,7 +656,7 @@ pass_kernel(const PassDesc P, const PassIO io) {
   // input, the last pass from the grid it forms the residual against, so both arrive at the same k.
   double lin_scale = 1.0;
   if (F_AUXOUT) {
-    const double wref[1] = {LINP ? io.in[P.ref_off] : io.old[P.ref_off]};
+    const double wref[1] = {P.lin_ref > 0.0 ? P.lin_ref : (LINP ? io.in[P.ref_off] : io.old[P.ref_off])};
     double xr[1];
     pow_fast_n<true, 1>(wref, P.theta, PT, xr);
     const int k = -ilogb(xr[0] / wref[0]);

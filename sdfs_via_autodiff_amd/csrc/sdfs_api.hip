@@ -129,6 +129,7 @@ struct sdfs_handle {
 
   // Newton-Krylov with fp32 Krylov vectors / J.v streams (opts.krylov_f32); set while such a solve runs
   bool krylov_f32 = false;
+  double lin_ref = 0.0;              // sharded handles: reference value of the fp32 linearisation scale (sdfs_set_krylov_f32)
 
   // continuous-state operator (sdfs_create_continuous): no plan, one kernel per application
   bool cont = false;
@@ -517,6 +518,7 @@ int launch_pass(sdfs_handle* h, Pass& P, int pro, int epi, const PassIO& io, int
   d.ablate = h->knobs.ablate;            // always 0 unless built with -DSDFS_DIAG
   d.a3 = (epi == EPI_CES || epi == EPI_CES_LIN) ? h->a3 : nullptr;
   d.ref_off = 0;
+  d.lin_ref = h->sharded ? h->lin_ref : 0.0;
   if (!h->sharded) {                       // C-order offset of the mid-grid point
     long long stride = 1;
     for (int a = h->ndim - 1; a >= 0; --a) { d.ref_off += (long long)(h->shape[a] / 2) * stride; stride *= h->shape[a]; }
@@ -2029,6 +2031,15 @@ int sdfs_krylov_step(sdfs_handle* h, int step, int64_t n, int f32, void* const* 
   if ((rc = ensure_scalars(h))) return rc;
   return f32 ? krylov_step_t<float>(h, step, (long long)n, v, sums_dev, rtol, atol)
              : krylov_step_t<double>(h, step, (long long)n, v, sums_dev, rtol, atol);
+}
+
+int sdfs_set_krylov_f32(sdfs_handle* h, int on, double w_ref) {
+  int rc = check(h); if (rc) return rc;
+  if (!h->sharded) return fail(h, SDFS_ERR_ARG, "sdfs_set_krylov_f32 is for sharded handles (opts.krylov_f32 otherwise)");
+  if (on && !(w_ref > 0.0 && std::isfinite(w_ref))) return fail(h, SDFS_ERR_ARG, "reference value must be positive and finite");
+  h->krylov_f32 = on != 0;
+  h->lin_ref = on ? w_ref : 0.0;
+  return 0;
 }
 
 int sdfs_krylov_scalars(sdfs_handle* h, double* out) {

@@ -85,9 +85,18 @@ class HipStages:
         self.shape1 = list(self.shapes); self.shape1[axis_b] = b_len
         check(lib.sdfs_set_stream(self._h, torch.cuda.current_stream(self.device).cuda_stream, 0), self._h)
 
+    def set_krylov_f32(self, on, w_ref=0.0):
+        """fp32 storage of the J.v streams / linearisation for the stage calls that follow (config 5); w_ref: the
+        reference value all ranks derive the c1 / c2 scale from."""
+        check(lib.sdfs_set_krylov_f32(self._h, int(on), float(w_ref)), self._h)
+        self.f32 = bool(on)
+
     def run(self, stage, mode, x, old=None, resid=None):
         """resid: 1-element device tensor that receives max|out - old| (stage 1, T modes)."""
-        out = torch.empty(self.shape0 if stage == 0 else self.shape1, dtype=torch.float64, device=self.device)
+        dt = torch.float32 if (getattr(self, "f32", False) and mode == MODE_JVP) else torch.float64
+        if x.dtype != dt:
+            raise TypeError(f"stage input is {x.dtype}, expected {dt}")
+        out = torch.empty(self.shape0 if stage == 0 else self.shape1, dtype=dt, device=self.device)
         check(lib.sdfs_apply_stage_dev(self._h, stage, mode, x.data_ptr(), out.data_ptr(),
                                        old.data_ptr() if old is not None else None,
                                        resid.data_ptr() if resid is not None else None), self._h)
@@ -377,22 +386,35 @@ class HipKrylov:
         self.h = op.backend._h
         self.sums = None
 
-    def _step(self, step, n, vecs, rtol=0.0, atol=0.0):
+    def _step(self, step, n, vecs, rtol=0.0, atol=0.0, f32=False):
         arr = (C.c_void_p * 7)(*[(v.data_ptr() if v is not None else None) for v in vecs])
-        check(lib.sdfs_krylov_step(self.h, step, n, 0, arr, self.sums.data_ptr(), rtol, atol), self.h)
+        check(lib.sdfs_krylov_step(self.h, step, n, int(f32), arr, self.sums.data_ptr(), rtol, atol), self.h)
 
     def scalars(self):
         out = (C.c_double * 16)()
         check(lib.sdfs_krylov_scalars(self.h, out), self.h)
         return list(out)
 
-    def bicgstab(self, b, tol, atol, maxiter, stats=None):
+    def bicgstab(self, b, tol, atol, maxiter, stats=None, f32=False):
+        """f32: Krylov vectors (and, with the backend switched by set_krylov_f32, every J.v stream and both
+        exchanges) in fp32 storage; b, all sums and the scalar recurrences stay fp64."""
         op = self.op
         if self.sums is None:
             self.sums = torch.zeros(2, dtype=torch.float64, device=b.device)
         n = b.numel()
-        r, rhat, p, q, t, x = (torch.empty_like(b) for _ in range(6))
+        r, rhat, p, q, t, x = (torch.empty(b.shape, dtype=torch.float32 if f32 else torch.float64, device=b.device)
+                               for _ in range(6))
         V = [b, r, rhat, p, q, t, x]
+        _plain = self._step
+        self._step = lambda s_, n_, v_, rtol=0.0, atol=0.0: _plain(s_, n_, v_, rtol, atol, f32)
+        try:
+            return self._bicgstab_loop(V, n, tol, atol, maxiter, stats)
+        finally:
+            self._step = _plain
+
+    def _bicgstab_loop(self, V, n, tol, atol, maxiter, stats):
+        op = self.op
+        b, r, rhat, p, q, t, x = V
         self._step(KS_INIT, n, V)
         op.allreduce_sum(self.sums[:1])
         self._step(KS_INIT_FIN, n, V, tol, atol)
@@ -428,13 +450,13 @@ class HipKrylov:
 
     def newton_update(self, w, step):
         """w -= step in place; returns the all-reduced max|step| (NaN -> inf)"""
-        self._step(KS_NEWTON_UPDATE, w.numel(), [w, None, None, None, None, None, step])
+        self._step(KS_NEWTON_UPDATE, w.numel(), [w, None, None, None, None, None, step], f32=step.dtype == torch.float32)
         m = self.sums[:1]
         self.op.allreduce_max(m)
         return float(m.item())
 
 
-def bicgstab_sharded(op, b, tol=1e-5, atol=0.0, maxiter=None, stats=None):
+def bicgstab_sharded(op, b, tol=1e-5, atol=0.0, maxiter=None, stats=None, f32=False):
     """BiCGSTAB for (dT(w) - I) x = b on sharded vectors, JAX stopping rule, x0 = 0."""
     n_global = int(np.prod(op.shapes))
     maxiter = 10 * n_global if maxiter is None else maxiter
@@ -442,7 +464,7 @@ def bicgstab_sharded(op, b, tol=1e-5, atol=0.0, maxiter=None, stats=None):
     if isinstance(op.backend, HipStages):
         if getattr(op, "_krylov", None) is None:
             op._krylov = HipKrylov(op)
-        return op._krylov.bicgstab(b, tol, atol, maxiter, stats)
+        return op._krylov.bicgstab(b, tol, atol, maxiter, stats, f32=f32)
     # CPU rehearsal (numpy-oracle stage backend): the same recurrences with torch arithmetic
     mv = lambda u: op.jvp(u) - u
     (bb,) = op.dots([(b, b)])
@@ -483,20 +505,45 @@ def bicgstab_sharded(op, b, tol=1e-5, atol=0.0, maxiter=None, stats=None):
 
 
 def newton_sharded(op, w_loc, tol=1e-7, max_iter=1000000, inner_rtol=1e-5, inner_atol=1e-4,
-                   errors=None, stats=None):
+                   errors=None, stats=None, krylov_f32=False):
+    """krylov_f32 (HIP stages only): the inner solve in fp32 storage -- Krylov vectors, c1 / c2, every J.v stream and
+    both exchanges of a J.v application (half the bytes per link); outer residual, iterate and all sums fp64.  A step
+    whose fp32 linearisation overflows (iterate still far from the fixed point) is redone in fp64."""
     it, err = 0, tol + 1
     hip = isinstance(op.backend, HipStages)
+    f32 = bool(krylov_f32) and hip
+    f32_failures = 0
     if hip:
         if getattr(op, "_krylov", None) is None:
             op._krylov = HipKrylov(op)
         w_loc = w_loc.clone()
         op._krylov.sums = torch.zeros(2, dtype=torch.float64, device=w_loc.device)
     while err > tol and it < max_iter:
-        Tw = op.linearize(w_loc)
         if hip:
-            step = bicgstab_sharded(op, op._krylov.residual(Tw, w_loc), tol=inner_rtol, atol=inner_atol, stats=stats)
-            err = op._krylov.newton_update(w_loc, step)
+            use32 = f32 and f32_failures < 3
+            if use32:
+                mm = torch.stack([w_loc.max(), -w_loc.min()])
+                op.allreduce_max(mm)
+                hi, lo = float(mm[0].item()), -float(mm[1].item())
+                use32 = lo > 0.0 and np.isfinite(hi)
+                if use32:
+                    op.backend.set_krylov_f32(True, float(np.sqrt(hi * lo)))
+                    keep = w_loc.clone()
+            try:
+                Tw = op.linearize(w_loc)
+                step = bicgstab_sharded(op, op._krylov.residual(Tw, w_loc), tol=inner_rtol, atol=inner_atol, stats=stats,
+                                        f32=use32)
+                err = op._krylov.newton_update(w_loc, step)
+            finally:
+                if use32:
+                    op.backend.set_krylov_f32(False)
+            if use32 and not np.isfinite(err):
+                w_loc.copy_(keep)
+                f32_failures += 1
+                err = tol + 1
+                continue
         else:
+            Tw = op.linearize(w_loc)
             step = bicgstab_sharded(op, Tw - w_loc, tol=inner_rtol, atol=inner_atol, stats=stats)
             m = step.abs().max().reshape(1)
             m = torch.where(torch.isnan(m), torch.full_like(m, float("inf")), m)

@@ -143,6 +143,12 @@ def body(rank, model, shapes, use_hip, plain=False):
         xs = osol.newton_polish(T, J, x.copy())
         out["newton_err"] = float(np.max(np.abs(x - xs)))
         out["newton_iters"] = n
+        if use_hip:
+            # BASELINE config 5 sharded: fp32 Krylov vectors, J.v streams and exchange buffers, fp64 outer residual
+            x_loc32, n32 = D.newton_sharded(op, op.scatter_from_full(torch.full(shapes, 800.0, dtype=torch.float64)).to(dev),
+                                            tol=1e-10, max_iter=30, inner_rtol=1e-6, inner_atol=0.0, krylov_f32=True)
+            out["newton_f32_err"] = float(np.max(np.abs(op.gather_full(x_loc32).cpu().numpy() - xs)))
+            out["newton_f32_iters"] = n32
         # distributed SA: same iteration count as the single-process oracle loop
         out["mirror_ok"] = bool(op.mirror_ok)
         errs, stats = [], {}

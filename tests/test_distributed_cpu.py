@@ -92,6 +92,7 @@ def test_sharded_hip_stages_world2(model, shapes):
     assert out["T"] < 1e-12 and out["Tlin"] < 1e-12 and out["jvp"] < 1e-11, out
     assert out["resid"] < 1e-8
     assert out["newton_err"] < 1e-8 and out["newton_iters"] < 20, out
+    assert out["newton_f32_err"] < 1e-8 and out["newton_f32_iters"] < 25, out      # fp32 Krylov storage, fp64 fixed point
     assert out["sa_iters"][0] == out["sa_iters"][1] and out["sa_err"] < 1e-8, out
 
 
@@ -104,6 +105,7 @@ def test_sharded_hip_stages_plain_tensors_mirror(model, shapes):
     assert "newton_err" in out, out
     assert out["T"] < 1e-12 and out["Tlin"] < 1e-12 and out["jvp"] < 1e-11, out
     assert out["resid"] < 1e-8 and out["newton_err"] < 1e-8
+    assert out["newton_f32_err"] < 1e-8, out
     assert out["mirror_ok"]
     na, no = out["sa_iters"]
     assert na == no and out["sa_err"] < 1e-8, out
