@@ -725,6 +725,295 @@ line_kernel(const LineDesc P, const LineIO io) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Small grids (every extent <= 16; SSY 15^4 of BASELINE configs 1 and 2 is 405 KB): the same pair plan with
+// run-time extents.  Such a grid lives in L2 and a pass is bound by its own critical path -- launch (1.55 us
+// per graph node, tools/probes/launch_floor_probe.hip), one global round trip, the power's ~280 dependent
+// instructions per two points, one more round trip -- so the plan wants few launches with little work per
+// wave: D/2 passes, one WAVE per tile, no workgroup barrier on the data path.
+// A tile is all nx x ny (x, y) rows of R consecutive positions of the contiguous remainder behind Y (R = 1:
+// every pass is then a set of strided 2-D slices, <= 4 points per lane; R = 4: 32-byte runs for the larger of
+// these grids).  The tile sits in LDS padded to 16 x 16 x R with zeros, the matrices are padded to 16 x 16
+// with zero rows and columns: padded outputs are exact zeros, so ctile<16, .> runs unmasked.
+// SM_FUSED_T: the last pass of one application of T and the first pass of the next in one kernel (successive
+// approximation with the pair order reversed every iteration, so that both act on the same pair): contract,
+// aggregator, residual, store Tw, then (Tw)^theta and the same two contractions again, into the intermediate.
+#ifndef SDFS_STAMP
+#define SDFS_STAMP(i)       // tools/probes/small_fused_probe.hip defines it: phase time stamps of workgroup 0
+#endif
+enum SmallMode { SM_FIRST_T = 0, SM_FIRST_TLIN = 1, SM_FIRST_J = 2, SM_MID = 3, SM_LAST_T = 4, SM_LAST_TLIN = 5, SM_LAST_J = 6, SM_FUSED_T = 7, SM_NMODES = 8 };
+
+struct SmallDesc {
+  int nx, ny;               // extents of the contracted pair (X slower)
+  unsigned my;              // ceil(65536 / ny): row / ny == (row * my) >> 16 for row < 256
+  unsigned sx, sy;          // element strides of X and Y
+  long long ostride;        // element stride of the outer index (all axes before X, or the slice index)
+  unsigned lrest;           // positions behind Y
+  unsigned nchunks;         // ceil(lrest / R)
+  long long ntiles;         // nouter * nchunks
+  const double* Qxp;        // 16 x 16 zero-padded matrices
+  const double* Qyp;
+  double theta, inv_theta, beta;
+  const double* a3;         // aggregator scale: index = out_idx[o] + x * a3x + y * a3y + rest_idx[pos]
+  const int* out_idx;
+  const int* rest_idx;
+  int a3x, a3y;
+  int minus_identity;
+};
+
+struct SmallIO {
+  const double* in;
+  double* out;
+  const double* aux_in;     // first pass of J.v: c1;  last pass of J.v: c2
+  double* aux_out;          // linearising T: first pass writes c1, last pass c2;  fused form: the next intermediate
+  const double* old;        // last pass of T: w (residual);  of J.v: v
+  unsigned long long* resid;
+  const unsigned long long* gate;
+  double gate_tol;
+  double* dotp;             // J.v with minus_identity: per-workgroup partial sums <out, v>, <out, out>: [2][gridDim.x]
+  unsigned long long* zero; // first pass: cleared by workgroup 0 (the residual word the last pass maximises into)
+};
+
+// element e of a tile -> LDS offset, global element offset against the tile base, a3 index part, position
+template <int R>
+__device__ __forceinline__ void small_decode(const SmallDesc& P, int e, int& l, unsigned& g, unsigned& ixy, int& r) {
+  const int row = R == 1 ? e : (e >> 2);
+  r = R == 1 ? 0 : (e & 3);
+  const int x = (int)(__umul24((unsigned)row, P.my) >> 16);
+  const int y = row - x * P.ny;
+  l = R == 1 ? x * 16 + y : x * 64 + y * 4 + r;
+  g = (unsigned)x * P.sx + (unsigned)y * P.sy + (unsigned)r;
+  ixy = __umul24((unsigned)x, (unsigned)P.a3x) + __umul24((unsigned)y, (unsigned)P.a3y);
+}
+
+template <int MODE, int R>
+__global__ void __launch_bounds__(256)
+small_tile_kernel(const SmallDesc P, const SmallIO io) {
+  constexpr bool POWP = MODE == SM_FIRST_T || MODE == SM_FIRST_TLIN;
+  constexpr bool LINP = MODE == SM_FIRST_TLIN;
+  constexpr bool MULP = MODE == SM_FIRST_J;
+  constexpr bool FUSED = MODE == SM_FUSED_T;
+  constexpr bool CES = MODE == SM_LAST_T || MODE == SM_LAST_TLIN || FUSED;
+  constexpr bool LINE = MODE == SM_LAST_TLIN;
+  constexpr bool MULE = MODE == SM_LAST_J;
+  constexpr int TILE = 256 * R;                // doubles per wave
+  constexpr int EPL = 4 * R;                   // elements per lane (padded tile / 64)
+  static_assert(R == 1 || R == 4, "run lengths");
+  __shared__ __attribute__((aligned(16))) double lds[4 * TILE];
+  __shared__ double red[12];
+  // the gate word is fetched first and tested behind the tile loads (nothing is written before the test)
+  const unsigned long long gate_word = io.gate != nullptr ? *io.gate : ~0ULL;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const long long t = (long long)blockIdx.x * 4 + wave;
+  SDFS_STAMP(0);
+  const bool active = t < P.ntiles;            // wave-uniform; idle waves fall through to the reductions
+  double rmax = 0.0, dot_yv = 0.0, dot_yy = 0.0;
+  bool rnan = false;
+  if (active) {
+    const unsigned o = (unsigned)t / P.nchunks, chunk = (unsigned)t - o * P.nchunks;
+    const long long base = (long long)o * P.ostride + (long long)chunk * R;
+    const int total = P.nx * P.ny * R;
+    const unsigned pos0 = chunk * R;
+    double* const wl = lds + wave * TILE;
+    const bool need_old = CES ? (io.resid != nullptr) : (MULE && P.minus_identity);
+    // ---- decode this lane's elements once ------------------------------------------------------------------
+    int l[EPL]; unsigned g[EPL], ia3[EPL]; bool ok[EPL];
+#pragma unroll
+    for (int k = 0; k < EPL; ++k) {
+      const int e = lane + 64 * k;
+      int r; unsigned ixy;
+      ok[k] = e < total;
+      small_decode<R>(P, ok[k] ? e : 0, l[k], g[k], ixy, r);
+      ok[k] = ok[k] && (R == 1 || pos0 + (unsigned)r < P.lrest);
+      if (!ok[k]) g[k] = 0u;
+      ia3[k] = ixy;
+      if (CES) ia3[k] = ok[k] ? (unsigned)(P.out_idx[o] + P.rest_idx[pos0 + (unsigned)r]) + ixy : 0u;
+    }
+    // ---- loads: the tile and, for the last pass, its side streams -- all in flight at once -----------------
+    const double* const inb = io.in + base;
+    double v[EPL], s1[EPL], s2[EPL];
+#pragma unroll
+    for (int k = 0; k < EPL; ++k) {
+      if (64 * k < total) {
+        v[k] = inb[g[k]];
+        if (MULP) s1[k] = io.aux_in[base + g[k]];
+        if ((CES || MULE) && need_old) s1[k] = io.old[base + g[k]];
+        if (CES) s2[k] = P.a3[ia3[k]];
+        if (MULE) s2[k] = io.aux_in[base + g[k]];
+      }
+    }
+    QFrag<16> q, q2;
+    q.load(P.Qxp, lane);
+    if (FUSED) q2.load(P.Qyp, lane);
+    SDFS_STAMP(1);
+    if (gate_word <= (unsigned long long)__double_as_longlong(io.gate_tol)) return;      // uniform over the grid
+    SDFS_STAMP(2);
+    if (io.zero != nullptr && blockIdx.x == 0 && tid == 0) *io.zero = 0ULL;
+    // ---- zero the padded tile, then park the data ------------------------------------------------------------
+#pragma unroll
+    for (int k = 0; k < 2 * R; ++k) *reinterpret_cast<double2*>(wl + 2 * (lane + 64 * k)) = make_double2(0.0, 0.0);
+    wave_lds_fence();
+    if (POWP) {
+      // x = w^theta (c1 = w^(theta-1)); masked lanes feed the power 1.  Four points per call: on these grids a
+      // wave is alone on its SIMD and the power's dependent chains, not its issue slots, set the pace
+      const PowLane PT = pow_lane_init(lane);
+#pragma unroll
+      for (int k = 0; k < EPL; k += 4) {
+        if (64 * k < total) {
+          double xin[4], xw[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) xin[j] = ok[k + j] ? v[k + j] : 1.0;
+          pow_fast_n<true, 4>(xin, P.theta, PT, xw);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            v[k + j] = xw[j];
+            if (LINP && ok[k + j]) io.aux_out[base + g[k + j]] = xw[j] / xin[j];
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < EPL; ++k) {
+      if (64 * k < total) {
+        if (MULP) v[k] *= s1[k];
+        if (ok[k]) wl[l[k]] = v[k];
+      }
+    }
+    wave_lds_fence();
+    const int li = lane & 15, lk = lane >> 4;
+    // ---- contraction over X (row stride 16 R), then over Y (row stride R) --------------------------------------
+    auto contract_pair = [&](const QFrag<16>& qx, const QFrag<16>& qy) {
+      if (R == 1) {
+        ctile<16, 16>(wl + li + lk * 16, qx);
+        wave_lds_fence();
+        ctile<16, 1>(wl + li * 16 + lk, qy);
+      } else {
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct)
+          if (4 * ct < P.ny) ctile<16, 64>(wl + 16 * ct + li + lk * 64, qx);
+        wave_lds_fence();
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct)
+          if (4 * ct < P.nx) ctile<16, 4>(wl + (4 * ct + (li >> 2)) * 64 + (li & 3) + lk * 4, qy);
+      }
+      wave_lds_fence();
+    };
+    if (!FUSED) q2.load(P.Qyp, lane);
+    SDFS_STAMP(3);
+    contract_pair(q, q2);
+    SDFS_STAMP(4);
+    // ---- epilogue -----------------------------------------------------------------------------------------------
+    double* const outb = io.out + base;
+    if (CES) {
+      // Tw = 1 + beta (a3 S)^(1/theta), c2 = beta u / S, |Tw - w|
+      const PowLane PT = pow_lane_init(lane);
+#pragma unroll
+      for (int k = 0; k < EPL; k += 4) {
+        if (64 * k < total) {
+          double sv[4], ks[4], uu[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { sv[j] = wl[l[k + j]]; ks[j] = ok[k + j] ? s2[k + j] * sv[j] : 1.0; }
+          pow_fast_n<false, 4>(ks, P.inv_theta, PT, uu);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            if (ok[k + j]) {
+              const double y = 1.0 + P.beta * uu[j];
+              if (LINE) io.aux_out[base + g[k + j]] = P.beta * uu[j] / sv[j];
+              if (need_old) {
+                const double r0 = fabs(y - s1[k + j]);
+                rnan |= (r0 != r0);
+                rmax = fmax(rmax, r0);
+              }
+              outb[g[k + j]] = y;
+              if (FUSED) v[k + j] = y;
+            }
+          }
+        }
+      }
+      SDFS_STAMP(5);
+      if (FUSED) {
+        // the next application's first pass on the same pair: x = (Tw)^theta, both contractions, into the intermediate
+        // (the padding of the LDS tile is still exact zeros)
+#pragma unroll
+        for (int k = 0; k < EPL; k += 4) {
+          if (64 * k < total) {
+            double xin[4], xw[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) xin[j] = ok[k + j] ? v[k + j] : 1.0;
+            pow_fast_n<true, 4>(xin, P.theta, PT, xw);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) if (ok[k + j]) wl[l[k + j]] = xw[j];
+          }
+        }
+        wave_lds_fence();
+        SDFS_STAMP(6);
+        contract_pair(q, q2);
+        SDFS_STAMP(7);
+        double* const tmpb = io.aux_out + base;
+#pragma unroll
+        for (int k = 0; k < EPL; ++k)
+          if (64 * k < total && ok[k]) tmpb[g[k]] = wl[l[k]];
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < EPL; ++k) {
+        if (64 * k < total && ok[k]) {
+          double y = wl[l[k]];
+          if (MULE) {
+            y *= s2[k];
+            if (P.minus_identity) {
+              y -= s1[k];
+              dot_yv = fma(y, s1[k], dot_yv);
+              dot_yy = fma(y, y, dot_yy);
+            }
+          }
+          outb[g[k]] = y;
+        }
+      }
+    }
+  }
+  SDFS_STAMP(8);
+  // ---- per-workgroup reductions (every wave of an open gate arrives) ------------------------------------------------
+  if (gate_word <= (unsigned long long)__double_as_longlong(io.gate_tol)) return;
+  if (MULE && io.dotp != nullptr) {
+#pragma unroll
+    for (int s = 32; s > 0; s >>= 1) { dot_yv += __shfl_xor(dot_yv, s); dot_yy += __shfl_xor(dot_yy, s); }
+    if (lane == 0) { red[wave] = dot_yv; red[4 + wave] = dot_yy; }
+    __syncthreads();
+    if (tid == 0) {
+      io.dotp[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+      io.dotp[gridDim.x + blockIdx.x] = (red[4] + red[5]) + (red[6] + red[7]);
+    }
+  }
+  if (CES && io.resid != nullptr) {
+    if (rnan) rmax = __longlong_as_double(0x7ff0000000000000LL);                // NaN -> +inf
+#pragma unroll
+    for (int s = 32; s > 0; s >>= 1) rmax = fmax(rmax, __shfl_xor(rmax, s));
+    if (lane == 0) red[8 + wave] = rmax;
+    __syncthreads();
+    if (tid == 0) atomicMax(io.resid, (unsigned long long)__double_as_longlong(fmax(fmax(red[8], red[9]), fmax(red[10], red[11]))));
+  }
+  SDFS_STAMP(9);
+}
+
+typedef void (*small_fn)(const SmallDesc, const SmallIO);
+template <int R> inline small_fn small_variant_r(int mode) {
+  switch (mode) {
+    case SM_FIRST_T: return R == 1 ? (small_fn)small_tile_kernel<SM_FIRST_T, 1> : nullptr;
+    case SM_FIRST_TLIN: return R == 1 ? (small_fn)small_tile_kernel<SM_FIRST_TLIN, 1> : nullptr;
+    case SM_FIRST_J: return R == 1 ? (small_fn)small_tile_kernel<SM_FIRST_J, 1> : nullptr;
+    case SM_MID: return (small_fn)small_tile_kernel<SM_MID, R>;
+    case SM_LAST_T: return (small_fn)small_tile_kernel<SM_LAST_T, R>;
+    case SM_LAST_TLIN: return (small_fn)small_tile_kernel<SM_LAST_TLIN, R>;
+    case SM_LAST_J: return (small_fn)small_tile_kernel<SM_LAST_J, R>;
+    case SM_FUSED_T: return (small_fn)small_tile_kernel<SM_FUSED_T, R>;
+    default: return nullptr;
+  }
+}
+// the first pass walks the two fastest axes: nothing lies behind Y, so its run length is 1
+inline small_fn small_variant(int mode, int r) { return r == 1 ? small_variant_r<1>(mode) : (r == 4 ? small_variant_r<4>(mode) : nullptr); }
+
 typedef void (*slice_fn)(const SliceDesc, const SliceIO);
 typedef void (*line_fn)(const LineDesc, const LineIO);
 

@@ -41,6 +41,8 @@ struct AxisInfo {
   int off = 0;          // global index of local index 0
   const double* Q = nullptr;   // device transition tensor [.., n, n]
   const double* Qt = nullptr;  // its transpose, for unconditional tensors only (the vector-Jacobian product)
+  const double* Qp = nullptr;  // unconditional, n <= 16: the matrix and its transpose zero-padded to 16 x 16
+  const double* Qtp = nullptr; // (small-grid pair plan)
   int qs[MAXD] = {0, 0, 0, 0, 0, 0};  // matrix-index stride per conditioning axis
   long long qcount = 0;        // number of n x n matrices in Q
   int a3s = 0;                 // index stride of this axis in the a3 table (when it is kept as a table)
@@ -78,11 +80,15 @@ struct FastPass {
   int ax0 = -1, ax1 = -1;      // the contracted pair (ax0 slower)
   SliceDesc sd;
   LineDesc ld;
+  bool small = false;          // small-grid form: run-time extents <= 16, one wave per tile (SmallDesc)
+  int r = 1;                   // its run length
+  SmallDesc sm;
   double q_bytes = 0, flops = 0;
   std::string label;
 };
 struct FastPlan {
   bool ok = false;
+  bool small = false;          // built from small_tile_kernel passes
   bool f32_ok = false;         // every line pass walks whole 16-element chunks: fp32 J.v forms exist
   std::vector<FastPass> passes;
 };
@@ -95,6 +101,9 @@ struct Knobs {
                                // (measured equal to one tile per workgroup at GCY 20^6, tools/ab_plan.py: off by default)
   int pair_order = 1;          // SDFS_PAIR_ORDER: 1 = line passes slowest pair first (the last pass then walks the faster pair), 0 = fastest first
   int plan = 0;                // SDFS_PLAN: 0 = automatic, 1 = "classic" (generic tiles only), 2 = "pair" (pair plan whenever legal)
+  int small_plan = 1;          // SDFS_SMALL_PLAN: 0 = never use the small-grid pair plan
+  int small_r = 0;             // SDFS_SMALL_R: force the run length of its line passes (1 or 4)
+  int sa_fused = 1;            // SDFS_SA_FUSED: 0 = successive approximation on the small-grid plan keeps one launch per pass
   int ablate = 0;              // SDFS_ABLATE, honoured only by -DSDFS_DIAG builds
 };
 
@@ -227,6 +236,9 @@ Knobs read_knobs() {
   k.cont_lds_cap = env_int("SDFS_CONT_LDS_CAP", 4000);
   k.pair_order = env_int("SDFS_PAIR_ORDER", 1);
   k.line_persist = env_int("SDFS_LINE_PERSIST", 0);
+  k.small_plan = env_int("SDFS_SMALL_PLAN", 1);
+  k.small_r = env_int("SDFS_SMALL_R", 0);
+  k.sa_fused = env_int("SDFS_SA_FUSED", 1);
   const char* pl = getenv("SDFS_PLAN");
   if (pl && !strcmp(pl, "classic")) k.plan = 1;
   else if (pl && !strcmp(pl, "pair")) k.plan = 2;
@@ -685,6 +697,7 @@ int upload_ints(sdfs_handle* h, const std::vector<int>& v, int** out) {
 
 int build_fast_plan(sdfs_handle* h) {
   h->fast.ok = false;
+  h->fast.small = false;
   h->fast.passes.clear();
   const int D = h->ndim;
   if (h->knobs.plan == 1 || h->sharded || h->cont || h->dense || (D != 4 && D != 6) || h->a3 == nullptr) return 0;
@@ -793,6 +806,86 @@ int build_fast_plan(sdfs_handle* h) {
   return 0;
 }
 
+// Small grids: every extent <= 16 (fast_kernels.hpp, small_tile_kernel).  Same pass structure as the pair plan:
+// the two fastest axes first, then the slower pairs, the aggregator in the last pass.
+int build_small_plan(sdfs_handle* h) {
+  const int D = h->ndim;
+  if (h->fast.ok || h->knobs.plan == 1 || h->knobs.small_plan == 0 || h->sharded || h->cont || h->dense ||
+      (D != 4 && D != 6) || h->a3 == nullptr) return 0;
+  // one wave per tile pays while the grid is latency-bound; from about half a million points on the generic tiles
+  // are faster (tools/ab_small.py: 8^6 25 us against 28 us per step, 10^6 58 us against 50 us)
+  if (h->N > 400000 && h->knobs.plan != 2) return 0;
+  if (h->N >= (1LL << 24)) return 0;                       // 24-bit index products, 32-bit element offsets
+  for (int a = 0; a < D; ++a) {
+    if (h->ax[a].qcount != 1 || h->shape[a] > 16 || !h->ax[a].Qp || !h->ax[a].Qtp) return 0;
+    for (int c = 0; c < D; ++c) if (h->ax[a].qs[c] != 0) return 0;
+    if (h->ax[a].a3s < 0 || h->ax[a].a3s >= (1 << 24)) return 0;
+  }
+  long long stride[MAXD];
+  { long long st = 1; for (int a = D - 1; a >= 0; --a) { stride[a] = st; st *= h->shape[a]; } }
+  std::vector<int> pairs;
+  pairs.push_back(D - 2);
+  {
+    std::vector<int> rest;
+    for (int a = D - 4; a >= 0; a -= 2) rest.push_back(a);
+    if (h->knobs.pair_order == 1) std::reverse(rest.begin(), rest.end());
+    pairs.insert(pairs.end(), rest.begin(), rest.end());
+  }
+  std::vector<FastPass> passes;
+  for (size_t i = 0; i < pairs.size(); ++i) {
+    const int a = pairs[i];
+    FastPass P;
+    P.small = true; P.line = i > 0; P.n = 16; P.ax0 = a; P.ax1 = a + 1;
+    memset(&P.sd, 0, sizeof P.sd); memset(&P.ld, 0, sizeof P.ld); memset(&P.sm, 0, sizeof P.sm);
+    SmallDesc& S = P.sm;
+    S.nx = h->shape[a]; S.ny = h->shape[a + 1];
+    S.my = (unsigned)((65536 + S.ny - 1) / S.ny);
+    const long long lrest = stride[a + 1];
+    const long long nouter = h->N / ((long long)S.nx * S.ny * lrest);
+    S.sx = (unsigned)(S.ny * lrest); S.sy = (unsigned)lrest; S.lrest = (unsigned)lrest;
+    S.ostride = (long long)S.nx * S.ny * lrest;
+    // 32-byte runs once there is a tile for every CU (tools/ab_small.py: 8^6 25 us against 41 us per step with
+    // single positions; 15^4, 57 tiles of four: 17.6 us against 11.7 us)
+    int r = 1;
+    if (lrest >= 4 && nouter * ((lrest + 3) / 4) >= (long long)h->num_cus) r = 4;
+    if (lrest > 1 && (h->knobs.small_r == 1 || h->knobs.small_r == 4)) r = h->knobs.small_r;
+    P.r = r;
+    S.nchunks = (unsigned)((lrest + r - 1) / r);
+    S.ntiles = nouter * S.nchunks;
+    if (S.ntiles >= (1LL << 31)) return 0;
+    S.Qxp = h->ax[a].Qp; S.Qyp = h->ax[a + 1].Qp;
+    S.theta = h->theta; S.inv_theta = 1.0 / h->theta; S.beta = h->beta;
+    S.a3x = h->ax[a].a3s; S.a3y = h->ax[a + 1].a3s;
+    P.q_bytes = 2 * 8.0 * 256; P.flops = 2.0 * (double)h->N * (S.nx + S.ny);
+    P.label = std::string(i == 0 ? "slices[" : "lines[") + h->ax[a].name + "," + h->ax[a + 1].name + "|wave " +
+              std::to_string(S.nx) + "x" + std::to_string(S.ny) + "x" + std::to_string(r) + "]";
+    // a3 index tables: the last pass of T needs them, and successive approximation ends on either end pair
+    if (i + 1 == pairs.size() || i == 0) {
+      std::vector<int> outv((size_t)nouter, 0), restv((size_t)lrest, 0);
+      for (long long o = 0; o < nouter; ++o) {
+        long long q = o; int idx = 0;
+        for (int c = a - 1; c >= 0; --c) { idx += (int)(q % h->shape[c]) * h->ax[c].a3s; q /= h->shape[c]; }
+        outv[(size_t)o] = idx;
+      }
+      for (long long q0 = 0; q0 < lrest; ++q0) {
+        long long q = q0; int idx = 0;
+        for (int c = D - 1; c > a + 1; --c) { idx += (int)(q % h->shape[c]) * h->ax[c].a3s; q /= h->shape[c]; }
+        restv[(size_t)q0] = idx;
+      }
+      int *od = nullptr, *rd = nullptr;
+      int rc;
+      if ((rc = upload_ints(h, outv, &od)) || (rc = upload_ints(h, restv, &rd))) return rc;
+      S.a3 = h->a3; S.out_idx = od; S.rest_idx = rd;
+    }
+    passes.push_back(P);
+  }
+  h->fast.passes = passes;
+  h->fast.f32_ok = false;
+  h->fast.small = true;
+  h->fast.ok = true;
+  return 0;
+}
+
 // persistent line kernel: at most its resident workgroups per CU, each walking tiles b, b + grid, ...
 unsigned line_grid(const sdfs_handle* h, const FastPass& P) {
   if (!P.persist) return (unsigned)P.ld.ntiles;
@@ -819,7 +912,31 @@ int run_fast_plan(sdfs_handle* h, int mode, const double* in, double* out, const
     double bytes = 2 * n8 + P.q_bytes;
     const double* pin = (i == 0) ? in : h->tmp;
     double* pout = last ? out : h->tmp;
-    if (!P.line) {
+    if (P.small) {
+      SmallIO io;
+      memset(&io, 0, sizeof io);
+      io.in = pin; io.out = pout; io.gate = gate; io.gate_tol = gate_tol;
+      SmallDesc d = P.sm;
+      d.minus_identity = minus_identity;
+      if (vjp) { d.Qxp = h->ax[P.ax0].Qtp; d.Qyp = h->ax[P.ax1].Qtp; }
+      int sm = SM_MID;
+      if (i == 0) {
+        io.zero = (mode != MODE_JVP) ? resid : nullptr;
+        if (mode == MODE_T) sm = SM_FIRST_T;
+        else if (mode == MODE_T_LIN) { sm = SM_FIRST_TLIN; io.aux_out = h->c1; bytes += n8; }
+        else { sm = SM_FIRST_J; io.aux_in = vjp ? h->c2 : h->c1; bytes += n8; }
+      } else if (last) {
+        if (mode == MODE_T) { sm = SM_LAST_T; io.old = old; io.resid = resid; if (resid) bytes += n8; }
+        else if (mode == MODE_T_LIN) { sm = SM_LAST_TLIN; io.old = old; io.resid = resid; io.aux_out = h->c2; bytes += n8; if (resid) bytes += n8; }
+        else { sm = SM_LAST_J; io.aux_in = vjp ? h->c1 : h->c2; io.old = old; bytes += n8; if (minus_identity) { bytes += n8; io.dotp = dotp; } }
+      }
+      small_fn fn = small_variant(sm, P.r);
+      if (!fn) return fail(h, SDFS_ERR_UNSUPPORTED, "no small-grid kernel variant");
+      int cid = -1;
+      if (h->profiling) { char nm[48]; snprintf(nm, sizeof nm, "%s:%s", tag, P.label.c_str()); cid = counter_id(h, nm, bytes, P.flops); }
+      ProfScope ps(h, cid);
+      hipLaunchKernelGGL(fn, dim3((unsigned)((d.ntiles + 3) / 4)), dim3(256), 0, h->stream, d, io);
+    } else if (!P.line) {
       SliceIO io;
       memset(&io, 0, sizeof io);
       io.in = pin; io.out = pout; io.gate = gate; io.gate_tol = gate_tol;
@@ -868,6 +985,7 @@ int run_fast_plan(sdfs_handle* h, int mode, const double* in, double* out, const
 // tiles of the last pass of a J.v application (per-block partial sums of the fused dots)
 long long jvp_last_tiles(sdfs_handle* h) {
   if (h->cont || h->dense) return 0;
+  if (h->fast.ok && h->fast.small) return h->krylov_f32 ? h->plan[0].passes.back().d.ntiles : (h->fast.passes.back().sm.ntiles + 3) / 4;
   if (h->fast.ok && h->krylov_f32 && h->fast.f32_ok) return h->fast.passes.back().ld.ntiles;
   if (h->fast.ok && !h->krylov_f32) return line_grid(h, h->fast.passes.back());
   return h->plan[0].passes.empty() ? 0 : h->plan[0].passes.back().d.ntiles;
@@ -964,6 +1082,49 @@ int ensure_scalars(sdfs_handle* h) {
   return 0;
 }
 
+// Successive approximation on the small-grid plan (fast_kernels.hpp, SM_FUSED_T): the pair order is reversed
+// every iteration, so the last pass of one application and the first pass of the next act on the same pair and
+// run as one kernel.  Invariant before iteration `it`: h->tmp holds the first pair of this iteration's order
+// already contracted over w_it^theta.  4-D: one launch per iteration; 6-D: two.
+int small_sa_prologue(sdfs_handle* h, const double* w) {
+  const FastPass& P = h->fast.passes[0];
+  SmallIO io;
+  memset(&io, 0, sizeof io);
+  io.in = w; io.out = h->tmp;
+  small_fn fn = small_variant(SM_FIRST_T, P.r);
+  if (!fn) return fail(h, SDFS_ERR_UNSUPPORTED, "no small-grid kernel variant");
+  int cid = -1;
+  if (h->profiling) cid = counter_id(h, ("sa:first " + P.label).c_str(), 16.0 * (double)h->N, P.flops);
+  ProfScope ps(h, cid);
+  hipLaunchKernelGGL(fn, dim3((unsigned)((P.sm.ntiles + 3) / 4)), dim3(256), 0, h->stream, P.sm, io);
+  HIPCHK(h, hipGetLastError());
+  return 0;
+}
+
+int small_sa_iteration(sdfs_handle* h, long long it, const double* w_old, double* w_new, unsigned long long* resid,
+                       const unsigned long long* gate, double gate_tol) {
+  const int np = (int)h->fast.passes.size();
+  const bool forward = (it & 1) == 0;
+  const double n8 = 8.0 * (double)h->N;
+  for (int j = 1; j < np; ++j) {
+    const FastPass& P = h->fast.passes[forward ? j : np - 1 - j];
+    const bool last = j == np - 1;
+    SmallIO io;
+    memset(&io, 0, sizeof io);
+    io.in = h->tmp; io.gate = gate; io.gate_tol = gate_tol;
+    if (last) { io.out = w_new; io.old = w_old; io.resid = resid; io.aux_out = h->tmp; }
+    else io.out = h->tmp;
+    small_fn fn = small_variant(last ? SM_FUSED_T : SM_MID, P.r);
+    if (!fn) return fail(h, SDFS_ERR_UNSUPPORTED, "no small-grid kernel variant");
+    int cid = -1;
+    if (h->profiling) cid = counter_id(h, ((last ? "sa:fused " : "sa:") + P.label).c_str(), (last ? 4 : 2) * n8, (last ? 2 : 1) * P.flops);
+    ProfScope ps(h, cid);
+    hipLaunchKernelGGL(fn, dim3((unsigned)((P.sm.ntiles + 3) / 4)), dim3(256), 0, h->stream, P.sm, io);
+    HIPCHK(h, hipGetLastError());
+  }
+  return 0;
+}
+
 double bits_to_double(unsigned long long b) { double d; memcpy(&d, &b, 8); return d; }
 
 // ---------------------------------------------------------------------------
@@ -985,14 +1146,17 @@ int solve_sa(sdfs_handle* h, const sdfs_opts& o, double* w, int64_t* n_iter, int
   HIPCHK(h, hipStreamSynchronize(h->stream));
   h->trace.clear();
   double* bufs[2] = {h->buf0, h->buf1};
+  // small-grid plan: last pass of iteration k and first pass of iteration k+1 in one kernel (pair order alternates)
+  const bool fused = h->fast.ok && h->fast.small && !h->cont && !h->dense && h->knobs.sa_fused != 0;
+  if (fused && (rc = small_sa_prologue(h, h->buf0))) return rc;
 
   // `count` iterations starting at global iteration it0 (it0 even whenever count == chunk)
   auto enqueue = [&](long long it0, int count) -> int {
     HIPCHK(h, hipMemsetAsync(h->slots, 0, 8 * (size_t)chunk, h->stream));
     for (int i = 0; i < count; ++i) {
       const long long it = it0 + i;
-      int r2 = apply_T_dev(h, bufs[it & 1], bufs[(it + 1) & 1], h->slots + i,
-                           i == 0 ? carry : h->slots + i - 1, o.tol);
+      int r2 = fused ? small_sa_iteration(h, it, bufs[it & 1], bufs[(it + 1) & 1], h->slots + i, i == 0 ? carry : h->slots + i - 1, o.tol)
+                     : apply_T_dev(h, bufs[it & 1], bufs[(it + 1) & 1], h->slots + i, i == 0 ? carry : h->slots + i - 1, o.tol);
       if (r2) return r2;
     }
     HIPCHK(h, hipMemcpyAsync(carry, h->slots + count - 1, 8, hipMemcpyDeviceToDevice, h->stream));
@@ -1487,6 +1651,13 @@ int create_common(int model, int ndim, const int64_t* shapes, const double* para
     double* d = nullptr;
     if ((rc = upload(h, &d, qt.data(), qt.size()))) return bail(rc);
     h->ax[a].Qt = d;
+    if (n <= 16) {
+      std::vector<double> qp(256, 0.0), qtp(256, 0.0);
+      for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) { qp[(size_t)i * 16 + j] = q[(size_t)i * n + j]; qtp[(size_t)j * 16 + i] = q[(size_t)i * n + j]; }
+      double *dp = nullptr, *dtp = nullptr;
+      if ((rc = upload(h, &dp, qp.data(), 256)) || (rc = upload(h, &dtp, qtp.data(), 256))) return bail(rc);
+      h->ax[a].Qp = dp; h->ax[a].Qtp = dtp;
+    }
   }
   // dynamic LDS above 64 KB has to be allowed per kernel variant (and per device)
   static unsigned long long attr_done = 0;
@@ -1510,6 +1681,8 @@ int create_common(int model, int ndim, const int64_t* shapes, const double* para
     rc = build_plan(h, h->plan[0], all, std::vector<bool>(ndim, false));
     if (rc) return bail(rc);
     rc = build_fast_plan(h);
+    if (rc) return bail(rc);
+    rc = build_small_plan(h);
     if (rc) return bail(rc);
   } else {
     if (axis_a >= ndim || axis_b < 0 || axis_b >= ndim || axis_a == axis_b)
@@ -2111,7 +2284,10 @@ int sdfs_describe_plan(const sdfs_handle* h, char* buf, int64_t cap) {
     for (size_t i = 0; i < h->fast.passes.size(); ++i) {
       const FastPass& P = h->fast.passes[i];
       int occ = -1;
-      if (!P.line) {
+      if (P.small) {
+        snprintf(line, sizeof line, "small-grid plan pass %zu: %s one wave per tile, run %d, tiles %lld, workgroups %lld\n", i,
+                 P.label.c_str(), P.r, P.sm.ntiles, (P.sm.ntiles + 3) / 4);
+      } else if (!P.line) {
         hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)slice_variant(P.n, S_TFIRST), 256, slice_lds_bytes(P.n));
         const long long nt = (P.sd.nslices + slice_tile_slices(P.n) - 1) / slice_tile_slices(P.n);
         snprintf(line, sizeof line, "pair plan pass %zu: %s lds %zu B block 256 (4 wave tiles) wave-tiles %lld blocks/CU %d\n", i,
