@@ -738,8 +738,8 @@ line_kernel(const LineDesc P, const LineIO io) {
 // SM_FUSED_T: the last pass of one application of T and the first pass of the next in one kernel (successive
 // approximation with the pair order reversed every iteration, so that both act on the same pair): contract,
 // aggregator, residual, store Tw, then (Tw)^theta and the same two contractions again, into the intermediate.
-#ifndef SDFS_STAMP
-#define SDFS_STAMP(i)       // tools/probes/small_fused_probe.hip defines it: phase time stamps of workgroup 0
+#ifndef SDFS_SMALL_STAMP
+#define SDFS_SMALL_STAMP(i)       // tools/probes/small_fused_probe.hip defines it: phase time stamps of workgroup 0
 #endif
 enum SmallMode { SM_FIRST_T = 0, SM_FIRST_TLIN = 1, SM_FIRST_J = 2, SM_MID = 3, SM_LAST_T = 4, SM_LAST_TLIN = 5, SM_LAST_J = 6, SM_FUSED_T = 7, SM_NMODES = 8 };
 
@@ -772,7 +772,43 @@ struct SmallIO {
   double gate_tol;
   double* dotp;             // J.v with minus_identity: per-workgroup partial sums <out, v>, <out, out>: [2][gridDim.x]
   unsigned long long* zero; // first pass: cleared by workgroup 0 (the residual word the last pass maximises into)
+  // Successive approximation without atomics (225 workgroups maximising into one word cost 2.9 of the 7.5 us of a
+  // fused kernel, tools/probes/small_fused_probe.hip): every workgroup stores its own maximum, the kernels of the
+  // next iteration reduce those gate_n values themselves (their gate), and workgroup 0 leaves the result in slot_out
+  // for the host.  A closed gate writes zeros, so it stays closed.
+  const double* gate_part;
+  int gate_n;
+  double* part_out;
+  unsigned long long* slot_out;
 };
+
+// Wave reductions on the VALU (DPP moves inside the rows of 16, v_readlane across the four rows): ~30 instructions
+// where six __shfl_xor steps of a double are twelve LDS-crossbar round trips (~1000 cycles measured at the end of
+// a small-grid kernel, tools/probes/small_fused_probe.hip).  Every lane must be active; the result is wave-uniform.
+template <int CTRL> __device__ __forceinline__ double dpp_mov_f64(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
+  hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double readlane_f64(double v, int l) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
+// quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror, row_mirror: afterwards every lane holds its row's result
+__device__ __forceinline__ double wave_max_f64(double v) {      // NaN-free input (fmax drops NaNs)
+  v = fmax(v, dpp_mov_f64<0xB1>(v));
+  v = fmax(v, dpp_mov_f64<0x4E>(v));
+  v = fmax(v, dpp_mov_f64<0x141>(v));
+  v = fmax(v, dpp_mov_f64<0x140>(v));
+  return fmax(fmax(readlane_f64(v, 0), readlane_f64(v, 16)), fmax(readlane_f64(v, 32), readlane_f64(v, 48)));
+}
+__device__ __forceinline__ double wave_sum_f64(double v) {
+  v += dpp_mov_f64<0xB1>(v);
+  v += dpp_mov_f64<0x4E>(v);
+  v += dpp_mov_f64<0x141>(v);
+  v += dpp_mov_f64<0x140>(v);
+  return (readlane_f64(v, 0) + readlane_f64(v, 16)) + (readlane_f64(v, 32) + readlane_f64(v, 48));
+}
 
 // element e of a tile -> LDS offset, global element offset against the tile base, a3 index part, position
 template <int R>
@@ -786,7 +822,14 @@ __device__ __forceinline__ void small_decode(const SmallDesc& P, int e, int& l, 
   ixy = __umul24((unsigned)x, (unsigned)P.a3x) + __umul24((unsigned)y, (unsigned)P.a3y);
 }
 
-template <int MODE, int R>
+// WPT = waves per tile.  1: four wave-private tiles per workgroup, no workgroup barrier on the data path (many
+// tiles: every SIMD has waves anyway).  4: one tile per workgroup, an element (R = 1) or four (R = 4) per thread:
+// with at most a tile per CU the power -- ~140 instructions per point, issue-bound for a lone wave -- spreads
+// over the CU's four SIMDs (tools/probes/small_fused_probe.hip: 1800 of the 13900 cycles of a fused kernel per
+// power of four points per lane); the contractions' column tiles go to wave 0 (R = 1) or one to each wave (R = 4).
+constexpr int SMALL_RING = 512;      // most workgroups of an end pass for which successive approximation runs without atomics
+
+template <int MODE, int R, int WPT>
 __global__ void __launch_bounds__(256)
 small_tile_kernel(const SmallDesc P, const SmallIO io) {
   constexpr bool POWP = MODE == SM_FIRST_T || MODE == SM_FIRST_TLIN;
@@ -796,18 +839,32 @@ small_tile_kernel(const SmallDesc P, const SmallIO io) {
   constexpr bool CES = MODE == SM_LAST_T || MODE == SM_LAST_TLIN || FUSED;
   constexpr bool LINE = MODE == SM_LAST_TLIN;
   constexpr bool MULE = MODE == SM_LAST_J;
-  constexpr int TILE = 256 * R;                // doubles per wave
-  constexpr int EPL = 4 * R;                   // elements per lane (padded tile / 64)
+  constexpr int TILE = 256 * R;                // doubles per tile
+  constexpr int TPT = 64 * WPT;                // threads per tile
+  constexpr int EPL = TILE / TPT;              // elements per thread (padded tile)
+  constexpr int PG = EPL < 4 ? EPL : 4;        // points per call of the power routine
   static_assert(R == 1 || R == 4, "run lengths");
-  __shared__ __attribute__((aligned(16))) double lds[4 * TILE];
+  static_assert(WPT == 1 || WPT == 4, "waves per tile");
+  __shared__ __attribute__((aligned(16))) double lds[(4 / WPT) * TILE];
   __shared__ double red[12];
   // the gate word is fetched first and tested behind the tile loads (nothing is written before the test)
   const unsigned long long gate_word = io.gate != nullptr ? *io.gate : ~0ULL;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const long long t = (long long)blockIdx.x * 4 + wave;
-  SDFS_STAMP(0);
-  const bool active = t < P.ntiles;            // wave-uniform; idle waves fall through to the reductions
+  double gate_err = 0.0;                       // the previous iteration's error, reduced from per-workgroup maxima
+  if (io.gate_part != nullptr) {
+    // all loads at once: the values were written by the previous kernel on other XCDs, a round trip each
+    double gp[SMALL_RING / 64];
+#pragma unroll
+    for (int k = 0; k < SMALL_RING / 64; ++k) gp[k] = io.gate_part[lane + 64 * k < io.gate_n ? lane + 64 * k : 0];
+#pragma unroll
+    for (int k = 0; k < SMALL_RING / 64; ++k) gate_err = fmax(gate_err, gp[k]);
+  }
+  const int tl = WPT == 4 ? tid : lane;        // this thread's index inside its tile
+  const long long t = WPT == 4 ? (long long)blockIdx.x : (long long)blockIdx.x * 4 + wave;
+  SDFS_SMALL_STAMP(0);
+  const bool active = t < P.ntiles;            // uniform per tile; idle waves (WPT = 1) fall through to the reductions
+  auto tile_sync = [&]() { if (WPT == 4) __syncthreads(); else wave_lds_fence(); };
   double rmax = 0.0, dot_yv = 0.0, dot_yy = 0.0;
   bool rnan = false;
   if (active) {
@@ -815,58 +872,65 @@ small_tile_kernel(const SmallDesc P, const SmallIO io) {
     const long long base = (long long)o * P.ostride + (long long)chunk * R;
     const int total = P.nx * P.ny * R;
     const unsigned pos0 = chunk * R;
-    double* const wl = lds + wave * TILE;
-    const bool need_old = CES ? (io.resid != nullptr) : (MULE && P.minus_identity);
-    // ---- decode this lane's elements once ------------------------------------------------------------------
-    int l[EPL]; unsigned g[EPL], ia3[EPL]; bool ok[EPL];
+    double* const wl = WPT == 4 ? lds : lds + wave * TILE;
+    const bool need_old = CES ? (io.resid != nullptr || io.part_out != nullptr) : (MULE && P.minus_identity);
+    // ---- decode this thread's elements once ------------------------------------------------------------------
+    int l[EPL], rr[EPL]; unsigned g[EPL], ia3[EPL]; bool ok[EPL];
 #pragma unroll
     for (int k = 0; k < EPL; ++k) {
-      const int e = lane + 64 * k;
-      int r; unsigned ixy;
+      const int e = tl + TPT * k;
       ok[k] = e < total;
-      small_decode<R>(P, ok[k] ? e : 0, l[k], g[k], ixy, r);
-      ok[k] = ok[k] && (R == 1 || pos0 + (unsigned)r < P.lrest);
+      small_decode<R>(P, ok[k] ? e : 0, l[k], g[k], ia3[k], rr[k]);
+      ok[k] = ok[k] && (R == 1 || pos0 + (unsigned)rr[k] < P.lrest);
       if (!ok[k]) g[k] = 0u;
-      ia3[k] = ixy;
-      if (CES) ia3[k] = ok[k] ? (unsigned)(P.out_idx[o] + P.rest_idx[pos0 + (unsigned)r]) + ixy : 0u;
     }
-    // ---- loads: the tile and, for the last pass, its side streams -- all in flight at once -----------------
+    // ---- loads: the tile and, for the last pass, its side streams -- all in flight at once; the a3 gather, whose
+    // index comes out of two tables, goes last ---------------------------------------------------------------------
     const double* const inb = io.in + base;
     double v[EPL], s1[EPL], s2[EPL];
 #pragma unroll
     for (int k = 0; k < EPL; ++k) {
-      if (64 * k < total) {
+      if (TPT * k < total) {
         v[k] = inb[g[k]];
         if (MULP) s1[k] = io.aux_in[base + g[k]];
         if ((CES || MULE) && need_old) s1[k] = io.old[base + g[k]];
-        if (CES) s2[k] = P.a3[ia3[k]];
         if (MULE) s2[k] = io.aux_in[base + g[k]];
       }
     }
     QFrag<16> q, q2;
-    q.load(P.Qxp, lane);
-    if (FUSED) q2.load(P.Qyp, lane);
-    SDFS_STAMP(1);
+    const bool mfma_wave = WPT == 1 || R == 4 || wave == 0;
+    if (mfma_wave) { q.load(P.Qxp, lane); q2.load(P.Qyp, lane); }
+    if (CES) {
+      const unsigned io0 = (unsigned)P.out_idx[o];
+#pragma unroll
+      for (int k = 0; k < EPL; ++k)
+        if (TPT * k < total) s2[k] = P.a3[ok[k] ? io0 + (unsigned)P.rest_idx[pos0 + (unsigned)rr[k]] + ia3[k] : 0u];
+    }
+    SDFS_SMALL_STAMP(1);
     if (gate_word <= (unsigned long long)__double_as_longlong(io.gate_tol)) return;      // uniform over the grid
-    SDFS_STAMP(2);
+    SDFS_SMALL_STAMP(2);
     if (io.zero != nullptr && blockIdx.x == 0 && tid == 0) *io.zero = 0ULL;
     // ---- zero the padded tile, then park the data ------------------------------------------------------------
+    if (EPL >= 2) {
 #pragma unroll
-    for (int k = 0; k < 2 * R; ++k) *reinterpret_cast<double2*>(wl + 2 * (lane + 64 * k)) = make_double2(0.0, 0.0);
-    wave_lds_fence();
+      for (int k = 0; k < EPL / 2; ++k) *reinterpret_cast<double2*>(wl + 2 * (tl + TPT * k)) = make_double2(0.0, 0.0);
+    } else {
+      wl[tl] = 0.0;
+    }
+    tile_sync();
+    PowLane PT;
+    if (POWP || CES) PT = pow_lane_init(lane);
     if (POWP) {
-      // x = w^theta (c1 = w^(theta-1)); masked lanes feed the power 1.  Four points per call: on these grids a
-      // wave is alone on its SIMD and the power's dependent chains, not its issue slots, set the pace
-      const PowLane PT = pow_lane_init(lane);
+      // x = w^theta (c1 = w^(theta-1)); masked lanes feed the power 1
 #pragma unroll
-      for (int k = 0; k < EPL; k += 4) {
-        if (64 * k < total) {
-          double xin[4], xw[4];
+      for (int k = 0; k < EPL; k += PG) {
+        if (TPT * k < total) {
+          double xin[PG], xw[PG];
 #pragma unroll
-          for (int j = 0; j < 4; ++j) xin[j] = ok[k + j] ? v[k + j] : 1.0;
-          pow_fast_n<true, 4>(xin, P.theta, PT, xw);
+          for (int j = 0; j < PG; ++j) xin[j] = ok[k + j] ? v[k + j] : 1.0;
+          pow_fast_n<true, PG>(xin, P.theta, PT, xw);
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
+          for (int j = 0; j < PG; ++j) {
             v[k + j] = xw[j];
             if (LINP && ok[k + j]) io.aux_out[base + g[k + j]] = xw[j] / xin[j];
           }
@@ -875,48 +939,61 @@ small_tile_kernel(const SmallDesc P, const SmallIO io) {
     }
 #pragma unroll
     for (int k = 0; k < EPL; ++k) {
-      if (64 * k < total) {
+      if (TPT * k < total) {
         if (MULP) v[k] *= s1[k];
         if (ok[k]) wl[l[k]] = v[k];
       }
     }
-    wave_lds_fence();
+    tile_sync();
     const int li = lane & 15, lk = lane >> 4;
     // ---- contraction over X (row stride 16 R), then over Y (row stride R) --------------------------------------
-    auto contract_pair = [&](const QFrag<16>& qx, const QFrag<16>& qy) {
+    auto contract_pair = [&]() {
       if (R == 1) {
-        ctile<16, 16>(wl + li + lk * 16, qx);
+        if (mfma_wave) {
+          ctile<16, 16>(wl + li + lk * 16, q);
+          wave_lds_fence();
+          ctile<16, 1>(wl + li * 16 + lk, q2);
+        }
+      } else if (WPT == 1) {
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct)
+          if (4 * ct < P.ny) ctile<16, 64>(wl + 16 * ct + li + lk * 64, q);
         wave_lds_fence();
-        ctile<16, 1>(wl + li * 16 + lk, qy);
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct)
+          if (4 * ct < P.nx) ctile<16, 4>(wl + (4 * ct + (li >> 2)) * 64 + (li & 3) + lk * 4, q2);
       } else {
-#pragma unroll
-        for (int ct = 0; ct < 4; ++ct)
-          if (4 * ct < P.ny) ctile<16, 64>(wl + 16 * ct + li + lk * 64, qx);
-        wave_lds_fence();
-#pragma unroll
-        for (int ct = 0; ct < 4; ++ct)
-          if (4 * ct < P.nx) ctile<16, 4>(wl + (4 * ct + (li >> 2)) * 64 + (li & 3) + lk * 4, qy);
+        if (4 * wave < P.ny) ctile<16, 64>(wl + 16 * wave + li + lk * 64, q);
+        __syncthreads();
+        if (4 * wave < P.nx) ctile<16, 4>(wl + (4 * wave + (li >> 2)) * 64 + (li & 3) + lk * 4, q2);
       }
-      wave_lds_fence();
+      tile_sync();
     };
-    if (!FUSED) q2.load(P.Qyp, lane);
-    SDFS_STAMP(3);
-    contract_pair(q, q2);
-    SDFS_STAMP(4);
+    SDFS_SMALL_STAMP(3);
+    contract_pair();
+    SDFS_SMALL_STAMP(4);
+    if (io.gate_part != nullptr) {
+      // tested here, behind the contractions: nothing has been written to memory yet
+      gate_err = wave_max_f64(gate_err);
+      if (blockIdx.x == 0 && tid == 0 && io.slot_out != nullptr) *io.slot_out = (unsigned long long)__double_as_longlong(gate_err);
+      if (gate_err <= io.gate_tol) {                             // uniform over the grid
+        if (tid == 0 && io.part_out != nullptr) io.part_out[blockIdx.x] = 0.0;
+        return;
+      }
+    }
     // ---- epilogue -----------------------------------------------------------------------------------------------
     double* const outb = io.out + base;
     if (CES) {
       // Tw = 1 + beta (a3 S)^(1/theta), c2 = beta u / S, |Tw - w|
-      const PowLane PT = pow_lane_init(lane);
 #pragma unroll
-      for (int k = 0; k < EPL; k += 4) {
-        if (64 * k < total) {
-          double sv[4], ks[4], uu[4];
+      for (int k = 0; k < EPL; k += PG) {
+        if (TPT * k < total) {
+          double sv[PG], ks[PG], uu[PG];
 #pragma unroll
-          for (int j = 0; j < 4; ++j) { sv[j] = wl[l[k + j]]; ks[j] = ok[k + j] ? s2[k + j] * sv[j] : 1.0; }
-          pow_fast_n<false, 4>(ks, P.inv_theta, PT, uu);
+          for (int j = 0; j < PG; ++j) { sv[j] = wl[l[k + j]]; ks[j] = ok[k + j] ? s2[k + j] * sv[j] : 1.0; }
+          pow_fast_n<false, PG>(ks, P.inv_theta, PT, uu);
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
+          for (int j = 0; j < PG; ++j) {
             if (ok[k + j]) {
               const double y = 1.0 + P.beta * uu[j];
               if (LINE) io.aux_out[base + g[k + j]] = P.beta * uu[j] / sv[j];
@@ -931,34 +1008,34 @@ small_tile_kernel(const SmallDesc P, const SmallIO io) {
           }
         }
       }
-      SDFS_STAMP(5);
+      SDFS_SMALL_STAMP(5);
       if (FUSED) {
         // the next application's first pass on the same pair: x = (Tw)^theta, both contractions, into the intermediate
         // (the padding of the LDS tile is still exact zeros)
 #pragma unroll
-        for (int k = 0; k < EPL; k += 4) {
-          if (64 * k < total) {
-            double xin[4], xw[4];
+        for (int k = 0; k < EPL; k += PG) {
+          if (TPT * k < total) {
+            double xin[PG], xw[PG];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) xin[j] = ok[k + j] ? v[k + j] : 1.0;
-            pow_fast_n<true, 4>(xin, P.theta, PT, xw);
+            for (int j = 0; j < PG; ++j) xin[j] = ok[k + j] ? v[k + j] : 1.0;
+            pow_fast_n<true, PG>(xin, P.theta, PT, xw);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) if (ok[k + j]) wl[l[k + j]] = xw[j];
+            for (int j = 0; j < PG; ++j) if (ok[k + j]) wl[l[k + j]] = xw[j];
           }
         }
-        wave_lds_fence();
-        SDFS_STAMP(6);
-        contract_pair(q, q2);
-        SDFS_STAMP(7);
+        tile_sync();
+        SDFS_SMALL_STAMP(6);
+        contract_pair();
+        SDFS_SMALL_STAMP(7);
         double* const tmpb = io.aux_out + base;
 #pragma unroll
         for (int k = 0; k < EPL; ++k)
-          if (64 * k < total && ok[k]) tmpb[g[k]] = wl[l[k]];
+          if (TPT * k < total && ok[k]) tmpb[g[k]] = wl[l[k]];
       }
     } else {
 #pragma unroll
       for (int k = 0; k < EPL; ++k) {
-        if (64 * k < total && ok[k]) {
+        if (TPT * k < total && ok[k]) {
           double y = wl[l[k]];
           if (MULE) {
             y *= s2[k];
@@ -973,12 +1050,15 @@ small_tile_kernel(const SmallDesc P, const SmallIO io) {
       }
     }
   }
-  SDFS_STAMP(8);
+  SDFS_SMALL_STAMP(8);
   // ---- per-workgroup reductions (every wave of an open gate arrives) ------------------------------------------------
   if (gate_word <= (unsigned long long)__double_as_longlong(io.gate_tol)) return;
+  if (io.gate_part != nullptr && !active) {                      // idle waves of a WPT = 1 workgroup: same test
+    gate_err = wave_max_f64(gate_err);
+    if (gate_err <= io.gate_tol) return;
+  }
   if (MULE && io.dotp != nullptr) {
-#pragma unroll
-    for (int s = 32; s > 0; s >>= 1) { dot_yv += __shfl_xor(dot_yv, s); dot_yy += __shfl_xor(dot_yy, s); }
+    dot_yv = wave_sum_f64(dot_yv); dot_yy = wave_sum_f64(dot_yy);
     if (lane == 0) { red[wave] = dot_yv; red[4 + wave] = dot_yy; }
     __syncthreads();
     if (tid == 0) {
@@ -986,33 +1066,52 @@ small_tile_kernel(const SmallDesc P, const SmallIO io) {
       io.dotp[gridDim.x + blockIdx.x] = (red[4] + red[5]) + (red[6] + red[7]);
     }
   }
-  if (CES && io.resid != nullptr) {
+  if (CES && (io.resid != nullptr || io.part_out != nullptr)) {
     if (rnan) rmax = __longlong_as_double(0x7ff0000000000000LL);                // NaN -> +inf
-#pragma unroll
-    for (int s = 32; s > 0; s >>= 1) rmax = fmax(rmax, __shfl_xor(rmax, s));
+    rmax = wave_max_f64(rmax);
     if (lane == 0) red[8 + wave] = rmax;
     __syncthreads();
-    if (tid == 0) atomicMax(io.resid, (unsigned long long)__double_as_longlong(fmax(fmax(red[8], red[9]), fmax(red[10], red[11]))));
+    if (tid == 0) {
+      const double bm = fmax(fmax(red[8], red[9]), fmax(red[10], red[11]));
+      if (io.part_out != nullptr) io.part_out[blockIdx.x] = bm;
+      else atomicMax(io.resid, (unsigned long long)__double_as_longlong(bm));
+    }
   }
-  SDFS_STAMP(9);
+  SDFS_SMALL_STAMP(9);
+}
+
+// end of a chunk of iterations: the last iteration's error for the host
+__global__ void __launch_bounds__(64) small_sa_finish(const double* part, int n, unsigned long long* slot) {
+  double gp[SMALL_RING / 64];
+#pragma unroll
+  for (int k = 0; k < SMALL_RING / 64; ++k) gp[k] = part[(int)threadIdx.x + 64 * k < n ? (int)threadIdx.x + 64 * k : 0];
+  double m = 0.0;
+#pragma unroll
+  for (int k = 0; k < SMALL_RING / 64; ++k) m = fmax(m, gp[k]);
+  m = wave_max_f64(m);
+  if (threadIdx.x == 0) *slot = (unsigned long long)__double_as_longlong(m);
 }
 
 typedef void (*small_fn)(const SmallDesc, const SmallIO);
-template <int R> inline small_fn small_variant_r(int mode) {
+template <int R, int WPT> inline small_fn small_variant_rw(int mode) {
   switch (mode) {
-    case SM_FIRST_T: return R == 1 ? (small_fn)small_tile_kernel<SM_FIRST_T, 1> : nullptr;
-    case SM_FIRST_TLIN: return R == 1 ? (small_fn)small_tile_kernel<SM_FIRST_TLIN, 1> : nullptr;
-    case SM_FIRST_J: return R == 1 ? (small_fn)small_tile_kernel<SM_FIRST_J, 1> : nullptr;
-    case SM_MID: return (small_fn)small_tile_kernel<SM_MID, R>;
-    case SM_LAST_T: return (small_fn)small_tile_kernel<SM_LAST_T, R>;
-    case SM_LAST_TLIN: return (small_fn)small_tile_kernel<SM_LAST_TLIN, R>;
-    case SM_LAST_J: return (small_fn)small_tile_kernel<SM_LAST_J, R>;
-    case SM_FUSED_T: return (small_fn)small_tile_kernel<SM_FUSED_T, R>;
+    case SM_FIRST_T: return R == 1 ? (small_fn)small_tile_kernel<SM_FIRST_T, 1, WPT> : nullptr;
+    case SM_FIRST_TLIN: return R == 1 ? (small_fn)small_tile_kernel<SM_FIRST_TLIN, 1, WPT> : nullptr;
+    case SM_FIRST_J: return R == 1 ? (small_fn)small_tile_kernel<SM_FIRST_J, 1, WPT> : nullptr;
+    case SM_MID: return (small_fn)small_tile_kernel<SM_MID, R, WPT>;
+    case SM_LAST_T: return (small_fn)small_tile_kernel<SM_LAST_T, R, WPT>;
+    case SM_LAST_TLIN: return (small_fn)small_tile_kernel<SM_LAST_TLIN, R, WPT>;
+    case SM_LAST_J: return (small_fn)small_tile_kernel<SM_LAST_J, R, WPT>;
+    case SM_FUSED_T: return (small_fn)small_tile_kernel<SM_FUSED_T, R, WPT>;
     default: return nullptr;
   }
 }
 // the first pass walks the two fastest axes: nothing lies behind Y, so its run length is 1
-inline small_fn small_variant(int mode, int r) { return r == 1 ? small_variant_r<1>(mode) : (r == 4 ? small_variant_r<4>(mode) : nullptr); }
+inline small_fn small_variant(int mode, int r, int wpt) {
+  if (wpt == 4) return r == 1 ? small_variant_rw<1, 4>(mode) : (r == 4 ? small_variant_rw<4, 4>(mode) : nullptr);
+  return r == 1 ? small_variant_rw<1, 1>(mode) : (r == 4 ? small_variant_rw<4, 1>(mode) : nullptr);
+}
+inline unsigned small_grid(long long ntiles, int wpt) { return (unsigned)(wpt == 4 ? ntiles : (ntiles + 3) / 4); }
 
 typedef void (*slice_fn)(const SliceDesc, const SliceIO);
 typedef void (*line_fn)(const LineDesc, const LineIO);

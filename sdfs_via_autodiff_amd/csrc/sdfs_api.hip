@@ -82,6 +82,7 @@ struct FastPass {
   LineDesc ld;
   bool small = false;          // small-grid form: run-time extents <= 16, one wave per tile (SmallDesc)
   int r = 1;                   // its run length
+  int wpt = 1;                 // ... and waves per tile
   SmallDesc sm;
   double q_bytes = 0, flops = 0;
   std::string label;
@@ -103,6 +104,7 @@ struct Knobs {
   int plan = 0;                // SDFS_PLAN: 0 = automatic, 1 = "classic" (generic tiles only), 2 = "pair" (pair plan whenever legal)
   int small_plan = 1;          // SDFS_SMALL_PLAN: 0 = never use the small-grid pair plan
   int small_r = 0;             // SDFS_SMALL_R: force the run length of its line passes (1 or 4)
+  int small_wpt = 0;           // SDFS_SMALL_WPT: force its waves per tile (1 or 4)
   int sa_fused = 1;            // SDFS_SA_FUSED: 0 = successive approximation on the small-grid plan keeps one launch per pass
   int ablate = 0;              // SDFS_ABLATE, honoured only by -DSDFS_DIAG builds
 };
@@ -130,6 +132,7 @@ struct sdfs_handle {
   Plan plan[2];
   FastPlan fast;                      // pair plan of the full grid, when the model admits it
   unsigned* sched = nullptr;          // tile tickets of the persistent line pass (two words per pass, zero between launches)
+  double* sa_ring = nullptr;          // small-grid SA: per-workgroup residual maxima of the last two iterations [2][SA_RING]
   std::vector<void*> misc_allocs;     // device index tables of the pair plan
   bool sharded = false;
   int axis_a = -1, axis_b = -1;
@@ -239,6 +242,7 @@ Knobs read_knobs() {
   k.small_plan = env_int("SDFS_SMALL_PLAN", 1);
   k.small_r = env_int("SDFS_SMALL_R", 0);
   k.sa_fused = env_int("SDFS_SA_FUSED", 1);
+  k.small_wpt = env_int("SDFS_SMALL_WPT", 0);
   const char* pl = getenv("SDFS_PLAN");
   if (pl && !strcmp(pl, "classic")) k.plan = 1;
   else if (pl && !strcmp(pl, "pair")) k.plan = 2;
@@ -852,6 +856,9 @@ int build_small_plan(sdfs_handle* h) {
     P.r = r;
     S.nchunks = (unsigned)((lrest + r - 1) / r);
     S.ntiles = nouter * S.nchunks;
+    // a whole workgroup per tile while there are CUs to spare: the power then runs on all four SIMDs of a CU
+    P.wpt = S.ntiles <= 2LL * h->num_cus ? 4 : 1;
+    if (h->knobs.small_wpt == 1 || h->knobs.small_wpt == 4) P.wpt = h->knobs.small_wpt;
     if (S.ntiles >= (1LL << 31)) return 0;
     S.Qxp = h->ax[a].Qp; S.Qyp = h->ax[a + 1].Qp;
     S.theta = h->theta; S.inv_theta = 1.0 / h->theta; S.beta = h->beta;
@@ -859,6 +866,7 @@ int build_small_plan(sdfs_handle* h) {
     P.q_bytes = 2 * 8.0 * 256; P.flops = 2.0 * (double)h->N * (S.nx + S.ny);
     P.label = std::string(i == 0 ? "slices[" : "lines[") + h->ax[a].name + "," + h->ax[a + 1].name + "|wave " +
               std::to_string(S.nx) + "x" + std::to_string(S.ny) + "x" + std::to_string(r) + "]";
+    if (P.wpt == 4) P.label.replace(P.label.find("|wave "), 6, "|workgroup ");
     // a3 index tables: the last pass of T needs them, and successive approximation ends on either end pair
     if (i + 1 == pairs.size() || i == 0) {
       std::vector<int> outv((size_t)nouter, 0), restv((size_t)lrest, 0);
@@ -930,12 +938,12 @@ int run_fast_plan(sdfs_handle* h, int mode, const double* in, double* out, const
         else if (mode == MODE_T_LIN) { sm = SM_LAST_TLIN; io.old = old; io.resid = resid; io.aux_out = h->c2; bytes += n8; if (resid) bytes += n8; }
         else { sm = SM_LAST_J; io.aux_in = vjp ? h->c1 : h->c2; io.old = old; bytes += n8; if (minus_identity) { bytes += n8; io.dotp = dotp; } }
       }
-      small_fn fn = small_variant(sm, P.r);
+      small_fn fn = small_variant(sm, P.r, P.wpt);
       if (!fn) return fail(h, SDFS_ERR_UNSUPPORTED, "no small-grid kernel variant");
       int cid = -1;
       if (h->profiling) { char nm[48]; snprintf(nm, sizeof nm, "%s:%s", tag, P.label.c_str()); cid = counter_id(h, nm, bytes, P.flops); }
       ProfScope ps(h, cid);
-      hipLaunchKernelGGL(fn, dim3((unsigned)((d.ntiles + 3) / 4)), dim3(256), 0, h->stream, d, io);
+      hipLaunchKernelGGL(fn, dim3(small_grid(d.ntiles, P.wpt)), dim3(256), 0, h->stream, d, io);
     } else if (!P.line) {
       SliceIO io;
       memset(&io, 0, sizeof io);
@@ -985,7 +993,7 @@ int run_fast_plan(sdfs_handle* h, int mode, const double* in, double* out, const
 // tiles of the last pass of a J.v application (per-block partial sums of the fused dots)
 long long jvp_last_tiles(sdfs_handle* h) {
   if (h->cont || h->dense) return 0;
-  if (h->fast.ok && h->fast.small) return h->krylov_f32 ? h->plan[0].passes.back().d.ntiles : (h->fast.passes.back().sm.ntiles + 3) / 4;
+  if (h->fast.ok && h->fast.small) return h->krylov_f32 ? h->plan[0].passes.back().d.ntiles : (long long)small_grid(h->fast.passes.back().sm.ntiles, h->fast.passes.back().wpt);
   if (h->fast.ok && h->krylov_f32 && h->fast.f32_ok) return h->fast.passes.back().ld.ntiles;
   if (h->fast.ok && !h->krylov_f32) return line_grid(h, h->fast.passes.back());
   return h->plan[0].passes.empty() ? 0 : h->plan[0].passes.back().d.ntiles;
@@ -1091,35 +1099,46 @@ int small_sa_prologue(sdfs_handle* h, const double* w) {
   SmallIO io;
   memset(&io, 0, sizeof io);
   io.in = w; io.out = h->tmp;
-  small_fn fn = small_variant(SM_FIRST_T, P.r);
+  small_fn fn = small_variant(SM_FIRST_T, P.r, P.wpt);
   if (!fn) return fail(h, SDFS_ERR_UNSUPPORTED, "no small-grid kernel variant");
   int cid = -1;
   if (h->profiling) cid = counter_id(h, ("sa:first " + P.label).c_str(), 16.0 * (double)h->N, P.flops);
   ProfScope ps(h, cid);
-  hipLaunchKernelGGL(fn, dim3((unsigned)((P.sm.ntiles + 3) / 4)), dim3(256), 0, h->stream, P.sm, io);
+  hipLaunchKernelGGL(fn, dim3(small_grid(P.sm.ntiles, P.wpt)), dim3(256), 0, h->stream, P.sm, io);
   HIPCHK(h, hipGetLastError());
   return 0;
 }
 
+constexpr int SA_RING = SMALL_RING;   // most workgroups of an end pass for which the atomic-free residual is used
+
+// ring == true: the error of iteration it-1 is reduced by this iteration's kernels from sa_ring[(it-1) & 1] (and left
+// in slot_prev for the host), this iteration's maxima go to sa_ring[it & 1]; otherwise resid / gate words as everywhere
 int small_sa_iteration(sdfs_handle* h, long long it, const double* w_old, double* w_new, unsigned long long* resid,
-                       const unsigned long long* gate, double gate_tol) {
+                       const unsigned long long* gate, double gate_tol, bool ring, unsigned long long* slot_prev) {
   const int np = (int)h->fast.passes.size();
   const bool forward = (it & 1) == 0;
   const double n8 = 8.0 * (double)h->N;
+  // writer of ring[p]: the end pass of the iterations of parity p (forward iterations end on the last pair)
+  auto ring_n = [&](int parity) { const FastPass& E = h->fast.passes[parity == 0 ? np - 1 : 0]; return (int)small_grid(E.sm.ntiles, E.wpt); };
   for (int j = 1; j < np; ++j) {
     const FastPass& P = h->fast.passes[forward ? j : np - 1 - j];
     const bool last = j == np - 1;
     SmallIO io;
     memset(&io, 0, sizeof io);
-    io.in = h->tmp; io.gate = gate; io.gate_tol = gate_tol;
-    if (last) { io.out = w_new; io.old = w_old; io.resid = resid; io.aux_out = h->tmp; }
-    else io.out = h->tmp;
-    small_fn fn = small_variant(last ? SM_FUSED_T : SM_MID, P.r);
+    io.in = h->tmp; io.gate_tol = gate_tol;
+    if (ring) { io.gate_part = h->sa_ring + (size_t)((it + 1) & 1) * SA_RING; io.gate_n = ring_n((int)((it + 1) & 1)); }
+    else io.gate = gate;
+    if (last) {
+      io.out = w_new; io.old = w_old; io.aux_out = h->tmp;
+      if (ring) { io.part_out = h->sa_ring + (size_t)(it & 1) * SA_RING; io.slot_out = slot_prev; }
+      else io.resid = resid;
+    } else io.out = h->tmp;
+    small_fn fn = small_variant(last ? SM_FUSED_T : SM_MID, P.r, P.wpt);
     if (!fn) return fail(h, SDFS_ERR_UNSUPPORTED, "no small-grid kernel variant");
     int cid = -1;
     if (h->profiling) cid = counter_id(h, ((last ? "sa:fused " : "sa:") + P.label).c_str(), (last ? 4 : 2) * n8, (last ? 2 : 1) * P.flops);
     ProfScope ps(h, cid);
-    hipLaunchKernelGGL(fn, dim3((unsigned)((P.sm.ntiles + 3) / 4)), dim3(256), 0, h->stream, P.sm, io);
+    hipLaunchKernelGGL(fn, dim3(small_grid(P.sm.ntiles, P.wpt)), dim3(256), 0, h->stream, P.sm, io);
     HIPCHK(h, hipGetLastError());
   }
   return 0;
@@ -1149,17 +1168,41 @@ int solve_sa(sdfs_handle* h, const sdfs_opts& o, double* w, int64_t* n_iter, int
   // small-grid plan: last pass of iteration k and first pass of iteration k+1 in one kernel (pair order alternates)
   const bool fused = h->fast.ok && h->fast.small && !h->cont && !h->dense && h->knobs.sa_fused != 0;
   if (fused && (rc = small_sa_prologue(h, h->buf0))) return rc;
+  // ... and the residual without atomics: per-workgroup maxima, reduced by the next iteration's kernels
+  bool ring = false;
+  int ring_n[2] = {0, 0};
+  if (fused && h->knobs.sa_fused != 2) {
+    const FastPass& E0 = h->fast.passes.back();
+    const FastPass& E1 = h->fast.passes.front();
+    ring_n[0] = (int)small_grid(E0.sm.ntiles, E0.wpt); ring_n[1] = (int)small_grid(E1.sm.ntiles, E1.wpt);
+    ring = ring_n[0] <= SA_RING && ring_n[1] <= SA_RING;
+  }
+  if (ring) {
+    if (!h->sa_ring) {
+      HIPCHK(h, hipMalloc((void**)&h->sa_ring, sizeof(double) * 2 * SA_RING));
+      h->misc_allocs.push_back(h->sa_ring);
+    }
+    // iteration 0 reads "the error of iteration -1": open
+    std::vector<double> open((size_t)SA_RING, 1e300);
+    HIPCHK(h, hipMemcpyAsync(h->sa_ring + SA_RING, open.data(), sizeof(double) * SA_RING, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+  }
 
   // `count` iterations starting at global iteration it0 (it0 even whenever count == chunk)
   auto enqueue = [&](long long it0, int count) -> int {
-    HIPCHK(h, hipMemsetAsync(h->slots, 0, 8 * (size_t)chunk, h->stream));
+    if (!ring) HIPCHK(h, hipMemsetAsync(h->slots, 0, 8 * (size_t)chunk, h->stream));
     for (int i = 0; i < count; ++i) {
       const long long it = it0 + i;
-      int r2 = fused ? small_sa_iteration(h, it, bufs[it & 1], bufs[(it + 1) & 1], h->slots + i, i == 0 ? carry : h->slots + i - 1, o.tol)
+      int r2 = fused ? small_sa_iteration(h, it, bufs[it & 1], bufs[(it + 1) & 1], h->slots + i, i == 0 ? carry : h->slots + i - 1, o.tol,
+                                          ring, i == 0 ? nullptr : h->slots + i - 1)
                      : apply_T_dev(h, bufs[it & 1], bufs[(it + 1) & 1], h->slots + i, i == 0 ? carry : h->slots + i - 1, o.tol);
       if (r2) return r2;
     }
-    HIPCHK(h, hipMemcpyAsync(carry, h->slots + count - 1, 8, hipMemcpyDeviceToDevice, h->stream));
+    if (ring) {
+      const int par = (int)((it0 + count - 1) & 1);
+      hipLaunchKernelGGL(small_sa_finish, dim3(1), dim3(64), 0, h->stream, (const double*)(h->sa_ring + (size_t)par * SA_RING), ring_n[par], h->slots + count - 1);
+      HIPCHK(h, hipGetLastError());
+    } else HIPCHK(h, hipMemcpyAsync(carry, h->slots + count - 1, 8, hipMemcpyDeviceToDevice, h->stream));
     HIPCHK(h, hipMemcpyAsync(h->slots_host, h->slots, 8 * (size_t)count, hipMemcpyDeviceToHost, h->stream));
     return 0;
   };
@@ -2285,8 +2328,8 @@ int sdfs_describe_plan(const sdfs_handle* h, char* buf, int64_t cap) {
       const FastPass& P = h->fast.passes[i];
       int occ = -1;
       if (P.small) {
-        snprintf(line, sizeof line, "small-grid plan pass %zu: %s one wave per tile, run %d, tiles %lld, workgroups %lld\n", i,
-                 P.label.c_str(), P.r, P.sm.ntiles, (P.sm.ntiles + 3) / 4);
+        snprintf(line, sizeof line, "small-grid plan pass %zu: %s %d wave%s per tile, run %d, tiles %lld, workgroups %u\n", i,
+                 P.label.c_str(), P.wpt, P.wpt == 1 ? "" : "s", P.r, P.sm.ntiles, small_grid(P.sm.ntiles, P.wpt));
       } else if (!P.line) {
         hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)slice_variant(P.n, S_TFIRST), 256, slice_lds_bytes(P.n));
         const long long nt = (P.sd.nslices + slice_tile_slices(P.n) - 1) / slice_tile_slices(P.n);

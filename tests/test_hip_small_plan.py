@@ -71,12 +71,15 @@ CASES = [("ssy", (15, 15, 15, 15)), ("ssy", (16, 16, 16, 16)), ("ssy", (2, 3, 4,
          ("gcy", (3, 3, 12, 12, 13, 13))]
 
 
+@pytest.mark.parametrize("wpt", [1, 4])
 @pytest.mark.parametrize("run", [0, 1, 4])
 @pytest.mark.parametrize("model,shapes", CASES)
-def test_small_plan_T_jvp_vjp_vs_oracle(S, model, shapes, run):
+def test_small_plan_T_jvp_vjp_vs_oracle(S, model, shapes, run, wpt):
     """run = 0: the planner's own choice of run length; 1 / 4: forced (strided 2-D slices / 32-byte runs with
-    partial trailing chunks whenever the remainder is not a multiple of four)."""
-    Ts = build(S, model, shapes, SDFS_PLAN=None, SDFS_SMALL_R=run if run else None)
+    partial trailing chunks whenever the remainder is not a multiple of four).  wpt: waves per tile (1: four
+    wave-private tiles per workgroup; 4: one tile per workgroup)."""
+    Ts = build(S, model, shapes, SDFS_PLAN=None, SDFS_SMALL_R=run if run else None, SDFS_SMALL_WPT=wpt)
+    assert ("%d wave%s per tile" % (wpt, "" if wpt == 1 else "s")) in Ts.describe_plan()
     Tc = build(S, model, shapes, SDFS_PLAN="classic")
     assert "small-grid plan pass" in Ts.describe_plan(), Ts.describe_plan()
     assert "small-grid plan pass" not in Tc.describe_plan()
@@ -160,20 +163,23 @@ def test_small_plan_solvers_match_generic_plan(S, model, shapes):
     assert np.max(np.abs(xf - xo)) < 1e-8
 
 
+@pytest.mark.parametrize("wpt", [0, 1, 4])
 @pytest.mark.parametrize("model,shapes,run", [("ssy", (15, 15, 15, 15), 0), ("ssy", (3, 3, 3, 3), 0), ("ssy", (7, 13, 11, 9), 4),
                                               ("gcy", (5, 4, 6, 3, 4, 5), 0), ("gcy", (6,) * 6, 4), ("gcy", (3, 4, 5, 2, 3, 4), 1)])
-def test_fused_successive_approximation(S, model, shapes, run):
+def test_fused_successive_approximation(S, model, shapes, run, wpt):
     """SA on the small-grid plan reverses the pair order every iteration and runs the last pass of one application
-    with the first pass of the next as one kernel.  Same iteration count, error trace and iterate as one launch per
+    with the first pass of the next as one kernel; the sup-norm error travels as per-workgroup maxima that the next
+    iteration's kernels reduce (no atomics).  Same iteration count, error trace and iterate as one launch per
     pass (SDFS_SA_FUSED=0) and as the generic kernels, with and without hipGraph chunks, for odd chunk lengths and
     when max_iter cuts a chunk short."""
-    knobs = dict(SDFS_PLAN=None, SDFS_SMALL_R=run if run else None)
+    knobs = dict(SDFS_PLAN=None, SDFS_SMALL_R=run if run else None, SDFS_SMALL_WPT=wpt if wpt else None)
     Tf = build(S, model, shapes, **knobs)
     Tu = build(S, model, shapes, SDFS_SA_FUSED=0, **knobs)
+    Ta = build(S, model, shapes, SDFS_SA_FUSED=2, **knobs)            # fused kernels, residual through the atomic word
     Tc = build(S, model, shapes, SDFS_PLAN="classic")
     w0 = np.full(shapes, 800.0)
     xc, n_c, ic = Tc.solve(w0, "successive_approx", tol=1e-6, record_errors=True)
-    for T, kw in ((Tf, {}), (Tu, {}), (Tf, dict(check_every=7)), (Tf, dict(use_graph=0, check_every=5)), (Tf, dict(check_every=1))):
+    for T, kw in ((Tf, {}), (Tu, {}), (Ta, {}), (Ta, dict(check_every=3)), (Tf, dict(check_every=7)), (Tf, dict(use_graph=0, check_every=5)), (Tf, dict(check_every=1))):
         x, n, info = T.solve(w0, "successive_approx", tol=1e-6, record_errors=True, **kw)
         assert n == n_c and info["n_apply"] == n
         np.testing.assert_allclose(info["errors"], ic["errors"], rtol=1e-9, atol=1e-11)
