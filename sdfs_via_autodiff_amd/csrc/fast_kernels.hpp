@@ -31,12 +31,19 @@
 #include <type_traits>
 
 #include "pass_kernel.hpp"
+#include "wave_reduce.hpp"
 
 namespace sdfs {
 
 // roles (compile time)
-enum SliceMode { S_TFIRST = 0, S_TFIRST_LIN = 1, S_JFIRST = 2, S_NMODES = 3 };
-enum LineMode { L_MID = 0, L_TLAST = 1, L_TLAST_LIN = 2, L_JLAST = 3, L_NMODES = 4 };
+// S_MID: plain contraction of the pair (successive approximation, see L_TFUSED).
+// L_TFUSED: the last pass of one application of T and the first pass of the next in one kernel: contract the pair,
+// aggregator, residual, store Tw, then (Tw)^theta in the same LDS slots, the same two contractions again, and the
+// tile goes out as the next application's intermediate.  With LineDesc::first_only only the second half runs (the
+// prologue of the loop).  The contraction order of an application is free, so successive approximation on a 6-D
+// grid runs [slices, plain] [lines, fused] per iteration, the fused pass alternating between the two line pairs.
+enum SliceMode { S_TFIRST = 0, S_TFIRST_LIN = 1, S_JFIRST = 2, S_MID = 3, S_NMODES = 4 };
+enum LineMode { L_MID = 0, L_TLAST = 1, L_TLAST_LIN = 2, L_JLAST = 3, L_TFUSED = 4, L_NMODES = 5 };
 
 template <int N> struct MShape {
   static_assert(N == 16 || N == 20 || N == 24 || N == 32, "pair plan extents");
@@ -158,7 +165,7 @@ slice_kernel(const SliceDesc P, const SliceIO io) {
   constexpr bool LIN = MODE == S_TFIRST_LIN;
   constexpr bool MULP = MODE == S_JFIRST;
   constexpr bool JV32 = F32 && MULP;
-  static_assert(!F32 || MODE != S_TFIRST, "plain T has no fp32 form");
+  static_assert(!F32 || (MODE != S_TFIRST && MODE != S_MID), "plain T has no fp32 form");
   extern __shared__ double lds[];
   if (io.gate != nullptr) {
     const unsigned long long g = *io.gate;
@@ -310,6 +317,8 @@ struct LineDesc {
   const double* Qx;
   const double* Qy;
   double inv_theta, beta;
+  double theta;             // L_TFUSED: exponent of the next application's first pass
+  int first_only;           // L_TFUSED: skip the closing half (the tile holds w, not an intermediate)
   // aggregator scale a3 (current state), index = out_idx[o] + x * a3x + y * a3y + rest_idx[pos]
   const double* a3;
   const int* out_idx;
@@ -323,7 +332,7 @@ struct LineIO {
   const double* in;
   double* out;
   const double* aux_in;     // J.v: c2
-  double* aux_out;          // T + linearise: c2 = beta u / S
+  double* aux_out;          // T + linearise: c2 = beta u / S;  L_TFUSED: the next intermediate
   const double* old;        // T: w (residual);  J.v: v
   unsigned long long* resid;
   const unsigned long long* gate;
@@ -504,10 +513,12 @@ line_kernel(const LineDesc P, const LineIO io) {
     }
     return;
   }
-  constexpr bool CES = MODE == L_TLAST || MODE == L_TLAST_LIN;
+  constexpr bool FUSED = MODE == L_TFUSED;
+  constexpr bool CES = MODE == L_TLAST || MODE == L_TLAST_LIN || FUSED;
   constexpr bool LINE = MODE == L_TLAST_LIN;
   constexpr bool MULE = MODE == L_JLAST;
   constexpr bool PARTIAL = Geo::UNITS % B != 0;
+  static_assert(!FUSED || !PERSIST, "the fused form runs one tile per workgroup");
   constexpr int LOOK = 4;                                         // units of look-ahead in the epilogue
   extern __shared__ double lds[];
   __shared__ double red[16];
@@ -520,7 +531,8 @@ line_kernel(const LineDesc P, const LineIO io) {
   const int c2 = tid & 7;                                        // this thread's double2 inside the 16-double row
   const unsigned b0 = ((unsigned)(tid >> 3) * (unsigned)P.lrest + 2u * c2) * 8u;    // a tile spans < 4 GB (host check)
   const unsigned bstep = (unsigned)(B / 8) * (unsigned)P.lrest * 8u;
-  const bool need_old = CES ? (io.resid != nullptr) : (MULE && P.minus_identity);
+  const bool first_only = FUSED && P.first_only != 0;            // uniform
+  const bool need_old = CES ? (io.resid != nullptr && !first_only) : (MULE && P.minus_identity);
   const unsigned ntiles = PERSIST ? (unsigned)P.ntiles : 0u, gstep = gridDim.x;
   const char* const a3b = reinterpret_cast<const char*>(P.a3);
   const unsigned a3x = (unsigned)P.a3x, a3y = (unsigned)P.a3y;   // < 2^24 (host check)
@@ -553,7 +565,7 @@ line_kernel(const LineDesc P, const LineIO io) {
   for (;;) {
     if (PERSIST && tid == 0)                                      // ticket of the tile after this one
       next_tile[parity] = gstep + __hip_atomic_fetch_add(&io.sched[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    {
+    auto contract_tile = [&]() {
       QFrag<N> q;
       q.load(P.Qx, lane);
       __syncthreads();
@@ -572,7 +584,8 @@ line_kernel(const LineDesc P, const LineIO io) {
         for (int j = 0; j < N / Geo::W; ++j) ctile<N, LINE_R>(p0 + (wave + j * Geo::W) * Geo::LX, q);
       }
       __syncthreads();
-    }
+    };
+    if (!first_only) contract_tile();                              // (first_only: a thread's units are its own slots)
 
     const unsigned tn = PERSIST ? next_tile[parity] : 0u;        // written before the first of the three barriers above
     const bool has_next = PERSIST && tn < ntiles;                // uniform over the workgroup
@@ -585,7 +598,7 @@ line_kernel(const LineDesc P, const LineIO io) {
     char* const auxo = reinterpret_cast<char*>(io.aux_out + T.tbase);
     char* const auxo32 = reinterpret_cast<char*>(reinterpret_cast<float*>(io.aux_out) + T.tbase);
     unsigned ia3a = 0u, ia3b = 0u;                               // a3 index of this thread's two elements, less (x, y)
-    if (CES && cok) {
+    if (CES && cok && !first_only) {
       ia3a = (unsigned)(P.out_idx[T.o] + P.rest_idx[T.pos]);
       ia3b = (unsigned)(P.out_idx[T.o] + P.rest_idx[T.pos + 1]);
     }
@@ -593,6 +606,7 @@ line_kernel(const LineDesc P, const LineIO io) {
     // ---- epilogue: unit k of tile t, with the loads of unit k + LOOK (and of tile t+1) ahead of it --------
     double2 vw[LOOK], sw[LOOK], cw[LOOK];     // next tile's unit; side stream 1 (w / v); side stream 2 (a3 pair / c2)
     auto issue = [&](const int k, double2& vn, double2& s1, double2& s2) {
+      if (first_only) return;
       const int u = tid + k * B;
       const bool rowok = k < EPT && (!PARTIAL || u < Geo::UNITS);
       const unsigned off = b0 + (unsigned)k * bstep;
@@ -633,6 +647,14 @@ line_kernel(const LineDesc P, const LineIO io) {
       const unsigned off = b0 + (unsigned)k * bstep;
       double2* const slot = reinterpret_cast<double2*>(lds + 2 * (rowok ? u : tid));
       const double2 sv = *slot;
+      if (first_only) {
+        // the tile holds w: x = w^theta in place (masked lanes feed the power 1)
+        const double xin[2] = {ok ? sv.x : 1.0, ok ? sv.y : 1.0};
+        double xw[2];
+        pow_fast_n<true, 2>(xin, P.theta, PT, xw);
+        if (rowok) *slot = make_double2(xw[0], xw[1]);
+        return;
+      }
       if (CES) {
         // Tw = 1 + beta (a3 S)^(1/theta), c2 = beta u / S, |Tw - w|.  Uniform trip: every lane runs the power
         // (its table gathers need the whole wave); masked lanes feed it 1 (under FULLC: real values of the
@@ -654,6 +676,13 @@ line_kernel(const LineDesc P, const LineIO io) {
             rmax = fmax(rmax, fmax(r0, r1));
           }
           *reinterpret_cast<double2*>(outb + off) = y2;
+        }
+        if (FUSED) {
+          // the next application's first pass on this pair: x = (Tw)^theta into the slot just read
+          const double xin[2] = {ok ? y2.x : 1.0, ok ? y2.y : 1.0};
+          double xw[2];
+          pow_fast_n<true, 2>(xin, P.theta, PT, xw);
+          if (rowok) *slot = make_double2(xw[0], xw[1]);
         }
       } else if (ok) {
         double2 y2 = sv;
@@ -684,6 +713,16 @@ line_kernel(const LineDesc P, const LineIO io) {
 #pragma unroll
     for (int j = 0; j < EPT % LOOK; ++j) unit(EPT - EPT % LOOK + j, vw[j], sw[j], cw[j]);
 
+    if (FUSED) {
+      contract_tile();                                             // (its first barrier closes the epilogue's LDS writes)
+      char* const tb = reinterpret_cast<char*>(io.aux_out + T.tbase);
+#pragma unroll
+      for (int k = 0; k < EPT; ++k) {
+        const int u = tid + k * B;
+        if ((FULLC || cok) && (!PARTIAL || u < Geo::UNITS))
+          *reinterpret_cast<double2*>(tb + (b0 + (unsigned)k * bstep)) = *reinterpret_cast<const double2*>(lds + 2 * u);
+      }
+    }
     if (!has_next) break;
     t = tn;
     T = Tn;
@@ -781,34 +820,6 @@ struct SmallIO {
   double* part_out;
   unsigned long long* slot_out;
 };
-
-// Wave reductions on the VALU (DPP moves inside the rows of 16, v_readlane across the four rows): ~30 instructions
-// where six __shfl_xor steps of a double are twelve LDS-crossbar round trips (~1000 cycles measured at the end of
-// a small-grid kernel, tools/probes/small_fused_probe.hip).  Every lane must be active; the result is wave-uniform.
-template <int CTRL> __device__ __forceinline__ double dpp_mov_f64(double v) {
-  int lo = __double2loint(v), hi = __double2hiint(v);
-  lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
-  hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
-  return __hiloint2double(hi, lo);
-}
-__device__ __forceinline__ double readlane_f64(double v, int l) {
-  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
-}
-// quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror, row_mirror: afterwards every lane holds its row's result
-__device__ __forceinline__ double wave_max_f64(double v) {      // NaN-free input (fmax drops NaNs)
-  v = fmax(v, dpp_mov_f64<0xB1>(v));
-  v = fmax(v, dpp_mov_f64<0x4E>(v));
-  v = fmax(v, dpp_mov_f64<0x141>(v));
-  v = fmax(v, dpp_mov_f64<0x140>(v));
-  return fmax(fmax(readlane_f64(v, 0), readlane_f64(v, 16)), fmax(readlane_f64(v, 32), readlane_f64(v, 48)));
-}
-__device__ __forceinline__ double wave_sum_f64(double v) {
-  v += dpp_mov_f64<0xB1>(v);
-  v += dpp_mov_f64<0x4E>(v);
-  v += dpp_mov_f64<0x141>(v);
-  v += dpp_mov_f64<0x140>(v);
-  return (readlane_f64(v, 0) + readlane_f64(v, 16)) + (readlane_f64(v, 32) + readlane_f64(v, 48));
-}
 
 // element e of a tile -> LDS offset, global element offset against the tile base, a3 index part, position
 template <int R>
@@ -1121,6 +1132,7 @@ template <int N> inline slice_fn slice_variant_n(int mode, bool f32) {
     case S_TFIRST: return f32 ? nullptr : (slice_fn)slice_kernel<N, S_TFIRST, false>;
     case S_TFIRST_LIN: return f32 ? (slice_fn)slice_kernel<N, S_TFIRST_LIN, true> : (slice_fn)slice_kernel<N, S_TFIRST_LIN, false>;
     case S_JFIRST: return f32 ? (slice_fn)slice_kernel<N, S_JFIRST, true> : (slice_fn)slice_kernel<N, S_JFIRST, false>;
+    case S_MID: return f32 ? nullptr : (slice_fn)slice_kernel<N, S_MID, false>;
     default: return nullptr;
   }
 }
@@ -1140,6 +1152,7 @@ template <int N, bool PERSIST, bool FULLC> inline line_fn line_variant_n(int mod
     case L_TLAST: return (line_fn)line_kernel<N, L_TLAST, PERSIST, FULLC, false>;
     case L_TLAST_LIN: return (line_fn)line_kernel<N, L_TLAST_LIN, PERSIST, FULLC, false>;
     case L_JLAST: return (line_fn)line_kernel<N, L_JLAST, PERSIST, FULLC, false>;
+    case L_TFUSED: if constexpr (!PERSIST) return (line_fn)line_kernel<N, L_TFUSED, false, FULLC, false>; else return nullptr;
     default: return nullptr;
   }
 }

@@ -105,6 +105,7 @@ struct Knobs {
   int small_plan = 1;          // SDFS_SMALL_PLAN: 0 = never use the small-grid pair plan
   int small_r = 0;             // SDFS_SMALL_R: force the run length of its line passes (1 or 4)
   int small_wpt = 0;           // SDFS_SMALL_WPT: force its waves per tile (1 or 4)
+  int and_host = 0;            // SDFS_AND_HOST: 1 = Anderson with the Gram solve on the host (one synchronisation per iteration)
   int sa_fused = 1;            // SDFS_SA_FUSED: 0 = successive approximation on the small-grid plan keeps one launch per pass
   int ablate = 0;              // SDFS_ABLATE, honoured only by -DSDFS_DIAG builds
 };
@@ -132,6 +133,13 @@ struct sdfs_handle {
   Plan plan[2];
   FastPlan fast;                      // pair plan of the full grid, when the model admits it
   unsigned* sched = nullptr;          // tile tickets of the persistent line pass (two words per pass, zero between launches)
+  AndState* and_state = nullptr;      // device-resident Anderson loop: state, per-chunk record of its passes
+  AndState* and_state_host = nullptr;
+  double* and_err = nullptr; int* and_kind = nullptr; int and_slots = 0;
+  double* and_err_host = nullptr; int* and_kind_host = nullptr;
+  hipGraphExec_t and_graph = nullptr;
+  int and_graph_chunk = 0, and_graph_m = 0, and_graph_freq = 0;
+  double and_graph_key[4] = {0, 0, 0, 0};   // tol, max_iter, beta, ridge: baked into the captured kernel arguments
   double* sa_ring = nullptr;          // small-grid SA: per-workgroup residual maxima of the last two iterations [2][SA_RING]
   std::vector<void*> misc_allocs;     // device index tables of the pair plan
   bool sharded = false;
@@ -243,6 +251,7 @@ Knobs read_knobs() {
   k.small_r = env_int("SDFS_SMALL_R", 0);
   k.sa_fused = env_int("SDFS_SA_FUSED", 1);
   k.small_wpt = env_int("SDFS_SMALL_WPT", 0);
+  k.and_host = env_int("SDFS_AND_HOST", 0);
   const char* pl = getenv("SDFS_PLAN");
   if (pl && !strcmp(pl, "classic")) k.plan = 1;
   else if (pl && !strcmp(pl, "pair")) k.plan = 2;
@@ -514,7 +523,9 @@ struct ProfScope {
 };
 
 int vec_grid(long long n) {
-  long long g = (n + VEC_BLOCK * 4 - 1) / (VEC_BLOCK * 4);
+  // one 16-byte packet per thread up to the cap: small grids are latency-bound, a second trip through a thread's
+  // grid-stride loop costs a memory round trip (15^4: k_and_push 8.2 us with 50 workgroups of two trips)
+  long long g = (n + VEC_BLOCK * 2 - 1) / (VEC_BLOCK * 2);
   return (int)std::max<long long>(1, std::min<long long>(g, MAX_PARTIAL_BLOCKS));
 }
 
@@ -748,7 +759,7 @@ int build_fast_plan(sdfs_handle* h) {
     L.ntiles = L.nouter * L.nchunks;
     if (L.ntiles >= (1LL << 31) || (long long)n * n * L.lrest * 8 >= (1LL << 32)) return 0;
     L.Qx = h->ax[a].Q; L.Qy = h->ax[a + 1].Q;
-    L.inv_theta = 1.0 / h->theta; L.beta = h->beta;
+    L.inv_theta = 1.0 / h->theta; L.beta = h->beta; L.theta = h->theta;
     L.a3x = h->ax[a].a3s; L.a3y = h->ax[a + 1].a3s;
     for (int c = D - 1; c >= 0; --c) L.ref_off += (long long)(h->shape[c] / 2) * stride[c];
     min_tiles = std::min(min_tiles, L.ntiles);
@@ -760,8 +771,9 @@ int build_fast_plan(sdfs_handle* h) {
   if (h->knobs.plan != 2 && min_tiles < 2LL * h->num_cus) return 0;      // too few tiles to fill the chip
   // index tables of the aggregator's a3 gather (last pass = the slowest pair): a3 index =
   // out_idx[outer] + x a3s[X] + y a3s[Y] + rest_idx[position behind Y]
-  {
-    FastPass& P = passes.back();
+  // (successive approximation ends its applications on either line pair in turn: tables for every line pass)
+  for (size_t pi = 1; pi < passes.size(); ++pi) {
+    FastPass& P = passes[pi];
     const int a = P.ax0;
     std::vector<int> outv((size_t)P.ld.nouter, 0), restv((size_t)P.ld.lrest, 0);
     for (long long o = 0; o < P.ld.nouter; ++o) {
@@ -789,6 +801,7 @@ int build_fast_plan(sdfs_handle* h) {
       if (f32) hipFuncSetAttribute((const void*)f32, hipFuncAttributeMaxDynamicSharedMemorySize, (int)slice_lds_bytes(P.n));
     } else for (int m = 0; m < L_NMODES; ++m) for (int pe = 0; pe < 2; ++pe) {
       line_fn f = line_variant(P.n, m, pe != 0, P.ld.lrest % LINE_R == 0);
+      if (!f && m == L_TFUSED && pe != 0) continue;          // one tile per workgroup only
       if (!f) return 0;
       hipFuncSetAttribute((const void*)f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)line_lds_bytes(P.n));
       line_fn f32 = line_variant(P.n, m, false, true, true);
@@ -1090,6 +1103,50 @@ int ensure_scalars(sdfs_handle* h) {
   return 0;
 }
 
+// Successive approximation on the 6-D pair plan (fast_kernels.hpp, L_TFUSED): the contraction order of an
+// application is free, so iteration `it` runs [slices, plain contraction] [lines L(it), fused], where the fused
+// kernel closes application `it` on line pair L(it) = passes[1 + (it & 1)] (aggregator, residual, Tw) and opens
+// application it+1 on the same pair.  Invariant before iteration `it`: h->tmp holds w_it^theta contracted over
+// the OTHER line pair.  7 grid streams per iteration become 6, the strided middle pass becomes a contiguous one.
+int big_sa_line(sdfs_handle* h, int pass, bool first_only, const double* in, double* w_new, const double* w_old,
+                unsigned long long* resid, const unsigned long long* gate, double gate_tol) {
+  const FastPass& P = h->fast.passes[pass];
+  LineIO io;
+  memset(&io, 0, sizeof io);
+  io.in = in; io.out = w_new; io.old = w_old; io.resid = resid; io.aux_out = h->tmp; io.gate = gate; io.gate_tol = gate_tol;
+  io.sched = h->sched + 2 * pass;
+  LineDesc d = P.ld;
+  d.first_only = first_only ? 1 : 0;
+  line_fn fn = line_variant(P.n, L_TFUSED, false, P.ld.lrest % LINE_R == 0);
+  if (!fn) return fail(h, SDFS_ERR_UNSUPPORTED, "no fused line kernel variant");
+  int cid = -1;
+  const double n8 = 8.0 * (double)h->N;
+  if (h->profiling) cid = counter_id(h, ((first_only ? "sa:open " : "sa:fused ") + P.label).c_str(), (first_only ? 2 : 4) * n8 + P.q_bytes, (first_only ? 1 : 2) * P.flops);
+  ProfScope ps(h, cid);
+  hipLaunchKernelGGL(fn, dim3((unsigned)d.ntiles), dim3(line_block(P.n)), line_lds_bytes(P.n), h->stream, d, io);
+  HIPCHK(h, hipGetLastError());
+  return 0;
+}
+
+int big_sa_iteration(sdfs_handle* h, long long it, const double* w_old, double* w_new, unsigned long long* resid,
+                     const unsigned long long* gate, double gate_tol) {
+  const FastPass& P = h->fast.passes[0];
+  SliceIO io;
+  memset(&io, 0, sizeof io);
+  io.in = h->tmp; io.out = h->tmp; io.gate = gate; io.gate_tol = gate_tol;
+  slice_fn fn = slice_variant(P.n, S_MID, false);
+  if (!fn) return fail(h, SDFS_ERR_UNSUPPORTED, "no plain slice kernel variant");
+  {
+    int cid = -1;
+    if (h->profiling) cid = counter_id(h, ("sa:" + P.label).c_str(), 16.0 * (double)h->N + P.q_bytes, P.flops);
+    const long long ntile = (P.sd.nslices + slice_tile_slices(P.n) - 1) / slice_tile_slices(P.n);
+    ProfScope ps(h, cid);
+    hipLaunchKernelGGL(fn, dim3((unsigned)((ntile + 3) / 4)), dim3(256), slice_lds_bytes(P.n), h->stream, P.sd, io);
+    HIPCHK(h, hipGetLastError());
+  }
+  return big_sa_line(h, 1 + (int)(it & 1), false, h->tmp, w_new, w_old, resid, gate, gate_tol);
+}
+
 // Successive approximation on the small-grid plan (fast_kernels.hpp, SM_FUSED_T): the pair order is reversed
 // every iteration, so the last pass of one application and the first pass of the next act on the same pair and
 // run as one kernel.  Invariant before iteration `it`: h->tmp holds the first pair of this iteration's order
@@ -1168,6 +1225,9 @@ int solve_sa(sdfs_handle* h, const sdfs_opts& o, double* w, int64_t* n_iter, int
   // small-grid plan: last pass of iteration k and first pass of iteration k+1 in one kernel (pair order alternates)
   const bool fused = h->fast.ok && h->fast.small && !h->cont && !h->dense && h->knobs.sa_fused != 0;
   if (fused && (rc = small_sa_prologue(h, h->buf0))) return rc;
+  // 6-D pair plan: plain slice pass + fused line pass per iteration
+  const bool fusedbig = h->fast.ok && !h->fast.small && h->fast.passes.size() == 3 && !h->cont && !h->dense && h->knobs.sa_fused != 0;
+  if (fusedbig && (rc = big_sa_line(h, 2, true, h->buf0, nullptr, nullptr, nullptr, nullptr, 0.0))) return rc;
   // ... and the residual without atomics: per-workgroup maxima, reduced by the next iteration's kernels
   bool ring = false;
   int ring_n[2] = {0, 0};
@@ -1195,6 +1255,7 @@ int solve_sa(sdfs_handle* h, const sdfs_opts& o, double* w, int64_t* n_iter, int
       const long long it = it0 + i;
       int r2 = fused ? small_sa_iteration(h, it, bufs[it & 1], bufs[(it + 1) & 1], h->slots + i, i == 0 ? carry : h->slots + i - 1, o.tol,
                                           ring, i == 0 ? nullptr : h->slots + i - 1)
+                     : fusedbig ? big_sa_iteration(h, it, bufs[it & 1], bufs[(it + 1) & 1], h->slots + i, i == 0 ? carry : h->slots + i - 1, o.tol)
                      : apply_T_dev(h, bufs[it & 1], bufs[(it + 1) & 1], h->slots + i, i == 0 ? carry : h->slots + i - 1, o.tol);
       if (r2) return r2;
     }
@@ -1442,7 +1503,7 @@ bool solve_dense(std::vector<double>& A, std::vector<double>& b, int n) {
 }
 
 // Anderson acceleration with jaxopt's parametrisation (code/solvers.py:98-124).
-int solve_anderson(sdfs_handle* h, const sdfs_opts& o, double* w, int64_t* n_iter, int64_t* n_apply, double* final_err) {
+int solve_anderson_host(sdfs_handle* h, const sdfs_opts& o, double* w, int64_t* n_iter, int64_t* n_apply, double* final_err) {
   int rc;
   const int m = o.history;
   if (m < 1 || m > AND_MAX_M) return fail(h, SDFS_ERR_ARG, "Anderson history must be in 1..%d", AND_MAX_M);
@@ -1532,6 +1593,123 @@ int solve_anderson(sdfs_handle* h, const sdfs_opts& o, double* w, int64_t* n_ite
   HIPCHK(h, hipStreamSynchronize(st));
   *n_iter = it; *n_apply = it; *final_err = err;
   if (status) return fail(h, status, "non-finite Anderson residual at iteration %lld", it);
+  return 0;
+}
+
+// The same loop with its control on the device (vec_kernels.hpp, AndState / k_and_step / k_and_mix_dev): per pass
+// T, push, one single-workgroup step kernel (Gram row, solve, safeguard, stopping test) and the update of x, every
+// launch gated on the loop's own flag; `chunk` passes per host synchronisation, replayed from a hipGraph.
+int solve_anderson(sdfs_handle* h, const sdfs_opts& o, double* w, int64_t* n_iter, int64_t* n_apply, double* final_err) {
+  if (h->knobs.and_host) return solve_anderson_host(h, o, w, n_iter, n_apply, final_err);
+  int rc;
+  const int m = o.history;
+  if (m < 1 || m > AND_MAX_M) return fail(h, SDFS_ERR_ARG, "Anderson history must be in 1..%d", AND_MAX_M);
+  if (o.mixing_freq < 1) return fail(h, SDFS_ERR_ARG, "mixing_freq must be >= 1");
+  if ((rc = ensure_buf(h, &h->buf0)) || (rc = ensure_buf(h, &h->buf1)) || (rc = ensure_scalars(h)) || (rc = ensure_tmp(h))) return rc;
+  while ((int)h->andX.size() < m) {
+    double *a = nullptr, *b = nullptr;
+    if ((rc = dev_alloc(h, &a, (size_t)h->N)) || (rc = dev_alloc(h, &b, (size_t)h->N))) return rc;
+    h->andX.push_back(a); h->andR.push_back(b);
+  }
+  // passes per synchronisation: a multiple of the history length, so that the slot of pass i of a chunk is fixed
+  int chunk = std::max(1, o.check_every);
+  chunk = ((chunk + m - 1) / m) * m;
+  if (!h->and_state) {
+    HIPCHK(h, hipMalloc((void**)&h->and_state, sizeof(AndState)));
+    h->misc_allocs.push_back(h->and_state);
+    HIPCHK(h, hipHostMalloc((void**)&h->and_state_host, sizeof(AndState)));
+  }
+  if (h->and_slots < chunk) {
+    if (h->and_graph) { hipGraphExecDestroy(h->and_graph); h->and_graph = nullptr; }
+    if (h->and_err_host) { hipHostFree(h->and_err_host); hipHostFree(h->and_kind_host); }
+    HIPCHK(h, hipMalloc((void**)&h->and_err, sizeof(double) * chunk));
+    h->misc_allocs.push_back(h->and_err);
+    HIPCHK(h, hipMalloc((void**)&h->and_kind, sizeof(int) * chunk));
+    h->misc_allocs.push_back(h->and_kind);
+    HIPCHK(h, hipHostMalloc((void**)&h->and_err_host, sizeof(double) * chunk));
+    HIPCHK(h, hipHostMalloc((void**)&h->and_kind_host, sizeof(int) * chunk));
+    h->and_slots = chunk;
+  }
+  AndPtrs hp;
+  memset(&hp, 0, sizeof hp);
+  for (int j = 0; j < m; ++j) { hp.X[j] = h->andX[j]; hp.R[j] = h->andR[j]; }
+  const long long n = h->N;
+  const int g = vec_grid(n);
+  const size_t nb = sizeof(double) * (size_t)n;
+  hipStream_t st = h->stream;
+  double* x = h->buf0;
+  double* fx = h->buf1;
+  HIPCHK(h, hipMemcpyAsync(x, w, nb, hipMemcpyDeviceToDevice, st));
+  for (int j = 0; j < m; ++j) HIPCHK(h, hipMemsetAsync(h->andR[j], 0, nb, st));
+  AndState* S = h->and_state;
+  {
+    AndState& I = *h->and_state_host;
+    memset(&I, 0, sizeof I);
+    I.err = std::numeric_limits<double>::infinity();
+    I.prev_pos = -1.0; I.mix_rel = -1;
+    I.gate = (o.max_iter > 0 && I.err > o.tol) ? ~0ULL : 0ULL;
+    HIPCHK(h, hipMemcpyAsync(S, &I, sizeof I, hipMemcpyHostToDevice, st));
+    HIPCHK(h, hipStreamSynchronize(st));
+  }
+  h->trace.clear();
+  const int cvec = h->profiling ? counter_id(h, "anderson_blas1", 0, 0) : -1;
+  auto enqueue = [&](int count) -> int {
+    HIPCHK(h, hipMemsetAsync(h->and_kind, 0, sizeof(int) * (size_t)chunk, st));
+    for (int i = 0; i < count; ++i) {
+      const int pos = i % m;                       // chunks start on multiples of m
+      int r2 = apply_T_dev(h, x, fx, nullptr, &S->gate, 0.0);
+      if (r2) return r2;
+      ProfScope ps(h, cvec);
+      hipLaunchKernelGGL(k_and_push, dim3(g), dim3(VEC_BLOCK), 0, st, (const double*)x, (const double*)fx, hp, m, pos, n, h->partial, (const unsigned long long*)&S->gate);
+      hipLaunchKernelGGL(k_and_step, dim3(1), dim3(VEC_BLOCK), 0, st, (const double*)h->partial, g, m, pos, i, S, h->and_err + i, h->and_kind + i,
+                         o.tol, (double)o.max_iter, (int)o.mixing_freq, o.ridge);
+      hipLaunchKernelGGL(k_and_mix_dev, dim3(g), dim3(VEC_BLOCK), 0, st, hp, (const AndState*)S, m, o.beta, x, (const double*)fx, pos, i, n);
+    }
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipMemcpyAsync(h->and_err_host, h->and_err, sizeof(double) * (size_t)count, hipMemcpyDeviceToHost, st));
+    HIPCHK(h, hipMemcpyAsync(h->and_kind_host, h->and_kind, sizeof(int) * (size_t)count, hipMemcpyDeviceToHost, st));
+    HIPCHK(h, hipMemcpyAsync(h->and_state_host, S, sizeof(AndState), hipMemcpyDeviceToHost, st));
+    return 0;
+  };
+  const bool graph = o.use_graph && !h->profiling && st != nullptr && chunk > 1;
+  const double key[4] = {o.tol, (double)o.max_iter, o.beta, o.ridge};
+  if (graph && (h->and_graph == nullptr || h->and_graph_chunk != chunk || h->and_graph_m != m || h->and_graph_freq != (int)o.mixing_freq ||
+                memcmp(key, h->and_graph_key, sizeof key) != 0)) {
+    if (h->and_graph) { hipGraphExecDestroy(h->and_graph); h->and_graph = nullptr; }
+    hipGraph_t gr = nullptr;
+    HIPCHK(h, hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+    rc = enqueue(chunk);
+    hipError_t e = hipStreamEndCapture(st, &gr);
+    if (rc || e != hipSuccess) {
+      if (gr) hipGraphDestroy(gr);
+      if (rc) return rc;
+      HIPCHK(h, e);
+    }
+    e = hipGraphInstantiate(&h->and_graph, gr, nullptr, nullptr, 0);
+    hipGraphDestroy(gr);
+    HIPCHK(h, e);
+    h->and_graph_chunk = chunk; h->and_graph_m = m; h->and_graph_freq = (int)o.mixing_freq;
+    memcpy(h->and_graph_key, key, sizeof key);
+  }
+  long long enq = 0;          // passes enqueued so far (a multiple of chunk while the loop runs)
+  bool running = h->and_state_host->gate != 0ULL;
+  while (running && enq < o.max_iter) {
+    const int count = (int)std::min<long long>(chunk, o.max_iter - enq);
+    if (graph && count == chunk) { HIPCHK(h, hipGraphLaunch(h->and_graph, st)); }
+    else if ((rc = enqueue(count))) return rc;
+    HIPCHK(h, hipStreamSynchronize(st));
+    enq += count;
+    if (o.record_errors)
+      for (int i = 0; i < count; ++i) if (h->and_kind_host[i] == 1) h->trace.push_back(h->and_err_host[i]);
+    running = h->and_state_host->gate != 0ULL;
+  }
+  const AndState& F = *h->and_state_host;
+  const long long it = (long long)F.it;
+  const double err = F.err;
+  HIPCHK(h, hipMemcpyAsync(w, x, nb, hipMemcpyDeviceToDevice, st));
+  HIPCHK(h, hipStreamSynchronize(st));
+  *n_iter = it; *n_apply = it; *final_err = err;
+  if (F.status != 0.0) return fail(h, SDFS_ERR_NUMERIC, "non-finite Anderson residual at iteration %lld", it);
   return 0;
 }
 
@@ -2054,6 +2232,9 @@ void sdfs_destroy(sdfs_handle* h) {
   hipSetDevice(h->device);
   if (h->stream) hipStreamSynchronize(h->stream);
   if (h->sa_graph) hipGraphExecDestroy(h->sa_graph);
+  if (h->and_graph) hipGraphExecDestroy(h->and_graph);
+  if (h->and_state_host) hipHostFree(h->and_state_host);
+  if (h->and_err_host) { hipHostFree(h->and_err_host); hipHostFree(h->and_kind_host); }
   for (int i = 0; i < 2; ++i) if (h->bicg_graph[i]) hipGraphExecDestroy(h->bicg_graph[i]);
   for (double* p : h->dev_allocs) hipFree(p);
   for (void* p : h->misc_allocs) hipFree(p);
@@ -2091,6 +2272,7 @@ int sdfs_set_stream(sdfs_handle* h, void* s, int use_own) {
   int rc = check(h); if (rc) return rc;
   hipStream_t ns = use_own ? h->own_stream : (hipStream_t)s;     // s == NULL is the device's default stream
   if (ns != h->stream && h->sa_graph) { hipGraphExecDestroy(h->sa_graph); h->sa_graph = nullptr; }
+  if (ns != h->stream && h->and_graph) { hipGraphExecDestroy(h->and_graph); h->and_graph = nullptr; }
   if (ns != h->stream) for (int i = 0; i < 2; ++i) if (h->bicg_graph[i]) { hipGraphExecDestroy(h->bicg_graph[i]); h->bicg_graph[i] = nullptr; }
   h->stream = ns;
   return 0;

@@ -10,6 +10,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "wave_reduce.hpp"
+
 namespace sdfs {
 
 constexpr int VEC_BLOCK = 256;
@@ -27,34 +29,32 @@ enum {
 // and the launches behind the last real iteration are no-ops: same iterates as one sync per iteration.
 #define SDFS_GATED(gate) do { if ((gate) != nullptr && *(gate) == 0ULL) return; } while (0)
 
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-  return v;
-}
-__device__ __forceinline__ double wave_max(double v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
-  return v;
-}
+// (every lane active; the result is wave-uniform)
+__device__ __forceinline__ double wave_sum(double v) { return wave_sum_f64(v); }
+__device__ __forceinline__ double wave_max(double v) { return wave_max_f64(v); }
 
 // block-level sum of up to NV values per thread -> partial[blockIdx.x + k*gridDim.x]
+// (nv: streams in use, the rest is skipped)
 template <int NV>
-__device__ __forceinline__ void block_partials(const double (&v)[NV], double* __restrict__ partial) {
+__device__ __forceinline__ void block_partials(const double (&v)[NV], double* __restrict__ partial, int nv = NV) {
   __shared__ double sm[NV][VEC_BLOCK / 64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
   for (int k = 0; k < NV; ++k) {
-    const double s = wave_sum(v[k]);
-    if (lane == 0) sm[k][wave] = s;
+    if (k < nv) {
+      const double s = wave_sum(v[k]);
+      if (lane == 0) sm[k][wave] = s;
+    }
   }
   __syncthreads();
   if (threadIdx.x == 0) {
 #pragma unroll
     for (int k = 0; k < NV; ++k) {
-      double s = 0.0;
-      for (int w = 0; w < VEC_BLOCK / 64; ++w) s += sm[k][w];
-      partial[blockIdx.x + (size_t)k * gridDim.x] = s;
+      if (k < nv) {
+        double s = 0.0;
+        for (int w = 0; w < VEC_BLOCK / 64; ++w) s += sm[k][w];
+        partial[blockIdx.x + (size_t)k * gridDim.x] = s;
+      }
     }
   }
 }
@@ -352,32 +352,41 @@ struct AndPtrs { double* X[AND_MAX_M]; double* R[AND_MAX_M]; };
 
 __global__ void __launch_bounds__(VEC_BLOCK)
 k_and_push(const double* __restrict__ x, const double* __restrict__ fx, AndPtrs h, int m, int pos,
-           long long n, double* __restrict__ partial) {
+           long long n, double* __restrict__ partial, const unsigned long long* gate = nullptr) {
+  SDFS_GATED(gate);
   double acc[AND_MAX_M];
 #pragma unroll
   for (int j = 0; j < AND_MAX_M; ++j) acc[j] = 0.0;
-#define BODY(W_) { double x_[W_], f_[W_], r_[W_]; LDx<W_>(x, e, x_); LDx<W_>(fx, e, f_); \
+  // every history stream is requested before the first one is used (a load inside the branch that consumes it
+  // would cost one memory round trip per stream)
+#define BODY(W_) { double x_[W_], f_[W_], r_[W_], o_[AND_MAX_M][W_]; LDx<W_>(x, e, x_); LDx<W_>(fx, e, f_); \
+                   _Pragma("unroll") for (int j = 0; j < AND_MAX_M; ++j) { if (j < m && j != pos) LDx<W_>((const double*)h.R[j], e, o_[j]); } \
                    _Pragma("unroll") for (int q = 0; q < W_; ++q) r_[q] = f_[q] - x_[q]; \
                    STx<W_>(h.X[pos], e, x_); STx<W_>(h.R[pos], e, r_); \
                    _Pragma("unroll") for (int j = 0; j < AND_MAX_M; ++j) { \
                      if (j < m) { \
-                       double o_[W_]; \
-                       if (j == pos) { _Pragma("unroll") for (int q = 0; q < W_; ++q) o_[q] = r_[q]; } \
-                       else LDx<W_>((const double*)h.R[j], e, o_); \
-                       _Pragma("unroll") for (int q = 0; q < W_; ++q) acc[j] += r_[q] * o_[q]; } } }
+                       if (j == pos) { _Pragma("unroll") for (int q = 0; q < W_; ++q) acc[j] += r_[q] * r_[q]; } \
+                       else { _Pragma("unroll") for (int q = 0; q < W_; ++q) acc[j] += r_[q] * o_[j][q]; } } } }
   SDFS_PACKET_LOOP(double, n, BODY)
 #undef BODY
-  block_partials<AND_MAX_M>(acc, partial);
+  block_partials<AND_MAX_M>(acc, partial, m);
 }
 
-// one block: gram_row[j] = sum of partial stream j
+// Gram row from the per-workgroup partial sums: wave w of the (single) workgroup sums the streams w, w + 4, ...
+// (one routine for the host-controlled and the device-resident loop: the Gram matrix is ill-conditioned and the
+// iteration path follows its last bits, so both loops must add in the same order)
+__device__ __forceinline__ void gram_row_sums(const double* __restrict__ partial, int nb, int m, double* __restrict__ row) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int j = wave; j < m; j += VEC_BLOCK / 64) {
+    double s = 0.0;
+    for (int i = lane; i < nb; i += 64) s += partial[i + (size_t)j * nb];
+    s = wave_sum(s);
+    if (lane == 0) row[j] = s;
+  }
+}
 __global__ void __launch_bounds__(VEC_BLOCK)
 k_and_push_finish(const double* __restrict__ partial, int nb, int m, double* __restrict__ gram_row) {
-  for (int j = 0; j < m; ++j) {
-    const double s = finish_sum(partial, nb, j);
-    if (threadIdx.x == 0) gram_row[j] = s;
-    __syncthreads();
-  }
+  gram_row_sums(partial, nb, m, gram_row);
 }
 
 struct AndCoef { double a[AND_MAX_M]; };
@@ -391,6 +400,150 @@ k_and_mix(AndPtrs h, AndCoef c, int m, double beta, double* __restrict__ xnext, 
                        _Pragma("unroll") for (int q = 0; q < W_; ++q) { xa[q] += c.a[j] * x_[q]; ra[q] += c.a[j] * r_[q]; } } } \
                    _Pragma("unroll") for (int q = 0; q < W_; ++q) xa[q] = xa[q] + beta * ra[q]; \
                    STx<W_>(xnext, e, xa); }
+  SDFS_PACKET_LOOP(double, n, BODY)
+#undef BODY
+}
+
+// ---- Anderson, device-resident control -------------------------------------------------------------------------
+// The loop of solve_anderson (sdfs_api.hip) -- Gram matrix, the (m+1) x (m+1) solve of jaxopt's parametrisation
+// (code/solvers.py:98-124), the rejection safeguard and the stopping test -- as state in device memory, advanced by
+// one single-workgroup kernel per iteration, so that the host enqueues (or replays from a hipGraph) whole chunks of
+// iterations and synchronises once per chunk.
+struct AndState {
+  double G[AND_MAX_M * AND_MAX_M];
+  double coef[AND_MAX_M];
+  double mix_beta;
+  double err;
+  double it;                 // loop passes executed
+  double rejected, no_mix_until, last_mixed, prev_pos;
+  double status;             // 1: non-finite residual ended the loop
+  unsigned long long gate;   // ~0 while the loop runs, 0 once it has ended
+  int mix_rel;               // index (within the chunk) of the pass whose update of x is due
+  int mix_mode;              // 0: x = fx;  1: x = sum_j coef_j (X_j + mix_beta R_j);  2: the same and R[pos] = 0 (rejected step)
+};
+
+// (mode 2 leaves the poisoned history slot `pos` out of the sum: its residual is NaN until the same kernel has zeroed it)
+// kinds of a pass in the per-chunk record: 0 = not executed (loop had ended), 1 = regular (its error joins the trace), 2 = rejected
+__global__ void __launch_bounds__(VEC_BLOCK)
+k_and_step(const double* __restrict__ partial, int nb, int m, int pos, int rel, AndState* __restrict__ S,
+           double* __restrict__ err_slot, int* __restrict__ kind_slot, double tol, double max_iter, int mixing_freq, double ridge) {
+#pragma clang fp contract(off)
+  SDFS_GATED(&S->gate);
+  __shared__ double row[AND_MAX_M];
+  __shared__ double Gs[AND_MAX_M * AND_MAX_M];
+  __shared__ double A[(AND_MAX_M + 1) * (AND_MAX_M + 1)];
+  __shared__ double b[AND_MAX_M + 1];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // the Gram matrix and the loop's scalars come in with one parallel round of loads
+  if (tid < m * m) Gs[tid] = S->G[tid];
+  const double it = S->it, prev_pos_d = S->prev_pos, last_mixed = S->last_mixed, rejected = S->rejected, no_mix_until = S->no_mix_until;
+  gram_row_sums(partial, nb, m, row);
+  __syncthreads();
+  if (wave != 0) return;                 // the rest is one wave's work: LDS operations of a wave execute in order
+  if (lane < m) { Gs[pos * m + lane] = row[lane]; Gs[lane * m + pos] = row[lane]; }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+  const int d = m + 1;
+  const int prev_pos = (int)prev_pos_d;
+  double err = sqrt(Gs[pos * m + pos]);
+  const bool reject = !isfinite(err) && last_mixed != 0.0 && prev_pos >= 0 && rejected < 1000.0;   // uniform
+  if (reject) {
+    // a mixing step left the domain: plain step from the last good iterate, drop the poisoned slot, pause mixing
+    err = sqrt(Gs[prev_pos * m + prev_pos]);
+    if (lane < m) { S->G[pos * m + lane] = 0.0; S->G[lane * m + pos] = 0.0; S->coef[lane] = (lane == prev_pos) ? 1.0 : 0.0; }
+    if (lane == 0) {
+      S->mix_beta = 1.0; S->mix_mode = 2; S->mix_rel = rel;
+      S->last_mixed = 0.0; S->rejected = rejected + 1.0; S->it = it + 1.0; S->no_mix_until = it + 1.0 + m;
+      S->err = err;
+      *kind_slot = 2;
+      if (!(err > tol && it + 1.0 < max_iter)) S->gate = 0ULL;
+    }
+    return;
+  }
+  if (lane < m) { S->G[pos * m + lane] = row[lane]; S->G[lane * m + pos] = row[lane]; }
+  const bool want_mix = it + 1.0 >= m && it + 1.0 >= no_mix_until && ((long long)(it + 1.0)) % mixing_freq == 0 && isfinite(err);   // uniform
+  bool mixed = false;
+  if (want_mix) {
+    auto wsync = [&]() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); };
+    for (int i = lane; i < d * d; i += 64) {
+      const int r = i / d, c = i - r * d;
+      A[i] = (r == 0) ? (c == 0 ? 0.0 : 1.0) : (c == 0 ? 1.0 : Gs[(r - 1) * m + c - 1] + (r == c ? ridge : 0.0));
+    }
+    if (lane < d) b[lane] = lane == 0 ? 1.0 : 0.0;
+    wsync();
+    // Gaussian elimination with partial pivoting, the operations of the host's solve_dense in the same order (no
+    // fused multiply-adds); lane r owns row r.  Pivot = first row of the largest |entry|, as the host's scan finds it
+    mixed = true;
+    for (int c = 0; c < d; ++c) {
+      const double mine = (lane >= c && lane < d) ? fabs(A[lane * d + c]) : -1.0;
+      const double big = wave_max(mine);
+      if (big == 0.0 || !(big == big)) { mixed = false; break; }     // (a NaN column: the host's scan keeps row c and divides by NaN; no mixing either way)
+      const int piv = __ffsll((long long)__ballot(mine == big)) - 1;
+      if (piv != c) {
+        double t0 = 0.0, t1 = 0.0;
+        if (lane < d) { t0 = A[c * d + lane]; t1 = A[piv * d + lane]; }
+        const double b0 = b[c], b1 = b[piv];
+        wsync();
+        if (lane < d) { A[c * d + lane] = t1; A[piv * d + lane] = t0; }
+        if (lane == 0) { b[c] = b1; b[piv] = b0; }
+        wsync();
+      }
+      if (lane > c && lane < d) {
+        const double f = A[lane * d + c] / A[c * d + c];
+        if (f != 0.0) {
+          for (int k = c; k < d; ++k) A[lane * d + k] -= f * A[c * d + k];
+          b[lane] -= f * b[c];
+        }
+      }
+      wsync();
+    }
+    if (mixed && lane == 0) {
+      for (int r = d - 1; r >= 0; --r) {
+        double s = b[r];
+        for (int k = r + 1; k < d; ++k) s -= A[r * d + k] * b[k];
+        b[r] = s / A[r * d + r];
+      }
+    }
+    wsync();
+    if (mixed && lane < m) S->coef[lane] = b[lane + 1];
+  }
+  if (lane == 0) {
+    *err_slot = err; *kind_slot = 1;
+    S->err = err;
+    S->mix_mode = mixed ? 1 : 0;
+    S->mix_rel = rel;
+    S->last_mixed = mixed ? 1.0 : 0.0; S->prev_pos = (double)pos;
+    S->it = it + 1.0;
+    if (!isfinite(err)) { S->status = 1.0; S->gate = 0ULL; }
+    else if (!(err > tol && it + 1.0 < max_iter)) S->gate = 0ULL;
+  }
+}
+
+// the update of x that pass `rel` decided on (runs also for the pass that ended the loop)
+__global__ void __launch_bounds__(VEC_BLOCK)
+k_and_mix_dev(AndPtrs h, const AndState* __restrict__ S, int m, double beta, double* __restrict__ x,
+              const double* __restrict__ fx, int pos, int rel, long long n) {
+  if (S->mix_rel != rel) return;
+  const int mode = S->mix_mode;
+  if (mode == 0) {
+#define BODY(W_) { double f_[W_]; LDx<W_>(fx, e, f_); STx<W_>(x, e, f_); }
+    SDFS_PACKET_LOOP(double, n, BODY)
+#undef BODY
+    return;
+  }
+  double ca[AND_MAX_M];
+#pragma unroll
+  for (int j = 0; j < AND_MAX_M; ++j) ca[j] = j < m ? S->coef[j] : 0.0;
+  const double be = mode == 2 ? S->mix_beta : beta;
+#define BODY(W_) { double xa[W_], ra[W_], xs_[AND_MAX_M][W_], rs_[AND_MAX_M][W_]; \
+                   _Pragma("unroll") for (int j = 0; j < AND_MAX_M; ++j) { \
+                     if (j < m && !(mode == 2 && j == pos)) { LDx<W_>((const double*)h.X[j], e, xs_[j]); LDx<W_>((const double*)h.R[j], e, rs_[j]); } } \
+                   _Pragma("unroll") for (int q = 0; q < W_; ++q) { xa[q] = 0.0; ra[q] = 0.0; } \
+                   _Pragma("unroll") for (int j = 0; j < AND_MAX_M; ++j) { \
+                     if (j < m && !(mode == 2 && j == pos)) { \
+                       _Pragma("unroll") for (int q = 0; q < W_; ++q) { xa[q] += ca[j] * xs_[j][q]; ra[q] += ca[j] * rs_[j][q]; } } } \
+                   _Pragma("unroll") for (int q = 0; q < W_; ++q) xa[q] = xa[q] + be * ra[q]; \
+                   STx<W_>(x, e, xa); \
+                   if (mode == 2) { double z_[W_]; _Pragma("unroll") for (int q = 0; q < W_; ++q) z_[q] = 0.0; STx<W_>(h.R[pos], e, z_); } }
   SDFS_PACKET_LOOP(double, n, BODY)
 #undef BODY
 }

@@ -158,9 +158,8 @@ class KoopmansOperator:
         check(lib.sdfs_set_stream(self._h, stream_ptr, int(use_own)), self._h)
 
     # -- device-resident solve --------------------------------------------------
-    def solve(self, x_init, algorithm="successive_approx", record_errors=False, **kw):
-        """Run the whole fixed-point iteration on the GPU.  Returns
-        (x_star, n_iter, info) with info = dict(n_apply, final_err, errors, status)."""
+    @staticmethod
+    def _opts(algorithm, record_errors, kw):
         algo = {"successive_approx": _lib.SDFS_ALGO_SA, "newton": _lib.SDFS_ALGO_NEWTON,
                 "anderson": _lib.SDFS_ALGO_ANDERSON}[algorithm]
         o = _lib.default_opts()
@@ -173,18 +172,34 @@ class KoopmansOperator:
                 raise TypeError(f"unknown solver option {k!r}")
             setattr(o, k, type(getattr(o, k))(v))
         o.record_errors = int(record_errors)
-        x = self._host_in(x_init, "x_init").copy()
-        n_iter, n_apply, err = C.c_int64(), C.c_int64(), C.c_double()
-        rc = lib.sdfs_solve(self._h, algo, C.byref(o), x.ctypes.data, C.byref(n_iter),
-                            C.byref(n_apply), C.byref(err))
+        return algo, o
+
+    def _solve_info(self, rc, n_apply, err, record_errors):
         check(rc, self._h, allow=(_lib.SDFS_ERR_NUMERIC,))
         errors = None
         if record_errors:
             n = lib.sdfs_error_trace(self._h, None, 0)
             errors = np.empty(n)
             lib.sdfs_error_trace(self._h, errors.ctypes.data, n)
-        info = dict(n_apply=n_apply.value, final_err=err.value, errors=errors, status=rc)
-        return x, n_iter.value, info
+        return dict(n_apply=n_apply.value, final_err=err.value, errors=errors, status=rc)
+
+    def solve(self, x_init, algorithm="successive_approx", record_errors=False, **kw):
+        """Run the whole fixed-point iteration on the GPU.  Returns
+        (x_star, n_iter, info) with info = dict(n_apply, final_err, errors, status)."""
+        algo, o = self._opts(algorithm, record_errors, kw)
+        x = self._host_in(x_init, "x_init").copy()
+        n_iter, n_apply, err = C.c_int64(), C.c_int64(), C.c_double()
+        rc = lib.sdfs_solve(self._h, algo, C.byref(o), x.ctypes.data, C.byref(n_iter),
+                            C.byref(n_apply), C.byref(err))
+        return x, n_iter.value, self._solve_info(rc, n_apply, err, record_errors)
+
+    def solve_dev(self, x_ptr, algorithm="successive_approx", record_errors=False, **kw):
+        """The same loop on a grid that already lives in device memory (``x_ptr``: N doubles, start value in,
+        result out; sdfs_solve_dev).  Returns (n_iter, info)."""
+        algo, o = self._opts(algorithm, record_errors, kw)
+        n_iter, n_apply, err = C.c_int64(), C.c_int64(), C.c_double()
+        rc = lib.sdfs_solve_dev(self._h, algo, C.byref(o), x_ptr, C.byref(n_iter), C.byref(n_apply), C.byref(err))
+        return n_iter.value, self._solve_info(rc, n_apply, err, record_errors)
 
     # -- profiling counters (bench.py) -----------------------------------------
     def set_profiling(self, on):

@@ -242,3 +242,40 @@ def test_pair_plan_gcy16_newton_fixed_point(S):
     p = models.gcy_params()
     oc = COperator("gcy", shapes, p, gcy.discretize_gcy(p, shapes))
     assert np.max(np.abs(oc(x) - x)) < 1e-8
+
+
+@pytest.mark.parametrize("shapes", [(16,) * 6, (16, 16, 20, 20, 16, 16)])
+def test_fused_sa_6d(S, shapes):
+    """Successive approximation on the 6-D pair plan runs [slices, plain contraction] [lines, fused: end of one
+    application + start of the next] per iteration, the fused pass alternating between the two line pairs.
+    Same iterates as repeated application of T (one launch per pass) and as SDFS_SA_FUSED=0."""
+    os.environ.pop("SDFS_PLAN", None)
+    g = S.GCY(); arr = S.discretize_gcy(g, shapes)
+    with plan_env("pair"):
+        Tf = S.KoopmansOperator("gcy", shapes, g.params, arr)
+        os.environ["SDFS_SA_FUSED"] = "0"
+        try:
+            Tu = S.KoopmansOperator("gcy", shapes, g.params, arr)
+        finally:
+            del os.environ["SDFS_SA_FUSED"]
+    w0 = np.full(shapes, 800.0)
+    want = w0
+    done = 0
+    for k in (1, 2, 3, 6):
+        while done < k:
+            want = Tu(want); done += 1
+        x, n, info = Tf.solve(w0, "successive_approx", tol=0.0, max_iter=k)
+        assert n == k and info["n_apply"] == k
+        np.testing.assert_allclose(x, want, rtol=1e-11)
+        assert abs(info["final_err"] - Tu.residual()) <= 1e-9 * Tu.residual()
+    xf, n_f, i_f = Tf.solve(w0, "successive_approx", tol=1e-3, record_errors=True, check_every=9)
+    xu, n_u, i_u = Tu.solve(w0, "successive_approx", tol=1e-3, record_errors=True)
+    assert n_f == n_u and n_f > 20
+    np.testing.assert_allclose(i_f["errors"], i_u["errors"], rtol=1e-9, atol=1e-11)
+    np.testing.assert_allclose(xf, xu, rtol=0, atol=1e-9)
+    # gate: once converged the remaining launches of the chunk leave the iterate alone
+    xg, n_g, _ = Tf.solve(w0, "successive_approx", tol=1e-3, check_every=64)
+    assert n_g == n_f
+    np.testing.assert_array_equal(xg, xf)
+    w = wbench(shapes)
+    np.testing.assert_allclose(Tf(w), Tu(w), rtol=APPLY_RTOL)           # the operator itself is untouched

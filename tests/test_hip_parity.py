@@ -619,3 +619,53 @@ def _ssy_model_args(S, shapes):
 def J_at(oJ, x, shapes):
     n = int(np.prod(shapes))
     return np.stack([oJ(x, e.reshape(shapes)).ravel() for e in np.eye(n)], axis=1)
+
+
+def test_anderson_device_loop_matches_host_controlled_loop(S):
+    """The Anderson loop keeps its control (Gram matrix, (m+1) x (m+1) solve, rejection safeguard, stopping test) on
+    the device and synchronises once per chunk of passes.  Same passes, errors and iterate as the loop that solves
+    on the host after every pass (SDFS_AND_HOST=1): with and without hipGraph replay, for chunk lengths that are
+    not multiples of the history, when max_iter ends the loop, and through the safeguard at GCY 12^6."""
+    import os
+
+    def build(model, shapes, host):
+        m = S.SSY() if model == "ssy" else S.GCY()
+        arr = (S.discretize_ssy if model == "ssy" else S.discretize_gcy)(m, shapes)
+        old = os.environ.get("SDFS_AND_HOST")
+        os.environ["SDFS_AND_HOST"] = "1" if host else "0"
+        try:
+            return S.KoopmansOperator(model, shapes, m.params, arr)
+        finally:
+            if old is None:
+                del os.environ["SDFS_AND_HOST"]
+            else:
+                os.environ["SDFS_AND_HOST"] = old
+
+    for model, shapes, tol in (("ssy", (3, 3, 3, 3), 1e-6), ("ssy", (15,) * 4, 1e-6), ("gcy", (3, 4, 2, 3, 2, 4), 1e-6)):
+        Td, Th = build(model, shapes, False), build(model, shapes, True)
+        w0 = np.full(shapes, 800.0)
+        xh, nh, ih = Th.solve(w0, "anderson", tol=tol, record_errors=True)
+        for kw in ({}, dict(check_every=7), dict(use_graph=0, check_every=3), dict(check_every=1)):
+            xd, nd, idv = Td.solve(w0, "anderson", tol=tol, record_errors=True, **kw)
+            assert nd == nh and idv["n_apply"] == ih["n_apply"], (model, shapes, kw, nd, nh)
+            np.testing.assert_allclose(idv["errors"], ih["errors"], rtol=1e-6, atol=1e-12)
+            np.testing.assert_allclose(xd, xh, rtol=0, atol=1e-7)
+        for k in (1, 4, 5, 11):
+            xd, nd, idv = Td.solve(w0, "anderson", tol=0.0, max_iter=k, record_errors=True)
+            xh2, nh2, ih2 = Th.solve(w0, "anderson", tol=0.0, max_iter=k, record_errors=True)
+            assert nd == nh2 == k and len(idv["errors"]) == len(ih2["errors"])
+            np.testing.assert_allclose(xd, xh2, rtol=1e-9)
+        # other hyper-parameters travel into the captured kernels
+        xd, nd, _ = Td.solve(w0, "anderson", tol=tol, history=3, mixing_freq=2, beta=1.0, ridge=1e-8)
+        xh3, nh3, _ = Th.solve(w0, "anderson", tol=tol, history=3, mixing_freq=2, beta=1.0, ridge=1e-8)
+        assert nd == nh3
+        np.testing.assert_allclose(xd, xh3, rtol=0, atol=1e-7)
+    # rejection safeguard (a mixing step leaves the domain)
+    shapes = (12,) * 6
+    Td, Th = build("gcy", shapes, False), build("gcy", shapes, True)
+    w0 = np.full(shapes, 800.0)
+    xd, nd, idv = Td.solve(w0, "anderson", tol=1e-6, max_iter=5000)
+    xh, nh, ih = Th.solve(w0, "anderson", tol=1e-6, max_iter=5000)
+    assert idv["status"] == 0 and np.all(np.isfinite(xd))
+    assert abs(nd - nh) <= max(8, nh // 10), (nd, nh)
+    np.testing.assert_allclose(xd, xh, rtol=0, atol=1e-4)

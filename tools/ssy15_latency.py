@@ -4,7 +4,7 @@ import sdfs_via_autodiff_amd as S
 m = S.SSY(); shp = (15,)*4
 T = S.ssy_operator(shp, m.params, S.discretize_ssy(m, shp))
 w0 = np.full(shp, 800.0)
-for algo, kw in (("newton", dict(tol=1e-8, inner_rtol=1e-6, inner_atol=0.0)), ("newton", dict(tol=1e-8, inner_rtol=1e-6, inner_atol=0.0, use_graph=0)), ("successive_approx", dict(tol=1e-8))):
+for algo, kw in (("newton", dict(tol=1e-8, inner_rtol=1e-6, inner_atol=0.0)), ("newton", dict(tol=1e-8, inner_rtol=1e-6, inner_atol=0.0, use_graph=0)), ("successive_approx", dict(tol=1e-8)), ("anderson", dict(tol=1e-8))):
     T.solve(w0, algo, max_iter=2, **{k: v for k, v in kw.items() if k != "tol"})
     best = 1e9
     for _ in range(5):
