@@ -810,6 +810,7 @@ struct SmallIO {
   const unsigned long long* gate;
   double gate_tol;
   double* dotp;             // J.v with minus_identity: per-workgroup partial sums <out, v>, <out, out>: [2][gridDim.x]
+  const double* dot_with;   // J.v: if given, dotp receives the single stream <out, dot_with> instead: [gridDim.x]
   unsigned long long* zero; // first pass: cleared by workgroup 0 (the residual word the last pass maximises into)
   // Successive approximation without atomics (225 workgroups maximising into one word cost 2.9 of the 7.5 us of a
   // fused kernel, tools/probes/small_fused_probe.hip): every workgroup stores its own maximum, the kernels of the
@@ -898,7 +899,7 @@ small_tile_kernel(const SmallDesc P, const SmallIO io) {
     // ---- loads: the tile and, for the last pass, its side streams -- all in flight at once; the a3 gather, whose
     // index comes out of two tables, goes last ---------------------------------------------------------------------
     const double* const inb = io.in + base;
-    double v[EPL], s1[EPL], s2[EPL];
+    double v[EPL], s1[EPL], s2[EPL], s3[MULE ? EPL : 1];
 #pragma unroll
     for (int k = 0; k < EPL; ++k) {
       if (TPT * k < total) {
@@ -906,6 +907,7 @@ small_tile_kernel(const SmallDesc P, const SmallIO io) {
         if (MULP) s1[k] = io.aux_in[base + g[k]];
         if ((CES || MULE) && need_old) s1[k] = io.old[base + g[k]];
         if (MULE) s2[k] = io.aux_in[base + g[k]];
+        if (MULE && io.dot_with != nullptr) s3[k] = io.dot_with[base + g[k]];
       }
     }
     QFrag<16> q, q2;
@@ -1052,9 +1054,12 @@ small_tile_kernel(const SmallDesc P, const SmallIO io) {
             y *= s2[k];
             if (P.minus_identity) {
               y -= s1[k];
-              dot_yv = fma(y, s1[k], dot_yv);
-              dot_yy = fma(y, y, dot_yy);
+              if (io.dot_with == nullptr) {
+                dot_yv = fma(y, s1[k], dot_yv);
+                dot_yy = fma(y, y, dot_yy);
+              }
             }
+            if (io.dot_with != nullptr) dot_yv = fma(y, s3[MULE ? k : 0], dot_yv);
           }
           outb[g[k]] = y;
         }
@@ -1074,7 +1079,7 @@ small_tile_kernel(const SmallDesc P, const SmallIO io) {
     __syncthreads();
     if (tid == 0) {
       io.dotp[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
-      io.dotp[gridDim.x + blockIdx.x] = (red[4] + red[5]) + (red[6] + red[7]);
+      if (io.dot_with == nullptr) io.dotp[gridDim.x + blockIdx.x] = (red[4] + red[5]) + (red[6] + red[7]);
     }
   }
   if (CES && (io.resid != nullptr || io.part_out != nullptr)) {

@@ -105,6 +105,7 @@ struct Knobs {
   int small_plan = 1;          // SDFS_SMALL_PLAN: 0 = never use the small-grid pair plan
   int small_r = 0;             // SDFS_SMALL_R: force the run length of its line passes (1 or 4)
   int small_wpt = 0;           // SDFS_SMALL_WPT: force its waves per tile (1 or 4)
+  int no_bicg_merge = 0;       // SDFS_NO_BICG_MERGE: 1 = BiCGSTAB keeps its finishing kernels as launches of their own on small grids too
   int and_host = 0;            // SDFS_AND_HOST: 1 = Anderson with the Gram solve on the host (one synchronisation per iteration)
   int sa_fused = 1;            // SDFS_SA_FUSED: 0 = successive approximation on the small-grid plan keeps one launch per pass
   int ablate = 0;              // SDFS_ABLATE, honoured only by -DSDFS_DIAG builds
@@ -186,6 +187,8 @@ struct sdfs_handle {
   std::vector<hipEvent_t> event_pool;
 
   // graph cache for the SA chunk
+  const double* jvp_dot_with = nullptr;                // set around a J.v call: the last pass also sums <out, this> (small-grid plan)
+  int bicg_graph_chunk[2] = {0, 0};                    // iterations in the captured graph
   hipGraphExec_t bicg_graph[2] = {nullptr, nullptr};   // one BiCGSTAB iteration (fp64 / fp32 Krylov storage)
   unsigned long long* bicg_gate = nullptr;             // device flag the iteration's kernels are gated on
   unsigned long long* bicg_gate_host = nullptr;        // pinned mirror
@@ -252,6 +255,7 @@ Knobs read_knobs() {
   k.sa_fused = env_int("SDFS_SA_FUSED", 1);
   k.small_wpt = env_int("SDFS_SMALL_WPT", 0);
   k.and_host = env_int("SDFS_AND_HOST", 0);
+  k.no_bicg_merge = env_int("SDFS_NO_BICG_MERGE", 0);
   const char* pl = getenv("SDFS_PLAN");
   if (pl && !strcmp(pl, "classic")) k.plan = 1;
   else if (pl && !strcmp(pl, "pair")) k.plan = 2;
@@ -949,7 +953,11 @@ int run_fast_plan(sdfs_handle* h, int mode, const double* in, double* out, const
       } else if (last) {
         if (mode == MODE_T) { sm = SM_LAST_T; io.old = old; io.resid = resid; if (resid) bytes += n8; }
         else if (mode == MODE_T_LIN) { sm = SM_LAST_TLIN; io.old = old; io.resid = resid; io.aux_out = h->c2; bytes += n8; if (resid) bytes += n8; }
-        else { sm = SM_LAST_J; io.aux_in = vjp ? h->c1 : h->c2; io.old = old; bytes += n8; if (minus_identity) { bytes += n8; io.dotp = dotp; } }
+        else {
+          sm = SM_LAST_J; io.aux_in = vjp ? h->c1 : h->c2; io.old = old; bytes += n8;
+          if (minus_identity) { bytes += n8; io.dotp = dotp; }
+          if (dotp && h->jvp_dot_with) { io.dot_with = h->jvp_dot_with; bytes += n8; }
+        }
       }
       small_fn fn = small_variant(sm, P.r, P.wpt);
       if (!fn) return fail(h, SDFS_ERR_UNSUPPORTED, "no small-grid kernel variant");
@@ -1350,8 +1358,38 @@ int bicgstab_dev_t(sdfs_handle* h, const sdfs_opts& o, int64_t* matvecs) {
   const long long last_tiles = jvp_last_tiles(h);
   const bool fused_dots = last_tiles > 0 && 2 * last_tiles <= (long long)MAX_PARTIAL_BLOCKS * AND_MAX_M &&
                           (h->plan[0].passes.size() > 1 || (h->fast.ok && (!h->krylov_f32 || h->fast.f32_ok))) && h->knobs.no_dot_fusion == 0;
+  // small grids are launch-bound: the finishing kernels merge into the vector kernels behind them (vec_kernels.hpp),
+  // each reduction with its own region of the partial-sum buffer
+  constexpr int PR = 2 * MAX_PARTIAL_BLOCKS;
+  double* const pdot = h->partial;              // <rhat, q>
+  double* const pss = h->partial + PR;          // <s, s>
+  double* const pt = h->partial + 2 * PR;       // <t, s>, <t, t>
+  double* const prr = h->partial + 4 * PR;      // <r, r>, <rhat, r>
+  const bool merged = n <= (1LL << 22) && (!fused_dots || last_tiles <= MAX_PARTIAL_BLOCKS) && h->knobs.no_bicg_merge == 0;
+  auto iteration_merged = [&]() -> int {
+    int rc2;
+    { ProfScope ps(h, cvec);
+      hipLaunchKernelGGL(k_bicg_update_p<T>, dim3(g), dim3(VEC_BLOCK), 0, st, (const T*)r, p, (const T*)q, n, h->sc, (const unsigned long long*)gate); }
+    // small-grid plan, fp64 vectors: <rhat, q> comes out of the last J.v pass as well
+    const bool fused_rhat = fused_dots && h->fast.ok && h->fast.small && std::is_same<T, double>::value;
+    if (fused_rhat) h->jvp_dot_with = (const double*)rhat;
+    rc2 = run_plan(h, h->plan[0], MODE_JVP, true, true, (const double*)p, (double*)q, (const double*)p, nullptr, gate, 0.0, 1, fused_rhat ? pdot : nullptr);
+    h->jvp_dot_with = nullptr;
+    if (rc2) return rc2;
+    { ProfScope ps(h, cvec);
+      if (!fused_rhat) hipLaunchKernelGGL(k_dot<T>, dim3(g), dim3(VEC_BLOCK), 0, st, (const T*)rhat, (const T*)q, n, pdot, (const unsigned long long*)gate);
+      hipLaunchKernelGGL(k_bicg_s_m<T>, dim3(g), dim3(VEC_BLOCK), 0, st, r, (const T*)q, n, h->sc, (const double*)pdot, fused_rhat ? (int)last_tiles : g, pss, (const unsigned long long*)gate); }
+    if ((rc2 = run_plan(h, h->plan[0], MODE_JVP, true, true, (const double*)r, (double*)t, (const double*)r, nullptr, gate, 0.0, 1,
+                        fused_dots ? pt : nullptr))) return rc2;
+    { ProfScope ps(h, cvec);
+      if (!fused_dots) hipLaunchKernelGGL(k_dot2<T>, dim3(g), dim3(VEC_BLOCK), 0, st, (const T*)t, (const T*)r, n, pt, (const unsigned long long*)gate);
+      hipLaunchKernelGGL(k_bicg_update_xr_m<T>, dim3(g), dim3(VEC_BLOCK), 0, st, x, r, (const T*)p, (const T*)t, (const T*)rhat, n, h->sc,
+                         (const double*)pss, g, (const double*)pt, fused_dots ? (int)last_tiles : g, prr, (const unsigned long long*)gate);
+      hipLaunchKernelGGL(k_bicg_iter_finish, dim3(1), dim3(VEC_BLOCK), 0, st, (const double*)prr, g, h->sc, gate); }
+    return 0;
+  };
   // one BiCGSTAB iteration, every launch gated on the device flag
-  auto iteration = [&]() -> int {
+  auto iteration_plain = [&]() -> int {
     int rc2;
     { ProfScope ps(h, cvec);
       hipLaunchKernelGGL(k_bicg_update_p<T>, dim3(g), dim3(VEC_BLOCK), 0, st, (const T*)r, p, (const T*)q, n, h->sc, (const unsigned long long*)gate); }
@@ -1370,6 +1408,7 @@ int bicgstab_dev_t(sdfs_handle* h, const sdfs_opts& o, int64_t* matvecs) {
       hipLaunchKernelGGL(k_bicg_iter_finish, dim3(1), dim3(VEC_BLOCK), 0, st, h->partial, g, h->sc, gate); }
     return 0;
   };
+  auto iteration = [&]() -> int { return merged ? iteration_merged() : iteration_plain(); };
   // Small grids are launch- and sync-bound: the iteration is captured once into a hipGraph (pointers, scalars
   // and the gate are fixed device addresses) and replayed; `chunk` iterations go out per host synchronisation.
   // Large grids (an iteration is milliseconds) keep one iteration per sync so that nothing runs past the
@@ -1377,10 +1416,12 @@ int bicgstab_dev_t(sdfs_handle* h, const sdfs_opts& o, int64_t* matvecs) {
   const int chunk = (int)std::min<long long>(maxit, n <= (1LL << 22) ? 8 : 1);
   const int gslot = std::is_same<T, float>::value ? 1 : 0;
   const bool graph = o.use_graph && !h->profiling && st != nullptr && chunk > 1;
-  if (graph && h->bicg_graph[gslot] == nullptr) {
+  if (graph && (h->bicg_graph[gslot] == nullptr || h->bicg_graph_chunk[gslot] != chunk)) {
+    if (h->bicg_graph[gslot]) { hipGraphExecDestroy(h->bicg_graph[gslot]); h->bicg_graph[gslot] = nullptr; }
     hipGraph_t gr = nullptr;
     HIPCHK(h, hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
-    rc = iteration();
+    rc = 0;
+    for (int i = 0; i < chunk && !rc; ++i) rc = iteration();         // the whole chunk is one graph: one launch per synchronisation
     hipError_t e = hipStreamEndCapture(st, &gr);
     if (rc || e != hipSuccess) {
       if (gr) hipGraphDestroy(gr);
@@ -1390,6 +1431,7 @@ int bicgstab_dev_t(sdfs_handle* h, const sdfs_opts& o, int64_t* matvecs) {
     e = hipGraphInstantiate(&h->bicg_graph[gslot], gr, nullptr, nullptr, 0);
     hipGraphDestroy(gr);
     HIPCHK(h, e);
+    h->bicg_graph_chunk[gslot] = chunk;
   }
   long long k = 0;
   for (;;) {
@@ -1399,10 +1441,8 @@ int bicgstab_dev_t(sdfs_handle* h, const sdfs_opts& o, int64_t* matvecs) {
     k = (long long)h->sc_host[SC_ITERS];
     if (h->bicg_gate_host[0] == 0ULL || k >= maxit) break;       // converged, broken down, NaN, or out of iterations
     const int todo = (int)std::min<long long>(chunk, maxit - k);
-    for (int i = 0; i < todo; ++i) {
-      if (graph) { HIPCHK(h, hipGraphLaunch(h->bicg_graph[gslot], st)); }
-      else if ((rc = iteration())) return rc;
-    }
+    if (graph && todo == h->bicg_graph_chunk[gslot]) { HIPCHK(h, hipGraphLaunch(h->bicg_graph[gslot], st)); }
+    else for (int i = 0; i < todo; ++i) if ((rc = iteration())) return rc;
     HIPCHK(h, hipGetLastError());
   }
   *matvecs += 2 * k;

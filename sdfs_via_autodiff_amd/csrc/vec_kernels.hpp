@@ -320,6 +320,60 @@ k_bicg_iter_finish(const double* __restrict__ partial, int nb, double* __restric
   }
 }
 
+// ---- merged forms for small grids (launch-bound: one launch less per finishing kernel) --------------------------------
+// Every workgroup finishes the sums it needs itself, in the same order, from the per-workgroup partials of the
+// kernel before; workgroup 0 also leaves the scalars in `sc` for the later kernels.  The partial sums of the
+// different reductions live in different regions of the buffer (a kernel reads one region while writing another).
+// s = r - alpha q with alpha = rho_new / <rhat, q>  (k_bicg_alpha_finish + k_bicg_s)
+template <typename T>
+__global__ void __launch_bounds__(VEC_BLOCK)
+k_bicg_s_m(T* __restrict__ r, const T* __restrict__ q, long long n, double* __restrict__ sc,
+           const double* __restrict__ pdot, int nbdot, double* __restrict__ pss, const unsigned long long* gate) {
+  SDFS_GATED(gate);
+  const double d = finish_sum(pdot, nbdot, 0);
+  const double alpha = sc[SC_RHO_NEW] / d;
+  if (blockIdx.x == 0 && threadIdx.x == 0) { sc[SC_RHAT_Q] = d; sc[SC_ALPHA] = alpha; }
+  double acc[1] = {0.0};
+#define BODY(W_) { double r_[W_], q_[W_]; LDx<W_>((const T*)r, e, r_); LDx<W_>(q, e, q_); \
+                   _Pragma("unroll") for (int j = 0; j < W_; ++j) { const double s = (double)(T)(r_[j] - alpha * q_[j]); r_[j] = s; acc[0] += s * s; } \
+                   STx<W_>(r, e, r_); }
+  SDFS_PACKET_LOOP(T, n, BODY)
+#undef BODY
+  block_partials<1>(acc, pss);
+}
+
+// x, r update with early = <s,s> < atol2 and omega = <t,s>/<t,t>  (k_bicg_s_finish + k_bicg_omega_finish + k_bicg_update_xr)
+template <typename T>
+__global__ void __launch_bounds__(VEC_BLOCK)
+k_bicg_update_xr_m(T* __restrict__ x, T* __restrict__ r, const T* __restrict__ p,
+                   const T* __restrict__ t, const T* __restrict__ rhat, long long n, double* __restrict__ sc,
+                   const double* __restrict__ pss, int nbss, const double* __restrict__ pt, int nbt,
+                   double* __restrict__ prr, const unsigned long long* gate) {
+  SDFS_GATED(gate);
+  const double ss = finish_sum(pss, nbss, 0);
+  const double ts = finish_sum(pt, nbt, 0);
+  const double tt = finish_sum(pt, nbt, 1);
+  const double alpha = sc[SC_ALPHA];
+  const bool early = ss < sc[SC_ATOL2];
+  const double omega_full = ts / tt;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    sc[SC_SS] = ss; sc[SC_EARLY] = early ? 1.0 : 0.0; sc[SC_TS] = ts; sc[SC_TT] = tt; sc[SC_OMEGA] = omega_full;
+  }
+  const double omega = early ? 0.0 : omega_full;
+  double acc[2] = {0.0, 0.0};
+#define BODY(W_) { double x_[W_], r_[W_], p_[W_], t_[W_], h_[W_]; LDx<W_>((const T*)x, e, x_); LDx<W_>((const T*)r, e, r_); \
+                   LDx<W_>(p, e, p_); LDx<W_>(t, e, t_); LDx<W_>(rhat, e, h_); \
+                   _Pragma("unroll") for (int j = 0; j < W_; ++j) { \
+                     const double s = r_[j]; \
+                     const double rn = (double)(T)(early ? s : s - omega * t_[j]); \
+                     x_[j] = x_[j] + alpha * p_[j] + omega * s; r_[j] = rn; \
+                     acc[0] += rn * rn; acc[1] += h_[j] * rn; } \
+                   STx<W_>(x, e, x_); STx<W_>(r, e, r_); }
+  SDFS_PACKET_LOOP(T, n, BODY)
+#undef BODY
+  block_partials<2>(acc, prr);
+}
+
 // Newton update: x_new = x - step ; stepmax = max|step| (bits, atomicMax)
 template <typename T>
 __global__ void __launch_bounds__(VEC_BLOCK)
