@@ -248,6 +248,18 @@ def main():
             sec["gcy20_newton_1e-8_krylov_f32"] = {"iterations": n, "operator_applies": info["n_apply"], "seconds": t,
                                                    "applies_per_s": info["n_apply"] / t, "final_err": info["final_err"]}
             del x, w800
+            # the device-resident successive-approximation loop on the bench grid (what solver(...) runs): per
+            # iteration one plain slice pass + one fused line pass (end of one application + start of the next)
+            ws = torch.full(shapes, 800.0, dtype=torch.float64, device="cuda")
+            op.solve_dev(ws.data_ptr(), "successive_approx", tol=0.0, max_iter=4, check_every=4)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            n_sa, info = op.solve_dev(ws.data_ptr(), "successive_approx", tol=0.0, max_iter=100, check_every=100)
+            torch.cuda.synchronize()
+            t = time.perf_counter() - t0
+            sec["gcy20_sa_device_loop"] = {"iterations": n_sa, "seconds": t, "ms_per_iteration": t / n_sa * 1e3,
+                                           "iterations_per_s": n_sa / t, "final_err": info["final_err"]}
+            del ws
             # the conditional-tensor kernels at full size: Rouwenhorst tensors are slice-identical, so the headline
             # runs the merged (unconditional) plan; SDFS_NO_SLICE_MERGE keeps z_Q (25.6 MB) / z_pi_Q conditional
             os.environ["SDFS_NO_SLICE_MERGE"] = "1"
@@ -272,7 +284,9 @@ def main():
             torch.cuda.empty_cache()
         m = S.SSY(); shp = (15,) * 4
         T = S.ssy_operator(shp, m.params, S.discretize_ssy(m, shp))
+        sec["ssy15_plan"] = T.describe_plan().strip().split("\n")
         for algo, kw in (("successive_approx", dict(tol=1e-8)),
+                         ("anderson", dict(tol=1e-8)),
                          ("newton", dict(tol=1e-8, inner_rtol=1e-6, inner_atol=0.0))):
             T.solve(np.full(shp, 800.0), algo, max_iter=64)      # warm-up (graph capture, buffers)
             t0 = time.perf_counter()

@@ -117,6 +117,48 @@ __device__ __forceinline__ double lin_scale_of(double wref, double theta, const 
   return ldexp(1.0, inverse ? -k : k);
 }
 
+// The power that opens the next application inside a fused kernel (L_TFUSED, SM_FUSED_T).  There y = 1 + beta u
+// with u = ks^(1/theta) just computed, so
+//     y^theta = (beta u)^theta (1 + 1/(beta u))^theta = beta^theta * ks * exp(theta * log1p(1 / (beta u))),
+// and with beta u in the hundreds (wealth-consumption ratios) the exponent is a few hundredths: log1p through
+// 2 atanh(1 / (2 beta u + 1)) and a degree-10 exponential in plain fp64 -- ~25 instructions instead of the
+// ~50 of the general double-double power.  Valid (all truncation terms < 1e-17) for beta u >= max(8 |theta|, 256);
+// returns false (wave-uniform) if any lane is outside that range or not finite: the caller then takes the general
+// routine.  cbt = beta^theta.  The result differs from pow(fl(y), theta) by the rounding of y times theta, a few
+// 1e-15 relative in x and |theta| times less in the next T w.
+template <int N>
+__device__ __forceinline__ bool next_power_fast(const double (&bu)[N], const double (&ks)[N], double theta, double cbt,
+                                                double (&x)[N]) {
+  const double lim = fmax(8.0 * fabs(theta), 256.0);
+  bool okl = true;
+#pragma unroll
+  for (int j = 0; j < N; ++j) okl = okl && (bu[j] >= lim) && (bu[j] < 1e300);
+  if (!__all(okl)) return false;
+#pragma unroll
+  for (int j = 0; j < N; ++j) {
+    const double dd = fma(2.0, bu[j], 1.0);
+    double z = __builtin_amdgcn_rcp(dd);
+    z = fma(fma(-dd, z, 1.0), z, z);
+    z = fma(fma(-dd, z, 1.0), z, z);
+    const double z2 = z * z;
+    const double L = 2.0 * z * fma(z2, fma(z2, 0.2, 1.0 / 3.0), 1.0);         // log1p(1 / bu), z <= 1/513
+    const double a = theta * L;                                               // |a| <= 0.125
+    double e = 1.0 / 3628800.0;
+    e = fma(e, a, 1.0 / 362880.0);
+    e = fma(e, a, 1.0 / 40320.0);
+    e = fma(e, a, 1.0 / 5040.0);
+    e = fma(e, a, 1.0 / 720.0);
+    e = fma(e, a, 1.0 / 120.0);
+    e = fma(e, a, 1.0 / 24.0);
+    e = fma(e, a, 1.0 / 6.0);
+    e = fma(e, a, 0.5);
+    e = fma(e, a, 1.0);
+    e = fma(e, a, 1.0);
+    x[j] = (cbt * ks[j]) * e;
+  }
+  return true;
+}
+
 __device__ __forceinline__ void wave_lds_fence() {
   // LDS operations of one wave execute in issue order; this only keeps the compiler from moving
   // accesses of the wave-private region across a phase boundary
@@ -318,6 +360,7 @@ struct LineDesc {
   const double* Qy;
   double inv_theta, beta;
   double theta;             // L_TFUSED: exponent of the next application's first pass
+  double cbt;               // beta^theta (next_power_fast)
   int first_only;           // L_TFUSED: skip the closing half (the tile holds w, not an intermediate)
   // aggregator scale a3 (current state), index = out_idx[o] + x * a3x + y * a3y + rest_idx[pos]
   const double* a3;
@@ -679,9 +722,12 @@ line_kernel(const LineDesc P, const LineIO io) {
         }
         if (FUSED) {
           // the next application's first pass on this pair: x = (Tw)^theta into the slot just read
-          const double xin[2] = {ok ? y2.x : 1.0, ok ? y2.y : 1.0};
+          const double bu[2] = {ok ? P.beta * uu[0] : 1e4, ok ? P.beta * uu[1] : 1e4};
           double xw[2];
-          pow_fast_n<true, 2>(xin, P.theta, PT, xw);
+          if (!next_power_fast<2>(bu, ks, P.theta, P.cbt, xw)) {
+            const double xin[2] = {ok ? y2.x : 1.0, ok ? y2.y : 1.0};
+            pow_fast_n<true, 2>(xin, P.theta, PT, xw);
+          }
           if (rowok) *slot = make_double2(xw[0], xw[1]);
         }
       } else if (ok) {
@@ -793,6 +839,7 @@ struct SmallDesc {
   const double* Qxp;        // 16 x 16 zero-padded matrices
   const double* Qyp;
   double theta, inv_theta, beta;
+  double cbt;               // beta^theta (next_power_fast)
   const double* a3;         // aggregator scale: index = out_idx[o] + x * a3x + y * a3y + rest_idx[pos]
   const int* out_idx;
   const int* rest_idx;
@@ -1005,10 +1052,12 @@ small_tile_kernel(const SmallDesc P, const SmallIO io) {
 #pragma unroll
           for (int j = 0; j < PG; ++j) { sv[j] = wl[l[k + j]]; ks[j] = ok[k + j] ? s2[k + j] * sv[j] : 1.0; }
           pow_fast_n<false, PG>(ks, P.inv_theta, PT, uu);
+          double yv[PG];
 #pragma unroll
           for (int j = 0; j < PG; ++j) {
+            yv[j] = 1.0 + P.beta * uu[j];
             if (ok[k + j]) {
-              const double y = 1.0 + P.beta * uu[j];
+              const double y = yv[j];
               if (LINE) io.aux_out[base + g[k + j]] = P.beta * uu[j] / sv[j];
               if (need_old) {
                 const double r0 = fabs(y - s1[k + j]);
@@ -1016,26 +1065,30 @@ small_tile_kernel(const SmallDesc P, const SmallIO io) {
                 rmax = fmax(rmax, r0);
               }
               outb[g[k + j]] = y;
-              if (FUSED) v[k + j] = y;
             }
+          }
+          if (FUSED) {
+            // the next application's first pass on the same pair: x = (Tw)^theta (next_power_fast, else the general routine)
+            double bu[PG], xw[PG];
+#pragma unroll
+            for (int j = 0; j < PG; ++j) bu[j] = ok[k + j] ? P.beta * uu[j] : 1e4;
+            if (!next_power_fast<PG>(bu, ks, P.theta, P.cbt, xw)) {
+              double xin[PG];
+#pragma unroll
+              for (int j = 0; j < PG; ++j) xin[j] = ok[k + j] ? yv[j] : 1.0;
+              pow_fast_n<true, PG>(xin, P.theta, PT, xw);
+            }
+#pragma unroll
+            for (int j = 0; j < PG; ++j) v[k + j] = xw[j];
           }
         }
       }
       SDFS_SMALL_STAMP(5);
       if (FUSED) {
-        // the next application's first pass on the same pair: x = (Tw)^theta, both contractions, into the intermediate
-        // (the padding of the LDS tile is still exact zeros)
+        // both contractions again, into the intermediate (the padding of the LDS tile is still exact zeros)
 #pragma unroll
-        for (int k = 0; k < EPL; k += PG) {
-          if (TPT * k < total) {
-            double xin[PG], xw[PG];
-#pragma unroll
-            for (int j = 0; j < PG; ++j) xin[j] = ok[k + j] ? v[k + j] : 1.0;
-            pow_fast_n<true, PG>(xin, P.theta, PT, xw);
-#pragma unroll
-            for (int j = 0; j < PG; ++j) if (ok[k + j]) wl[l[k + j]] = xw[j];
-          }
-        }
+        for (int k = 0; k < EPL; ++k)
+          if (TPT * k < total && ok[k]) wl[l[k]] = v[k];
         tile_sync();
         SDFS_SMALL_STAMP(6);
         contract_pair();

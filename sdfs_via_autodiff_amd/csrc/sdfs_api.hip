@@ -764,6 +764,7 @@ int build_fast_plan(sdfs_handle* h) {
     if (L.ntiles >= (1LL << 31) || (long long)n * n * L.lrest * 8 >= (1LL << 32)) return 0;
     L.Qx = h->ax[a].Q; L.Qy = h->ax[a + 1].Q;
     L.inv_theta = 1.0 / h->theta; L.beta = h->beta; L.theta = h->theta;
+    L.cbt = (double)powl((long double)h->beta, (long double)h->theta);
     L.a3x = h->ax[a].a3s; L.a3y = h->ax[a + 1].a3s;
     for (int c = D - 1; c >= 0; --c) L.ref_off += (long long)(h->shape[c] / 2) * stride[c];
     min_tiles = std::min(min_tiles, L.ntiles);
@@ -879,6 +880,7 @@ int build_small_plan(sdfs_handle* h) {
     if (S.ntiles >= (1LL << 31)) return 0;
     S.Qxp = h->ax[a].Qp; S.Qyp = h->ax[a + 1].Qp;
     S.theta = h->theta; S.inv_theta = 1.0 / h->theta; S.beta = h->beta;
+    S.cbt = (double)powl((long double)h->beta, (long double)h->theta);
     S.a3x = h->ax[a].a3s; S.a3y = h->ax[a + 1].a3s;
     P.q_bytes = 2 * 8.0 * 256; P.flops = 2.0 * (double)h->N * (S.nx + S.ny);
     P.label = std::string(i == 0 ? "slices[" : "lines[") + h->ax[a].name + "," + h->ax[a + 1].name + "|wave " +

@@ -5,6 +5,7 @@
 // kernel).  Workgroup 0, wave 0 records s_memtime (shader clock) at the phase boundaries of the kernel.
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cmath>
 #include <cstring>
 #include <vector>
 __device__ unsigned long long g_stamps[16];
@@ -29,7 +30,7 @@ int main() {
   SmallDesc d;
   memset(&d, 0, sizeof d);
   d.nx = n; d.ny = n; d.my = (65536 + n - 1) / n; d.sx = n; d.sy = 1; d.ostride = n * n; d.lrest = 1; d.nchunks = 1; d.ntiles = n * n;
-  d.Qxp = dq; d.Qyp = dq; d.theta = -30.0; d.inv_theta = 1.0 / -30.0; d.beta = 0.999; d.a3 = da3; d.out_idx = doi; d.rest_idx = dri;
+  d.Qxp = dq; d.Qyp = dq; d.theta = -30.0; d.inv_theta = 1.0 / -30.0; d.beta = 0.999; d.cbt = pow(0.999, -30.0); d.a3 = da3; d.out_idx = doi; d.rest_idx = dri;
   d.a3x = n; d.a3y = 1;
   hipStream_t st; hipStreamCreate(&st);
   const int len = 256;
