@@ -1,5 +1,6 @@
-"""One-off fuzz: random grid shapes (2..32 per axis) for SSY / GCY against the numpy oracle; T, JVP and
-the linearised T, with the slice-merge planner path on and off and perturbed (slice-dependent) tensors."""
+"""One-off fuzz: random grid shapes (2..32 per axis; FUZZ_SMALL=1: 2..16, the small-grid plan) for SSY / GCY against
+the numpy oracle; T, JVP, three successive-approximation iterations of the device loop (fused schedules) and the
+linearised T, with the slice-merge planner path on and off and perturbed (slice-dependent) tensors."""
 import os, sys
 import numpy as np
 sys.path.insert(0, ".")
@@ -12,7 +13,8 @@ for trial in range(int(os.environ.get("FUZZ_N", "40"))):
     model = "ssy" if trial % 2 == 0 else "gcy"
     nd = 4 if model == "ssy" else 6
     while True:
-        shapes = tuple(int(x) for x in rng.choice([2, 3, 4, 5, 7, 8, 9, 12, 13, 16, 17, 20, 21, 24, 25, 31, 32], nd))
+        pool = list(range(2, 17)) if os.environ.get("FUZZ_SMALL") else [2, 3, 4, 5, 7, 8, 9, 12, 13, 16, 17, 20, 21, 24, 25, 31, 32]
+        shapes = tuple(int(x) for x in rng.choice(pool, nd))
         if np.prod(shapes) <= (60000 if model == "gcy" else 200000):
             break
     m = S.SSY() if model == "ssy" else S.GCY()
@@ -34,9 +36,13 @@ for trial in range(int(os.environ.get("FUZZ_N", "40"))):
     e1 = np.max(np.abs(T(w) - To(w)) / To(w))
     jo = Jo(w, v)
     e2 = np.max(np.abs(T.jvp(w, v) - jo)) / np.max(np.abs(jo))
-    worst = max(worst, e1, e2)
-    flag = "" if max(e1, e2) < 1e-11 else "  <-- FAIL"
-    print(f"{trial:3d} {model} {shapes} perturbed={perturb}: T {e1:.1e} jvp {e2:.1e}{flag}", flush=True)
+    x3, n3, _ = T.solve(w, "successive_approx", tol=0.0, max_iter=3)
+    w3 = To(To(To(w)))
+    e3 = np.max(np.abs(x3 - w3) / w3)
+    worst = max(worst, e1, e2, e3)
+    flag = "" if max(e1, e2, e3) < 1e-11 else "  <-- FAIL"
+    small = "small-grid plan" in T.describe_plan()
+    print(f"{trial:3d} {model} {shapes} perturbed={perturb} small_plan={small}: T {e1:.1e} jvp {e2:.1e} sa3 {e3:.1e}{flag}", flush=True)
     T.close()
 print("worst", worst)
 sys.exit(0 if worst < 1e-11 else 1)
