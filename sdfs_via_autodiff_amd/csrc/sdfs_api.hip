@@ -30,7 +30,6 @@ using namespace sdfs;
 
 namespace {
 
-constexpr int MAXD = 6;
 constexpr unsigned long long INF_BITS = 0x7ff0000000000000ULL;
 
 thread_local std::string g_create_error;
