@@ -30,7 +30,7 @@ using namespace sdfs;
 
 namespace {
 
-constexpr unsigned long long INF_BITS = 0x7ff0000000000000ULL;
+constexpr int MAXD = 6;
 
 thread_local std::string g_create_error;
 
