@@ -56,7 +56,9 @@ typedef struct sdfs_opts {
   int32_t mixing_freq;   /* Anderson mixing frequency                       */
   double beta;           /* Anderson damping                                */
   double ridge;          /* Anderson ridge                                  */
-  int32_t check_every;   /* host polls the device residual every k iterations (>=1) */
+  int32_t check_every;   /* host polls the device residual every k iterations (>=1): SA and Anderson enqueue (or replay from
+                            a hipGraph) k gated iterations per synchronisation -- rounded up to an even number (SA) or to a
+                            multiple of `history` (Anderson); the iterates, counts and error trace do not depend on k */
   int32_t use_graph;     /* 1: replay the iteration chunk from a hipGraph   */
   int32_t record_errors; /* 1: keep the per-iteration error trace (sdfs_error_trace) */
   int32_t krylov_f32;    /* Newton: 1 = inner BiCGSTAB in fp32 storage (Krylov vectors, J.v streams), fp64
