@@ -244,7 +244,8 @@ def test_pair_plan_gcy16_newton_fixed_point(S):
     assert np.max(np.abs(oc(x) - x)) < 1e-8
 
 
-@pytest.mark.parametrize("shapes", [(16,) * 6, (16, 16, 20, 20, 16, 16)])
+# (24 and 32: the fused line kernel at two workgroups per CU, the plain slice pass at N = 32)
+@pytest.mark.parametrize("shapes", [(16,) * 6, (16, 16, 20, 20, 16, 16), (24, 24, 16, 16, 16, 16), (16, 16, 16, 16, 32, 32)])
 def test_fused_sa_6d(S, shapes):
     """Successive approximation on the 6-D pair plan runs [slices, plain contraction] [lines, fused: end of one
     application + start of the next] per iteration, the fused pass alternating between the two line pairs.
