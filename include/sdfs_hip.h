@@ -186,6 +186,15 @@ int64_t sdfs_error_trace(sdfs_handle* h, double* out, int64_t cap);
 int sdfs_apply_stage_dev(sdfs_handle* h, int stage, int mode, const double* in_dev,
                          double* out_dev, const double* w_old_dev, double* resid_dev);
 
+/* Exchange buffers of the re-shard between two stage calls (sdfs_via_autodiff_amd/distributed.py; the reference has no
+ * multi-GPU path).  The grid is viewed as [outer][n_axis][inner] in C order; `packed` is the concatenation
+ * over the nblocks blocks j (axis indices offs[j] .. offs[j+1], offs[0] = 0, offs[nblocks] = n_axis) of
+ * [outer][size_j][inner], i.e. what every peer sends or receives is one contiguous piece.  unpack = 0: src is the
+ * grid, dst the packed buffer; unpack = 1: the reverse.  elem_bytes 8 (fp64) or 4 (fp32 Krylov streams).  One launch on
+ * the handle's stream. */
+int sdfs_pack_blocks(sdfs_handle* h, int unpack, const void* src_dev, void* dst_dev, int64_t outer, int64_t n_axis,
+                     int64_t inner, int nblocks, const int64_t* offs, int elem_bytes);
+
 /* Multi-GPU Krylov building blocks: the fused BLAS-1 kernels of the single-GPU BiCGSTAB / Newton loops
  * (jax.scipy.sparse.linalg.bicgstab inside code/solvers.py:91-93) on caller-owned device vectors of `n` LOCAL
  * elements -- this rank's shard -- with the scalar recurrences in the handle's device block.  A step either

@@ -72,6 +72,7 @@ SYMBOLS = {
     "sdfs_solve_dev": (C.c_int, [_P, C.c_int, C.POINTER(sdfs_opts), _P, _I64, _I64, _D]),
     "sdfs_error_trace": (C.c_int64, [_P, _P, C.c_int64]),
     "sdfs_apply_stage_dev": (C.c_int, [_P, C.c_int, C.c_int, _P, _P, _P, _P]),
+    "sdfs_pack_blocks": (C.c_int, [_P, C.c_int, _P, _P, C.c_int64, C.c_int64, C.c_int64, C.c_int, C.POINTER(C.c_int64), C.c_int]),
     "sdfs_krylov_step": (C.c_int, [_P, C.c_int, C.c_int64, C.c_int, C.POINTER(_P), _P, C.c_double, C.c_double]),
     "sdfs_krylov_scalars": (C.c_int, [_P, _P]),
     "sdfs_set_krylov_f32": (C.c_int, [_P, C.c_int, C.c_double]),

@@ -2464,6 +2464,41 @@ int sdfs_apply_stage_dev(sdfs_handle* h, int stage, int mode, const double* in, 
                   (mode == MODE_JVP && old) ? 1 : 0);
 }
 
+int sdfs_pack_blocks(sdfs_handle* h, int unpack, const void* src, void* dst, int64_t outer, int64_t n_axis, int64_t inner,
+                     int nblocks, const int64_t* offs, int elem_bytes) {
+  int rc = check(h); if (rc) return rc;
+  if (!src || !dst || !offs) return fail(h, SDFS_ERR_ARG, "NULL argument");
+  if (nblocks < 1 || nblocks > PACK_MAX_BLOCKS) return fail(h, SDFS_ERR_ARG, "1..%d blocks", PACK_MAX_BLOCKS);
+  if (elem_bytes != 8 && elem_bytes != 4) return fail(h, SDFS_ERR_ARG, "elements of 4 or 8 bytes");
+  if (outer < 1 || n_axis < 1 || inner < 1 || offs[0] != 0 || offs[nblocks] != n_axis) return fail(h, SDFS_ERR_ARG, "bad block table");
+  PackBlocks B;
+  memset(&B, 0, sizeof B);
+  B.n = nblocks;
+  for (int j = 0; j <= nblocks; ++j) {
+    if (j > 0 && offs[j] <= offs[j - 1]) return fail(h, SDFS_ERR_ARG, "empty or unordered block");
+    B.off[j] = (unsigned)offs[j];
+  }
+  const long long run_bytes = (long long)inner * elem_bytes;
+  const int ub = (run_bytes % 16 == 0 && ((uintptr_t)src % 16) == 0 && ((uintptr_t)dst % 16) == 0) ? 16 : elem_bytes;
+  const long long innerU = run_bytes / ub;
+  const long long total = outer * n_axis * innerU;
+  if (total >= (1LL << 31)) return fail(h, SDFS_ERR_UNSUPPORTED, "pack: more than 2^31 units");
+  const unsigned grid = (unsigned)std::min<long long>((total + VEC_BLOCK - 1) / VEC_BLOCK, 8192);
+#define SDFS_PACK_LAUNCH(U)                                                                                              \
+  do {                                                                                                                   \
+    if (unpack) hipLaunchKernelGGL((k_pack_blocks<U, true>), dim3(grid), dim3(VEC_BLOCK), 0, h->stream, (const U*)src, (U*)dst, \
+                                   (unsigned)outer, (unsigned)n_axis, (unsigned)innerU, B);                              \
+    else hipLaunchKernelGGL((k_pack_blocks<U, false>), dim3(grid), dim3(VEC_BLOCK), 0, h->stream, (const U*)src, (U*)dst,       \
+                            (unsigned)outer, (unsigned)n_axis, (unsigned)innerU, B);                                     \
+  } while (0)
+  if (ub == 16) SDFS_PACK_LAUNCH(double2);
+  else if (ub == 8) SDFS_PACK_LAUNCH(double);
+  else SDFS_PACK_LAUNCH(float);
+#undef SDFS_PACK_LAUNCH
+  HIPCHK(h, hipGetLastError());
+  return 0;
+}
+
 int sdfs_krylov_step(sdfs_handle* h, int step, int64_t n, int f32, void* const* v, double* sums_dev, double rtol, double atol) {
   int rc = check(h); if (rc) return rc;
   if (!v || !sums_dev || n < 1) return fail(h, SDFS_ERR_ARG, "bad argument");

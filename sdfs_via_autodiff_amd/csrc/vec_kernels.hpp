@@ -602,4 +602,26 @@ k_and_mix_dev(AndPtrs h, const AndState* __restrict__ S, int m, double beta, dou
 #undef BODY
 }
 
+// ---- re-shard pack / unpack (multi-GPU exchange buffers) -----------------------------------------------------------------
+// grid = [outer][n_axis][inner] (C order), packed = concat_j [outer][size_j][inner] with block j = axis indices
+// offs[j] .. offs[j+1].  One launch moves the whole shard (the host side used one strided copy per peer).  U = unit type
+// (16 bytes when the inner run allows it, else one element); innerU = inner run in units.
+constexpr int PACK_MAX_BLOCKS = 16;
+struct PackBlocks { int n; unsigned off[PACK_MAX_BLOCKS + 1]; };
+template <typename U, bool UNPACK>
+__global__ void __launch_bounds__(VEC_BLOCK)
+k_pack_blocks(const U* __restrict__ src, U* __restrict__ dst, unsigned outer, unsigned n_axis, unsigned innerU, PackBlocks B) {
+  const unsigned total = outer * n_axis * innerU;          // < 2^31 (host check)
+  for (unsigned e = blockIdx.x * VEC_BLOCK + threadIdx.x; e < total; e += gridDim.x * VEC_BLOCK) {
+    const unsigned q = e / innerU, r = e - q * innerU;
+    const unsigned o = q / n_axis, i = q - o * n_axis;
+    int j = 0;
+#pragma unroll
+    for (int t = 1; t < PACK_MAX_BLOCKS; ++t) j += (t < B.n && i >= B.off[t]) ? 1 : 0;
+    const unsigned sz = B.off[j + 1] - B.off[j];
+    const unsigned p = (outer * B.off[j] + o * sz + (i - B.off[j])) * innerU + r;
+    if (UNPACK) dst[e] = src[p]; else dst[p] = src[e];
+  }
+}
+
 }  // namespace sdfs

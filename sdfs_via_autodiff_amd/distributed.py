@@ -102,6 +102,17 @@ class HipStages:
                                        resid.data_ptr() if resid is not None else None), self._h)
         return out
 
+    def pack_blocks(self, grid, packed, axis, offs, unpack=False):
+        """One launch between `grid` (contiguous, any rank) and the 1-D buffer `packed` in which every block
+        offs[j]:offs[j+1] of `axis` is one contiguous piece (sdfs_pack_blocks); unpack=True writes `grid`."""
+        shp = list(grid.shape)
+        outer = int(np.prod(shp[:axis], dtype=np.int64)) if axis > 0 else 1
+        inner = int(np.prod(shp[axis + 1:], dtype=np.int64)) if axis + 1 < len(shp) else 1
+        o = (C.c_int64 * len(offs))(*[int(v) for v in offs])
+        src, dst = (packed, grid) if unpack else (grid, packed)
+        check(lib.sdfs_pack_blocks(self._h, int(unpack), src.data_ptr(), dst.data_ptr(), outer, shp[axis], inner,
+                                   len(offs) - 1, o, grid.element_size()), self._h)
+
     def describe_plan(self):
         buf = C.create_string_buffer(4096)
         check(lib.sdfs_describe_plan(self._h, buf, len(buf)), self._h)
@@ -211,11 +222,25 @@ class ShardedKoopmans:
         shp[src_axis] = sum(src_sizes)
         shp[dst_axis] = dst_sizes[r]
         out = torch.empty(shp, dtype=x.dtype, device=x.device)
+        # device grids: one pack / unpack launch for the whole shard (sdfs_pack_blocks) instead of a strided copy per peer
+        fused = x.is_cuda and x.is_contiguous() and hasattr(self.backend, "pack_blocks") and self.world <= 16
         send = [x.narrow(dst_axis, dst_off[j], dst_sizes[j]) for j in range(self.world)]
         if dst_axis != 0:
-            send = [t.contiguous() for t in send]                      # pack
+            if fused:
+                packed = torch.empty(x.numel(), dtype=x.dtype, device=x.device)
+                self.backend.pack_blocks(x, packed, dst_axis, list(dst_off) + [x.shape[dst_axis]])
+                send = [p.view(t.shape) for p, t in zip(torch.split(packed, [t.numel() for t in send]), send)]
+            else:
+                send = [t.contiguous() for t in send]                  # pack
         slots = [out.narrow(src_axis, src_off[j], src_sizes[j]) for j in range(self.world)]
-        recv = slots if src_axis == 0 else [torch.empty(t.shape, dtype=x.dtype, device=x.device) for t in slots]
+        rflat = None
+        if src_axis == 0:
+            recv = slots
+        elif fused:
+            rflat = torch.empty(out.numel(), dtype=x.dtype, device=x.device)
+            recv = [p.view(t.shape) for p, t in zip(torch.split(rflat, [t.numel() for t in slots]), slots)]
+        else:
+            recv = [torch.empty(t.shape, dtype=x.dtype, device=x.device) for t in slots]
         if self._use_a2a:
             dist.all_to_all(recv, send, group=self.group)
         else:
@@ -237,8 +262,11 @@ class ShardedKoopmans:
                 for t, h_ in zip(recv, hr):
                     t.copy_(h_)
         if src_axis != 0:
-            for slot, t in zip(slots, recv):                               # unpack
-                slot.copy_(t)
+            if rflat is not None:
+                self.backend.pack_blocks(out, rflat, src_axis, list(src_off) + [out.shape[src_axis]], unpack=True)
+            else:
+                for slot, t in zip(slots, recv):                           # unpack
+                    slot.copy_(t)
         self.n_exchanges += 1
         return out
 
