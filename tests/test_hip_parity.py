@@ -669,3 +669,40 @@ def test_anderson_device_loop_matches_host_controlled_loop(S):
     assert idv["status"] == 0 and np.all(np.isfinite(xd))
     assert abs(nd - nh) <= max(8, nh // 10), (nd, nh)
     np.testing.assert_allclose(xd, xh, rtol=0, atol=1e-4)
+
+
+@pytest.mark.parametrize("model,shapes,beta,gamma,psi,level", [
+    ("ssy", (15, 15, 15, 15), 0.99, 13.68, 1.5, 5.0),          # theta = -38, start far below the fast opening power's range
+    ("ssy", (16, 16, 16, 16), 0.9987, 12.5, 1.97, 300.0),
+    ("ssy", (20, 5, 3, 17), 0.97, 4.71, 2.5, 60.0),            # generic tiles, theta = -6.2
+    ("gcy", (5, 4, 6, 3, 4, 5), 0.9987, 9.58, 0.7, 60.0),      # psi < 1: theta = +20
+    ("gcy", (8,) * 6, 0.999, 8.76, 0.7, 900.0),
+    ("gcy", (3,) * 6, 0.995, 9.92, 2.5, 5.0)])
+def test_other_calibrations(S, model, shapes, beta, gamma, psi, level):
+    """Exponents and discount factors other than the default calibrations (theta = (1-gamma)/(1-1/psi) from -38 to
+    +20): T, J.v and five iterations of the device SA loop -- whose fused kernels take the opening power either
+    from next_power_fast or, outside its range, from the general routine -- against the oracle."""
+    from oracle import models, ssy as ossy, gcy as ogcy
+    if model == "ssy":
+        m = S.SSY(β=beta, γ=gamma, ψ=psi); p = models.ssy_params(beta=beta, gamma=gamma, psi=psi)
+        arr = S.discretize_ssy(m, shapes)
+        To = lambda w: ossy.T_ssy_factorised(w, shapes, p, arr)       # noqa: E731
+        Jo = lambda w, v: ossy.jvp_ssy(w, v, shapes, p, arr)          # noqa: E731
+    else:
+        m = S.GCY(β=beta, γ=gamma, ψ=psi); p = models.gcy_params(beta=beta, gamma=gamma, psi=psi)
+        arr = S.discretize_gcy(m, shapes)
+        To = lambda w: ogcy.T_gcy_factorised(w, shapes, p, arr)       # noqa: E731
+        Jo = lambda w, v: ogcy.jvp_gcy(w, v, shapes, p, arr)          # noqa: E731
+    np.testing.assert_allclose(m.params, p, rtol=0, atol=0)
+    T = S.KoopmansOperator(model, shapes, m.params, arr)
+    rng = np.random.default_rng(4)
+    w = level * (0.6 + 0.8 * rng.random(shapes))
+    v = rng.standard_normal(shapes)
+    np.testing.assert_allclose(T(w), To(w), rtol=1e-12)
+    jo = Jo(w, v)
+    np.testing.assert_allclose(T.jvp(w, v), jo, rtol=1e-11, atol=1e-12 * np.max(np.abs(jo)))
+    x5, n5, _ = T.solve(w, "successive_approx", tol=0.0, max_iter=5)
+    w5 = w
+    for _ in range(5):
+        w5 = To(w5)
+    np.testing.assert_allclose(x5, w5, rtol=1e-11)
