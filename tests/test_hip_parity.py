@@ -505,44 +505,8 @@ def test_anderson_fixed_point_tight_after_polish(S):
     assert np.max(np.abs(xp - xs)) < 1e-8
 
 
-def test_newton_krylov_gcy20_config(S):
-    """configs[3] on one GPU: GCY 20^6 Newton-Krylov to 1e-8 from w = 800; |T(x) - x| < 1e-8 on the device and
-    a cross-check of the fixed point against the C oracle on the full grid; same with fp32 Krylov storage."""
-    from oracle.c_oracle import COperator
-    shapes = (20,) * 6
-    T, params, arr = make_op(S, "gcy", shapes)
-    w0 = np.full(shapes, 800.0)
-    x, n, info = T.solve(w0, "newton", tol=1e-8, inner_rtol=1e-6, inner_atol=0.0)
-    assert info["status"] == 0 and info["final_err"] <= 1e-8 and n < 25
-    tx = T(x)
-    assert np.max(np.abs(tx - x)) < 1e-8
-    oc = COperator("gcy", shapes, params, arr)
-    assert np.max(np.abs(oc(x) - x)) < 1e-8
-    del tx
-    x32, n32, i32 = T.solve(w0, "newton", tol=1e-8, inner_rtol=1e-6, inner_atol=0.0, krylov_f32=1)
-    assert i32["status"] == 0 and np.max(np.abs(x32 - x)) < 1e-7
-    T.close()
-
-
-def test_conditional_path_at_full_size(S):
-    """The conditional-tensor kernels (slice-dependent z_Q, 25.6 MB at 20^6) at full size: force them with
-    SDFS_NO_SLICE_MERGE (Rouwenhorst tensors are slice-identical) and compare with the merged plan and the
-    C oracle on a slab."""
-    import os
-    shapes = (20,) * 6
-    m = S.GCY(); arr = S.discretize_gcy(m, shapes)
-    os.environ["SDFS_NO_SLICE_MERGE"] = "1"
-    try:
-        Tc = S.KoopmansOperator("gcy", shapes, m.params, arr)
-    finally:
-        del os.environ["SDFS_NO_SLICE_MERGE"]
-    assert "z" in Tc.describe_plan() and "pair plan pass" not in Tc.describe_plan()
-    Tm = S.KoopmansOperator("gcy", shapes, m.params, arr)
-    w = wbench(shapes, seed=3)
-    a = Tc(w)
-    b = Tm(w)
-    np.testing.assert_allclose(a, b, rtol=APPLY_RTOL)
-    assert Tc.residual() == pytest.approx(Tm.residual(), rel=1e-12)
+# GCY 20^6: Newton-Krylov's distance to the polished fixed point and the conditional-tensor kernels against the
+# C oracle live in tests/test_hip_fullsize.py.
 
 
 def test_sa_on_callers_default_stream(S):
