@@ -183,6 +183,7 @@ struct SliceIO {
   const unsigned long long* gate;
   double gate_tol;
   unsigned long long* zero; // if non-null: cleared by workgroup 0 (the residual word the last pass will atomicMax into)
+  unsigned* sched;          // persistent form (stream_kernels.hpp): TK_WORDS scheduler words, zero between launches
 };
 
 template <int N> struct SliceGeo {
@@ -1162,6 +1163,10 @@ __global__ void __launch_bounds__(64) small_sa_finish(const double* part, int n,
 }
 
 typedef void (*small_fn)(const SmallDesc, const SmallIO);
+typedef void (*slice_fn)(const SliceDesc, const SliceIO);
+typedef void (*line_fn)(const LineDesc, const LineIO);
+
+#ifndef SDFS_NO_VARIANT_TABLES
 template <int R, int WPT> inline small_fn small_variant_rw(int mode) {
   switch (mode) {
     case SM_FIRST_T: return R == 1 ? (small_fn)small_tile_kernel<SM_FIRST_T, 1, WPT> : nullptr;
@@ -1182,8 +1187,6 @@ inline small_fn small_variant(int mode, int r, int wpt) {
 }
 inline unsigned small_grid(long long ntiles, int wpt) { return (unsigned)(wpt == 4 ? ntiles : (ntiles + 3) / 4); }
 
-typedef void (*slice_fn)(const SliceDesc, const SliceIO);
-typedef void (*line_fn)(const LineDesc, const LineIO);
 
 template <int N> inline slice_fn slice_variant_n(int mode, bool f32) {
   switch (mode) {
@@ -1237,6 +1240,7 @@ inline line_fn line_variant(int n, int mode, bool persist, bool fullc, bool f32 
     default: return nullptr;
   }
 }
+#endif
 inline int slice_tile_slices(int n) { return n == 16 ? SliceGeo<16>::G : n == 20 ? SliceGeo<20>::G : n == 24 ? SliceGeo<24>::G : SliceGeo<32>::G; }
 inline size_t slice_lds_bytes(int n) { return (size_t)slice_tile_slices(n) * n * n * 8 * 4; }
 inline int line_block(int n) { return n <= 24 ? 256 : 512; }

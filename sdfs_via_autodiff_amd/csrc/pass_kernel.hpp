@@ -831,6 +831,8 @@ __global__ void __launch_bounds__(256) debug_pow_kernel(const double* __restrict
 
 typedef void (*pass_fn)(const PassDesc, const PassIO);
 
+#ifndef SDFS_NO_VARIANT_TABLES   // (tools/probes/kernel_bench.hip names its kernels itself: referencing a variant instantiates it)
+
 // EPT in {1,2,4,8,16}, VEC in {1,2}, MODE in PassMode, PREC in {0, 1}
 template <int MODE, int PREC>
 inline pass_fn pass_kernel_variant_m(int ept, int vec) {
@@ -884,5 +886,7 @@ inline pass_fn pass_kernel_variant(int ept, int vec, int mode, int prec = 0) {
     default: return nullptr;
   }
 }
+
+#endif
 
 }  // namespace sdfs

@@ -22,6 +22,7 @@
 #include "../../include/sdfs_hip.h"
 #include "pass_kernel.hpp"
 #include "fast_kernels.hpp"
+#include "stream_kernels.hpp"
 #include "cont_kernel.hpp"
 #include "dense_kernel.hpp"
 #include "vec_kernels.hpp"
@@ -31,6 +32,7 @@ using namespace sdfs;
 namespace {
 
 constexpr int MAXD = 6;
+constexpr int SCHED_WORDS = TK_WORDS;   // scheduler words of one persistent line pass (stream_kernels.hpp; the older persistent form uses two)
 
 thread_local std::string g_create_error;
 
@@ -75,6 +77,7 @@ struct EventPair { hipEvent_t a, b; int counter; };
 struct FastPass {
   bool line = false;
   bool persist = false;        // line pass: persistent workgroups with look-ahead into the next tile
+  bool stream = false;         // line pass: the fp64 T / J.v middle pass and T's last pass run stream_kernels.hpp's forms
   int n = 0;
   int ax0 = -1, ax1 = -1;      // the contracted pair (ax0 slower)
   SliceDesc sd;
@@ -98,6 +101,7 @@ struct Knobs {
   int tile_budget = 0, filler_chunk = -1, force_waves = 0, no_occ_blocks = 0, no_pad = 0, no_vec2 = 0, no_vec4 = 0;
   int no_dot_fusion = 0, no_slice_merge = 0, cont_no_tensor = 0, cont_lds_cap = 4000;
   int line_persist = 0;        // SDFS_LINE_PERSIST bit 0: middle line passes persistent, bit 1: last line pass persistent
+  int line_stream = 3;         // SDFS_LINE_STREAM: stream_kernels.hpp forms of the fp64 line passes; bit 0: middle pass, bit 1: T's last pass (both: extents they were measured on), bit 2: every extent
                                // (measured equal to one tile per workgroup at GCY 20^6, tools/ab_plan.py: off by default)
   int pair_order = 1;          // SDFS_PAIR_ORDER: 1 = line passes slowest pair first (the last pass then walks the faster pair), 0 = fastest first
   int plan = 0;                // SDFS_PLAN: 0 = automatic, 1 = "classic" (generic tiles only), 2 = "pair" (pair plan whenever legal)
@@ -132,7 +136,7 @@ struct sdfs_handle {
   // plans: [0] full grid (or stage 0 of a sharded run), [1] stage 1 of a sharded run
   Plan plan[2];
   FastPlan fast;                      // pair plan of the full grid, when the model admits it
-  unsigned* sched = nullptr;          // tile tickets of the persistent line pass (two words per pass, zero between launches)
+  unsigned* sched = nullptr;          // tile tickets of the persistent line passes (SCHED_WORDS per pass, zero between launches)
   AndState* and_state = nullptr;      // device-resident Anderson loop: state, per-chunk record of its passes
   AndState* and_state_host = nullptr;
   double* and_err = nullptr; int* and_kind = nullptr; int and_slots = 0;
@@ -249,6 +253,7 @@ Knobs read_knobs() {
   k.cont_lds_cap = env_int("SDFS_CONT_LDS_CAP", 4000);
   k.pair_order = env_int("SDFS_PAIR_ORDER", 1);
   k.line_persist = env_int("SDFS_LINE_PERSIST", 0);
+  k.line_stream = env_int("SDFS_LINE_STREAM", 3);
   k.small_plan = env_int("SDFS_SMALL_PLAN", 1);
   k.small_r = env_int("SDFS_SMALL_R", 0);
   k.sa_fused = env_int("SDFS_SA_FUSED", 1);
@@ -818,9 +823,18 @@ int build_fast_plan(sdfs_handle* h) {
   for (size_t i = 0; i < passes.size(); ++i)
     if (passes[i].line) passes[i].persist = (h->knobs.line_persist >> (i + 1 == passes.size() ? 1 : 0)) & 1;
   if (!h->sched) {
-    HIPCHK(h, hipMalloc((void**)&h->sched, 64));
+    HIPCHK(h, hipMalloc((void**)&h->sched, sizeof(unsigned) * SCHED_WORDS * 4));
     h->misc_allocs.push_back(h->sched);
-    HIPCHK(h, hipMemset(h->sched, 0, 64));
+    HIPCHK(h, hipMemset(h->sched, 0, sizeof(unsigned) * SCHED_WORDS * 4));
+  }
+  for (FastPass& P : passes) {
+    P.stream = P.line && P.ld.lrest % LINE_R == 0 && (h->knobs.line_stream & 3) != 0 && ((h->knobs.line_stream & 4) != 0 || P.n == 20);
+    if (!P.stream) continue;
+    for (int m : {(int)L_MID, (int)L_TLAST, (int)L_TLAST_LIN}) {
+      line_fn f = line_stream_variant(P.n, m);
+      if (!f) return 0;
+      hipFuncSetAttribute((const void*)f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)line_lds_bytes(P.n));
+    }
   }
   h->fast.passes = passes;
   h->fast.ok = true;
@@ -912,6 +926,13 @@ int build_small_plan(sdfs_handle* h) {
   return 0;
 }
 
+// persistent middle pass of stream_kernels.hpp: a multiple of 8 workgroups (one ticket range per XCD)
+unsigned stream_mid_grid(const sdfs_handle* h, const FastPass& P) {
+  long long g = std::min<long long>(P.ld.ntiles, (long long)line_stream_wpc_mid(P.n) * h->num_cus);
+  g -= g % 8;
+  return (unsigned)std::max<long long>(g, 8);
+}
+
 // persistent line kernel: at most its resident workgroups per CU, each walking tiles b, b + grid, ...
 unsigned line_grid(const sdfs_handle* h, const FastPass& P) {
   if (!P.persist) return (unsigned)P.ld.ntiles;
@@ -988,7 +1009,7 @@ int run_fast_plan(sdfs_handle* h, int mode, const double* in, double* out, const
       LineIO io;
       memset(&io, 0, sizeof io);
       io.in = pin; io.out = pout; io.gate = gate; io.gate_tol = gate_tol;
-      io.sched = h->sched + 2 * i;
+      io.sched = h->sched + SCHED_WORDS * i;
       LineDesc d = P.ld;
       d.minus_identity = minus_identity;
       if (vjp) { d.Qx = h->ax[P.ax0].Qt; d.Qy = h->ax[P.ax1].Qt; }
@@ -1000,12 +1021,18 @@ int run_fast_plan(sdfs_handle* h, int mode, const double* in, double* out, const
       }
       const bool lf32 = f32 && (mode == MODE_JVP || lm == L_TLAST_LIN);
       line_fn fn = lf32 ? line_variant(P.n, lm, false, true, true) : line_variant(P.n, lm, P.persist, P.ld.lrest % LINE_R == 0);
+      unsigned grid = lf32 ? (unsigned)d.ntiles : line_grid(h, P);
+      if (P.stream && !lf32 && ((lm == L_MID && (h->knobs.line_stream & 1)) || ((lm == L_TLAST || lm == L_TLAST_LIN) && (h->knobs.line_stream & 2)))) {
+        // stream_kernels.hpp: persistent middle pass with the next tile in flight; last pass with its side stream loaded early
+        fn = line_stream_variant(P.n, lm);
+        grid = lm == L_MID ? stream_mid_grid(h, P) : (unsigned)d.ntiles;
+      }
       if (!fn) return fail(h, SDFS_ERR_UNSUPPORTED, "no line kernel variant");
       if (f32 && mode == MODE_JVP) bytes *= 0.5;
       int cid = -1;
       if (h->profiling) { char nm[48]; snprintf(nm, sizeof nm, "%s:%s", tag, P.label.c_str()); cid = counter_id(h, nm, bytes, P.flops); }
       ProfScope ps(h, cid);
-      hipLaunchKernelGGL(fn, dim3(lf32 ? (unsigned)d.ntiles : line_grid(h, P)), dim3(line_block(P.n)), line_lds_bytes(P.n), h->stream, d, io);
+      hipLaunchKernelGGL(fn, dim3(grid), dim3(line_block(P.n)), line_lds_bytes(P.n), h->stream, d, io);
     }
     HIPCHK(h, hipGetLastError());
   }
@@ -1123,7 +1150,7 @@ int big_sa_line(sdfs_handle* h, int pass, bool first_only, const double* in, dou
   LineIO io;
   memset(&io, 0, sizeof io);
   io.in = in; io.out = w_new; io.old = w_old; io.resid = resid; io.aux_out = h->tmp; io.gate = gate; io.gate_tol = gate_tol;
-  io.sched = h->sched + 2 * pass;
+  io.sched = h->sched + SCHED_WORDS * pass;
   LineDesc d = P.ld;
   d.first_only = first_only ? 1 : 0;
   line_fn fn = line_variant(P.n, L_TFUSED, false, P.ld.lrest % LINE_R == 0);
@@ -2597,6 +2624,7 @@ int sdfs_describe_plan(const sdfs_handle* h, char* buf, int64_t cap) {
         hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)line_variant(P.n, L_MID, P.persist, P.ld.lrest % LINE_R == 0), line_block(P.n), line_lds_bytes(P.n));
         snprintf(line, sizeof line, "pair plan pass %zu: %s lds %zu B block %d tiles %lld (outer %lld x %d chunks of 128 B) %s grid %u blocks/CU %d\n", i,
                  P.label.c_str(), line_lds_bytes(P.n), line_block(P.n), P.ld.ntiles, P.ld.nouter, P.ld.nchunks,
+                 P.stream ? "streamed (middle pass: persistent, next tile in flight; T's last pass: side stream loaded early)" :
                  P.persist ? "persistent" : "one tile per workgroup", line_grid(h, P), occ);
       }
       s += line;

@@ -1,0 +1,346 @@
+// stream_kernels.hpp -- forms of the pair plan's line kernel (fast_kernels.hpp) that keep global loads in flight
+// while a tile is in its fp64 phases.
+//
+// Why: the one-tile-per-workgroup kernels issue a tile's loads, wait, compute, store -- nothing of theirs is in
+// flight during the powers and the MFMAs, and the memory skeleton of the same tile walks loses 15-25 % of its rate
+// as soon as a compute-sized gap sits between its loads and its stores (tools/probes/tile_copy_probe.hip, `sleep`
+// rows of profiles/round2_probes.txt: 5.6 -> 4.4-4.6 TB/s); a load takes 5-7 us once the memory system is loaded.
+//   PERSIST  a workgroup walks tiles drawn from ticket counters; right after parking tile t in LDS it issues every
+//            load of tile t' and only waits for them when t is stored.  The Q fragments of both contractions stay in
+//            registers for the whole launch (loads return in order on gfx950: a Q load issued behind the prefetch
+//            would wait for all of it).  Pays for the middle pass (two contractions between load and store).
+//   OLDPF    the last pass's HBM side stream (w for the residual) is loaded for the whole tile before the
+//            contractions instead of a window of four units ahead of the power.
+// Measured one kernel at a time by tools/probes/kernel_bench.hip (profiles/round3_kernel_bench.txt).  The same
+// treatment of the slice kernel (one wave walking wave tiles, next tile in registers) lost 5 %: that pass is bound
+// by the issue of its power routine, and the 52 extra live registers cost more than the prefetch gains.
+#pragma once
+#include "fast_kernels.hpp"
+
+#ifndef SDFS_STREAM_STAMP      // tools/probes/kernel_bench.hip defines it: s_memtime stamps of one workgroup's phases
+#define SDFS_STREAM_STAMP(i)
+#define SDFS_STREAM_STAMP_NEXT
+#define SDFS_STREAM_STAMP_DECL
+#endif
+
+namespace sdfs {
+
+// tile registers as native vectors: a struct double2 moved between address spaces becomes an llvm.memcpy, and
+// a tile array that lives across the walk's loop then stays in scratch
+typedef double v2d __attribute__((ext_vector_type(2)));
+
+// Tile scheduler of a persistent launch: tickets, one counter per XCD.  The tiles are cut into eight contiguous
+// ranges; the workgroups (slice form: waves) of XCD x (= blockIdx.x & 7 under round-robin dispatch; only locality
+// depends on that) draw the tiles of range x in order, so tiles that are neighbours in memory are in flight at
+// about the same time (as under dispatch order; with a static stride per workgroup the walk drifts apart and
+// 128-byte rows lose their DRAM-page neighbours: 0.234 against 0.213 ms for the middle pass at 64 KB row spacing)
+// and the launch ends within one tile time on every CU.  The last workgroup out clears the scheduler words, so no
+// memset sits between launches.
+constexpr unsigned NO_TILE = 0xffffffffu;
+constexpr int TK_SUB = 4;                      // ticket words per XCD
+constexpr int TK_STRIDE = 16;                  // unsigneds between two words: a 64-byte line each
+constexpr int TK_WORDS = (8 * TK_SUB + 1) * TK_STRIDE;      // scheduler buffer of a launch (the last line: workgroups done)
+struct TicketWalk {
+  unsigned start, count;
+  unsigned* ctr;
+  // A returning atomic on one word retires every ~110 ns when hundreds of waves draw from it (measured: 40000
+  // tickets over 8 words took 0.55 ms), so every XCD's range is cut once more into TK_SUB sub-ranges with a word
+  // each, and a ticket can stand for `batch` consecutive tiles.
+  __device__ __forceinline__ TicketWalk(long long nunits, unsigned block, unsigned* sched) {
+    const unsigned q = (unsigned)(nunits >> 3), r = (unsigned)(nunits & 7);
+    const unsigned x = block & 7u, sub = (block >> 3) & (TK_SUB - 1);
+    const unsigned xs = (x < r) ? x * (q + 1) : r * (q + 1) + (x - r) * q;
+    const unsigned xc = q + (x < r ? 1u : 0u);
+    const unsigned q2 = xc / TK_SUB, r2 = xc % TK_SUB;
+    start = xs + ((sub < r2) ? sub * (q2 + 1) : r2 * (q2 + 1) + (sub - r2) * q2);
+    count = q2 + (sub < r2 ? 1u : 0u);
+    ctr = sched + (x * TK_SUB + sub) * TK_STRIDE;
+  }
+  // one lane calls; NO_TILE once the sub-range is drained
+  __device__ __forceinline__ unsigned draw() const {
+    const unsigned i = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return i < count ? start + i : NO_TILE;
+  }
+};
+// called by one lane per workgroup (slice form: per wave) after its last draw has returned
+__device__ __forceinline__ void ticket_walk_done(unsigned* sched, unsigned narrivals) {
+  const unsigned d = __hip_atomic_fetch_add(&sched[8 * TK_SUB * TK_STRIDE], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (d == narrivals - 1) {
+    for (int i = 0; i <= 8 * TK_SUB; ++i) __hip_atomic_store(&sched[i * TK_STRIDE], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+// tile t of a line pass -> (outer index, chunk) and the element offset of its first row
+__device__ __forceinline__ long long line_tile_base(const LineDesc& P, const long long t, const int nn, unsigned& o, int& chunk) {
+  o = (unsigned)t / (unsigned)P.nchunks;
+  chunk = (int)((unsigned)t - o * (unsigned)P.nchunks);
+  return (long long)o * nn * P.lrest + (long long)chunk * LINE_R;
+}
+// all loads of one line tile (whole chunks): unit u = tid + k B at byte offset b0 + k bstep of the tile's base
+template <int EPT, int B, int UNITS>
+__device__ __forceinline__ void line_tile_load(v2d (&v)[EPT], const double* base, const int tid, const unsigned b0, const unsigned bstep) {
+  const char* const inb = reinterpret_cast<const char*>(base);
+#pragma unroll
+  for (int k = 0; k < EPT; ++k) {
+    const bool rowok = UNITS % B == 0 || tid + k * B < UNITS;
+    v[k] = *reinterpret_cast<const v2d*>(inb + (rowok ? b0 + k * bstep : b0));
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// line_stream_kernel: line_kernel's forms on whole chunks (lrest % 16 == 0), one workgroup walking tiles.
+// WPC = workgroups per CU the register budget is set for (3: 168 VGPRs, 2: 256).
+// OLDPF: the epilogue's HBM side stream (T: w for the residual; J.v: v) is loaded for the WHOLE tile before the
+// contractions instead of a window of four units ahead of the power -- a window is a few hundred cycles deep, an HBM
+// load under load takes microseconds (phase stamps: the epilogue took 10 us per tile against 3.3 us of issue).  The
+// epilogue is then fully unrolled (static register indices).  (Issuing the next tile's loads unit by unit as the
+// epilogue retires side-stream registers, to save the second register set, did not work: the loads of a loaded
+// memory system take 5-7 us, the park at the top of the next tile waited 7 us for them.)
+// B = threads per workgroup (a multiple of 64; the column tiles of a contraction go round the B / 64 waves).
+// PERSIST = false: one tile per workgroup (grid = ntiles, XCD-contiguous order), no next-tile prefetch, one Q fragment
+// set at a time -- the OLDPF side-stream load on its own, at a register budget that admits three workgroups per CU.
+template <int N, int MODE, int WPC, bool OLDPF = false, int B = LineGeo<N>::B, bool PERSIST = true>
+__global__ void __launch_bounds__(B, WPC * B / 256)
+line_stream_kernel(const LineDesc P, const LineIO io) {
+  using Geo = LineGeo<N>;
+  constexpr int NW = B / 64;
+  constexpr int EPT = (Geo::UNITS + B - 1) / B;
+  constexpr bool CES = MODE == L_TLAST || MODE == L_TLAST_LIN;
+  constexpr bool LINE = MODE == L_TLAST_LIN;
+  constexpr bool MULE = MODE == L_JLAST;
+  constexpr bool PARTIAL = Geo::UNITS % B != 0;
+  static_assert(MODE != L_TFUSED, "see line_fused_stream_kernel");
+  extern __shared__ double lds[];
+  __shared__ double red[16];
+  if (io.gate != nullptr) {
+    const unsigned long long g = *io.gate;
+    if (g <= (unsigned long long)__double_as_longlong(io.gate_tol)) return;
+  }
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 15, lk = lane >> 4;
+  const int c2 = tid & 7;
+  const unsigned b0 = ((unsigned)(tid >> 3) * (unsigned)P.lrest + 2u * c2) * 8u;
+  const unsigned bstep = (unsigned)(B / 8) * (unsigned)P.lrest * 8u;
+  const bool need_old = CES ? (io.resid != nullptr) : (MULE && P.minus_identity);
+  const char* const a3b = reinterpret_cast<const char*>(P.a3);
+  const unsigned a3x = (unsigned)P.a3x, a3y = (unsigned)P.a3y;
+  const TicketWalk W(P.ntiles, blockIdx.x, io.sched);
+  __shared__ unsigned tk[3];           // tk[0], tk[1]: the first two tiles; then tk[par] = the ticket drawn during the tile before last
+  unsigned cur, nxt = NO_TILE;
+  int par = 0;
+  if (PERSIST) {
+    if (tid == 0) { const unsigned t0 = W.draw(); tk[0] = t0; tk[1] = t0 != NO_TILE ? W.draw() : NO_TILE; }
+    __syncthreads();
+    cur = tk[0]; nxt = tk[1];
+    __syncthreads();
+  } else {
+    cur = (unsigned)xcd_remap((long long)blockIdx.x, P.ntiles);
+  }
+  QFrag<N> qx, qy_;
+  qx.load(P.Qx, lane);
+  if (PERSIST) qy_.load(P.Qy, lane);
+  QFrag<N>& qy = PERSIST ? qy_ : qx;
+  PowLane PT;
+  if (CES) PT = pow_lane_init(lane);
+  SDFS_STREAM_STAMP_DECL;
+  double rmax = 0.0, dot_yv = 0.0, dot_yy = 0.0;
+  bool rnan = false;
+
+  v2d v[EPT];
+  v2d wv[OLDPF ? EPT : 1];
+  if (cur != NO_TILE) {
+    {
+      unsigned o0; int ch0;
+      line_tile_load<EPT, B, Geo::UNITS>(v, io.in + line_tile_base(P, cur, N * N, o0, ch0), tid, b0, bstep);
+    }
+    for (;;) {
+      SDFS_STREAM_STAMP(0);
+#pragma unroll
+      for (int k = 0; k < EPT; ++k)
+        if (!PARTIAL || tid + k * B < Geo::UNITS) *reinterpret_cast<v2d*>(lds + 2 * (tid + k * B)) = v[k];
+      const bool has_next = PERSIST && nxt != NO_TILE;            // uniform over the workgroup
+      unsigned o; int chunk;
+      const long long tbase = line_tile_base(P, cur, N * N, o, chunk);
+      if constexpr (OLDPF) { if (need_old) line_tile_load<EPT, B, Geo::UNITS>(wv, io.old + tbase, tid, b0, bstep); }
+      unsigned o1; int ch1;
+      const char* const nxb = reinterpret_cast<const char*>(io.in + line_tile_base(P, has_next ? nxt : cur, N * N, o1, ch1));
+      if (has_next) line_tile_load<EPT, B, Geo::UNITS>(v, reinterpret_cast<const double*>(nxb), tid, b0, bstep);
+      unsigned nn = NO_TILE;                                         // (published before the third barrier: by then it has returned)
+      if (PERSIST && tid == 0 && has_next) nn = W.draw();
+      SDFS_STREAM_STAMP(1);
+      __syncthreads();
+      SDFS_STREAM_STAMP(2);
+      {
+        double* const p0 = lds + li + lk * Geo::LX;
+#pragma unroll
+        for (int j = 0; j < (N + NW - 1) / NW; ++j) { if (N % NW == 0 || wave + j * NW < N) ctile<N, Geo::LX>(p0 + (wave + j * NW) * 16, qx); __builtin_amdgcn_sched_barrier(0); }
+      }
+      SDFS_STREAM_STAMP(3);
+      if (!PERSIST) qx.load(P.Qy, lane);
+      __syncthreads();
+      SDFS_STREAM_STAMP(4);
+      {
+        double* const p0 = lds + li + lk * LINE_R;
+#pragma unroll
+        for (int j = 0; j < (N + NW - 1) / NW; ++j) { if (N % NW == 0 || wave + j * NW < N) ctile<N, LINE_R>(p0 + (wave + j * NW) * Geo::LX, qy); __builtin_amdgcn_sched_barrier(0); }
+      }
+      SDFS_STREAM_STAMP(5);
+      if (PERSIST && tid == 0) tk[par] = nn;
+      __syncthreads();
+      SDFS_STREAM_STAMP(6);
+      char* const outb = reinterpret_cast<char*>(io.out + tbase);
+      if (!CES && !MULE) {
+#pragma unroll
+        for (int k = 0; k < EPT; ++k) {
+          const int u = tid + k * B;
+          if (!PARTIAL || u < Geo::UNITS) *reinterpret_cast<v2d*>(outb + (b0 + (unsigned)k * bstep)) = *reinterpret_cast<const v2d*>(lds + 2 * u);
+          if (k % 4 == 3) __builtin_amdgcn_sched_barrier(0);      // four units on their way out at a time (register budget)
+        }
+      } else {
+        // epilogue, unit by unit; side streams a window of LOOK units ahead (they queue behind the prefetch, which
+        // has had both contractions to land)
+        constexpr int LOOK = 4;
+        const char* const oldb = reinterpret_cast<const char*>(io.old + tbase);
+        const char* const auxb = reinterpret_cast<const char*>(io.aux_in + tbase);
+        char* const auxo = reinterpret_cast<char*>(io.aux_out + tbase);
+        unsigned ia3a = 0u, ia3b = 0u;
+        if (CES) {
+          const long long pos = (long long)chunk * LINE_R + 2 * c2;
+          ia3a = (unsigned)(P.out_idx[o] + P.rest_idx[pos]);
+          ia3b = (unsigned)(P.out_idx[o] + P.rest_idx[pos + 1]);
+        }
+        double2 sw[LOOK], cw[LOOK];
+        auto issue = [&](const int k, double2& s1, double2& s2) {
+          const int u = tid + k * B;
+          const bool rowok = k < EPT && (!PARTIAL || u < Geo::UNITS);
+          const unsigned offc = rowok ? b0 + (unsigned)k * bstep : b0;
+          if (!OLDPF && need_old) s1 = *reinterpret_cast<const double2*>(oldb + offc);
+          if (CES) {
+            const int row = rowok ? (u >> 3) : 0;
+            const int x = row / N, y = row - x * N;
+            const unsigned ixy = __umul24((unsigned)x, a3x) + __umul24((unsigned)y, a3y);
+            s2 = make_double2(*reinterpret_cast<const double*>(a3b + (ia3a + ixy) * 8u),
+                              *reinterpret_cast<const double*>(a3b + (ia3b + ixy) * 8u));
+          } else {
+            s2 = *reinterpret_cast<const double2*>(auxb + offc);
+          }
+        };
+        auto unit = [&](const int k, const double2 s1, const double2 s2) {
+          const int u = tid + k * B;
+          const bool rowok = !PARTIAL || u < Geo::UNITS;
+          const unsigned off = b0 + (unsigned)k * bstep;
+          const double2 sv = *reinterpret_cast<const double2*>(lds + 2 * (rowok ? u : tid));
+          if (CES) {
+            const double ks[2] = {s2.x * sv.x, s2.y * sv.y};
+            double uu[2];
+            pow_fast_n<false, 2>(ks, P.inv_theta, PT, uu);
+            const double2 y2 = make_double2(1.0 + P.beta * uu[0], 1.0 + P.beta * uu[1]);
+            if (rowok) {
+              if (LINE) *reinterpret_cast<double2*>(auxo + off) = make_double2(P.beta * uu[0] / sv.x, P.beta * uu[1] / sv.y);
+              if (need_old) {
+                const double r0 = fabs(y2.x - s1.x), r1 = fabs(y2.y - s1.y);
+                rnan |= (r0 != r0) | (r1 != r1);
+                rmax = fmax(rmax, fmax(r0, r1));
+              }
+              *reinterpret_cast<double2*>(outb + off) = y2;
+            }
+          } else if (rowok) {
+            double2 y2 = make_double2(sv.x * s2.x, sv.y * s2.y);
+            if (P.minus_identity) {
+              y2.x -= s1.x; y2.y -= s1.y;
+              dot_yv = fma(y2.x, s1.x, dot_yv); dot_yv = fma(y2.y, s1.y, dot_yv);
+              dot_yy = fma(y2.x, y2.x, dot_yy); dot_yy = fma(y2.y, y2.y, dot_yy);
+            }
+            *reinterpret_cast<double2*>(outb + off) = y2;
+          }
+        };
+#pragma unroll
+        for (int j = 0; j < LOOK; ++j) issue(j, sw[j], cw[j]);
+        if (OLDPF) {
+#pragma unroll
+          for (int k = 0; k < EPT; ++k) {
+            const v2d wk = wv[OLDPF ? k : 0];
+            unit(k, make_double2(wk.x, wk.y), cw[k % LOOK]);
+            if (k + LOOK < EPT) issue(k + LOOK, sw[k % LOOK], cw[k % LOOK]);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        } else {
+          int kk = 0;
+#pragma unroll 1
+          for (; kk + LOOK <= EPT; kk += LOOK) {
+#pragma unroll
+            for (int j = 0; j < LOOK; ++j) {
+              unit(kk + j, sw[j], cw[j]);
+              issue(kk + j + LOOK, sw[j], cw[j]);
+              __builtin_amdgcn_sched_barrier(0);
+            }
+          }
+#pragma unroll
+          for (int j = 0; j < EPT % LOOK; ++j) unit(EPT - EPT % LOOK + j, sw[j], cw[j]);
+        }
+      }
+      SDFS_STREAM_STAMP(7);
+      SDFS_STREAM_STAMP_NEXT;
+      if (!has_next) break;
+      cur = nxt;
+      nxt = tk[par];
+      par ^= 1;
+    }
+  }
+  if (PERSIST && tid == 0) ticket_walk_done(io.sched, gridDim.x);
+  if (MULE && io.dotp != nullptr) {
+#pragma unroll
+    for (int s = 32; s > 0; s >>= 1) { dot_yv += __shfl_xor(dot_yv, s); dot_yy += __shfl_xor(dot_yy, s); }
+    if (lane == 0) { red[wave] = dot_yv; red[8 + wave] = dot_yy; }
+    __syncthreads();
+    if (tid == 0) {
+      double a = 0.0, b = 0.0;
+      for (int w = 0; w < NW; ++w) { a += red[w]; b += red[8 + w]; }
+      io.dotp[blockIdx.x] = a;
+      io.dotp[gridDim.x + blockIdx.x] = b;
+    }
+  }
+  if (CES && io.resid != nullptr) {
+    if (rnan) rmax = __longlong_as_double(0x7ff0000000000000LL);
+#pragma unroll
+    for (int s = 32; s > 0; s >>= 1) rmax = fmax(rmax, __shfl_xor(rmax, s));
+    if (lane == 0) red[wave] = rmax;
+    __syncthreads();
+    if (tid == 0) {
+      double r = red[0];
+      for (int w = 1; w < NW; ++w) r = fmax(r, red[w]);
+      atomicMax(io.resid, (unsigned long long)__double_as_longlong(r));
+    }
+  }
+}
+
+#ifndef SDFS_NO_VARIANT_TABLES
+// whole chunks only (lrest % 16 == 0); fp64 streams
+template <int N> struct StreamGeo {
+  static constexpr int B = LineGeo<N>::B;
+  static constexpr int WPC_MID = N == 32 ? 1 : 2;                       // persistent middle pass: workgroups per CU launched
+  static constexpr int WPC_LAST = N == 16 ? 3 : LineGeo<N>::BPC;        // one tile per workgroup: register budget of the last pass
+};
+template <int N> inline line_fn line_stream_variant_n(int mode) {
+  using G = StreamGeo<N>;
+  switch (mode) {
+    case L_MID: return (line_fn)line_stream_kernel<N, L_MID, G::WPC_MID, false, G::B, true>;
+    case L_TLAST: return (line_fn)line_stream_kernel<N, L_TLAST, G::WPC_LAST, true, G::B, false>;
+    case L_TLAST_LIN: return (line_fn)line_stream_kernel<N, L_TLAST_LIN, G::WPC_LAST, true, G::B, false>;
+    default: return nullptr;
+  }
+}
+inline line_fn line_stream_variant(int n, int mode) {
+  switch (n) {
+    case 16: return line_stream_variant_n<16>(mode);
+    case 20: return line_stream_variant_n<20>(mode);
+    case 24: return line_stream_variant_n<24>(mode);
+    case 32: return line_stream_variant_n<32>(mode);
+    default: return nullptr;
+  }
+}
+inline int line_stream_wpc_mid(int n) { return n == 32 ? 1 : 2; }
+#endif
+
+}  // namespace sdfs

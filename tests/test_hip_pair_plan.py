@@ -280,3 +280,69 @@ def test_fused_sa_6d(S, shapes):
     np.testing.assert_array_equal(xg, xf)
     w = wbench(shapes)
     np.testing.assert_allclose(Tf(w), Tu(w), rtol=APPLY_RTOL)           # the operator itself is untouched
+
+
+# the streamed forms of the line passes (csrc/stream_kernels.hpp): persistent middle pass with the next tile in
+# flight (tickets), last pass with the residual's w loaded for the whole tile before the contractions.  Default for
+# 20-extent pairs; SDFS_LINE_STREAM is a bit mask (1: middle pass, 2: T's last pass, 4: every extent), 0 = off.
+@contextlib.contextmanager
+def stream_env(v):
+    old = os.environ.get("SDFS_LINE_STREAM")
+    os.environ["SDFS_LINE_STREAM"] = str(v)
+    try:
+        yield
+    finally:
+        if old is None:
+            del os.environ["SDFS_LINE_STREAM"]
+        else:
+            os.environ["SDFS_LINE_STREAM"] = old
+
+
+@pytest.mark.parametrize("shapes", [(16, 16, 16, 16, 16, 16), (16, 16, 20, 20, 16, 16), (24, 24, 16, 16, 16, 16),
+                                    (16, 16, 32, 32, 16, 16), (20, 20, 20, 20, 16, 16)])
+def test_streamed_line_passes_match_plain_ones(S, shapes):
+    """6-D grids (a middle and a last line pass): T with its residual, the linearising T and J.v through the streamed
+    forms against the one-tile-per-workgroup forms and the C oracle; twice in a row (the ticket words must be back at
+    zero after a launch); a gated launch must leave them alone too."""
+    from oracle.c_oracle import COperator
+    g = S.GCY(); arr = S.discretize_gcy(g, shapes)
+    with plan_env("pair"):
+        with stream_env(7):
+            Ts = S.KoopmansOperator("gcy", shapes, g.params, arr)
+        with stream_env(0):
+            Tp = S.KoopmansOperator("gcy", shapes, g.params, arr)
+    assert "streamed" in Ts.describe_plan() and "streamed" not in Tp.describe_plan()
+    oc = COperator("gcy", shapes, g.params, arr)
+    w = wbench(shapes, seed=21)
+    want = oc(w)
+    for _ in range(2):
+        got = Ts(w)
+        assert np.max(np.abs(got - want) / want) < APPLY_RTOL
+        assert Ts.residual() == pytest.approx(float(np.max(np.abs(want - w))), rel=1e-12)
+    np.testing.assert_allclose(Ts(w), Tp(w), rtol=1e-13)
+    v = np.random.default_rng(22).standard_normal(shapes)
+    js, jp = Ts.jvp(w, v), Tp.jvp(w, v)
+    assert np.max(np.abs(js - jp)) <= 1e-12 * np.max(np.abs(jp))
+    assert np.max(np.abs(js - oc.jvp(w, v))) <= 1e-11 * np.max(np.abs(jp))
+    # solver loops on the streamed kernels: same iterates as on the plain ones (unfused loop: T applications)
+    w0 = np.full(shapes, 800.0)
+    os.environ["SDFS_SA_FUSED"] = "0"
+    try:
+        with plan_env("pair"):
+            with stream_env(7):
+                Tsu = S.KoopmansOperator("gcy", shapes, g.params, arr)
+            with stream_env(0):
+                Tpu = S.KoopmansOperator("gcy", shapes, g.params, arr)
+    finally:
+        del os.environ["SDFS_SA_FUSED"]
+    xs, ns, i_s = Tsu.solve(w0, "successive_approx", tol=1e-2, record_errors=True, check_every=7)
+    xp, n_p, i_p = Tpu.solve(w0, "successive_approx", tol=1e-2, record_errors=True)
+    assert ns == n_p and ns > 10
+    np.testing.assert_allclose(i_s["errors"], i_p["errors"], rtol=1e-11)
+    np.testing.assert_allclose(xs, xp, rtol=1e-12)
+    xs, ns, _ = Ts.solve(w0, "newton", tol=1e-8, inner_rtol=1e-6, inner_atol=0.0)
+    xp, n_p, _ = Tp.solve(w0, "newton", tol=1e-8, inner_rtol=1e-6, inner_atol=0.0)
+    assert ns == n_p
+    assert np.max(np.abs(xs - xp)) < 1e-9
+    for T in (Ts, Tp, Tsu, Tpu):
+        T.close()

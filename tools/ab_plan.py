@@ -15,6 +15,9 @@ import sdfs_via_autodiff_amd as S  # noqa: E402
 
 VARIANTS = {
     "pair o1 p0 (default)": {},
+    "stream 0 (plain line kernels)": {"SDFS_LINE_STREAM": "0"},
+    "stream 1 (middle only)": {"SDFS_LINE_STREAM": "1"},
+    "stream 2 (last only)": {"SDFS_LINE_STREAM": "2"},
     "pair o1 p2": {"SDFS_LINE_PERSIST": "2"},
     "pair o1 p3": {"SDFS_LINE_PERSIST": "3"},
     "pair o0 p2": {"SDFS_PAIR_ORDER": "0"},
@@ -64,7 +67,7 @@ def main():
         per = "  ".join(f"{c['total_ms'] / max(c['launches'], 1):.4f}" for c in op.counters())
         op.set_profiling(False)
         t = sorted(times[name])
-        print(f"{name:24s} median {t[len(t) // 2]:.4f} ms  min {t[0]:.4f}  max {t[-1]:.4f}   kernels: {per}", flush=True)
+        print(f"{name:32s} median {t[len(t) // 2]:.4f} ms  min {t[0]:.4f}  max {t[-1]:.4f}   kernels: {per}", flush=True)
 
 
 if __name__ == "__main__":

@@ -1,0 +1,229 @@
+// Probe: the pair-plan kernels of csrc/fast_kernels.hpp and their persistent prefetching forms
+// (csrc/stream_kernels.hpp) on the GCY 20^6 geometry, one kernel at a time, outside the library:
+// HIP-event time per launch, algorithmic GB/s, and the maximum relative difference of the candidate's output
+// from the baseline kernel's.  Synthetic operands (random row-stochastic matrices, w in [400, 900]).
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -o kernel_bench kernel_bench.hip && ./kernel_bench [n]
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <algorithm>
+#include <random>
+#include <string>
+#include <vector>
+
+#define SDFS_NO_VARIANT_TABLES
+// phase stamps of workgroup 8 (wave 0) for its first 12 tiles
+__device__ long long g_stamps[12 * 8];
+__device__ int g_stamp_it;
+// (the counter lives in a register and the enable flag comes through a scalar load: a vector load in a stamp would
+// wait, in order, for every prefetch issued before it)
+#define SDFS_STREAM_STAMP_DECL int stamp_it = (blockIdx.x == 8 && __builtin_nontemporal_load(&g_stamp_it) == 0) ? 0 : 1000
+#define SDFS_STREAM_STAMP(i) do { if (threadIdx.x == 0 && stamp_it < 12) g_stamps[stamp_it * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define SDFS_STREAM_STAMP_NEXT do { stamp_it++; } while (0)
+#include "../../sdfs_via_autodiff_amd/csrc/stream_kernels.hpp"
+
+using namespace sdfs;
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
+
+static double time_ms(const std::function<void()>& f, int reps = 20) {
+  static hipEvent_t e0, e1; static bool init = false;
+  if (!init) { hipEventCreate(&e0); hipEventCreate(&e1); init = true; }
+  f();
+  hipEventRecord(e0);
+  for (int i = 0; i < reps; ++i) f();
+  hipEventRecord(e1); hipEventSynchronize(e1);
+  float ms; hipEventElapsedTime(&ms, e0, e1);
+  CK(hipGetLastError());
+  return ms / reps;
+}
+
+// candidates are registered first and then timed in interleaved rounds (clock ramp, thermal drift and cache state
+// hit every candidate alike); the median over the rounds is reported
+struct Cand { std::string name; std::function<void()> launch; std::function<double()> check; double bytes; std::vector<double> ms; };
+static std::vector<Cand> g_cands;
+// one launch with stamps: phase durations (s_memtime ticks at 2.09 GHz -> us) of workgroup 8's tiles
+static void dump_stamps(const char* name, const std::function<void()>& launch) {
+  int zero = 0;
+  static long long zeros[96];
+  CK(hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), zeros, sizeof zeros));
+  CK(hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_it), &zero, sizeof zero));
+  launch();
+  CK(hipDeviceSynchronize());
+  long long st[96]; int nit = 12;
+  CK(hipMemcpyFromSymbol(st, HIP_SYMBOL(g_stamps), sizeof st));
+  printf("%s: phases per tile, us (park+issue | barrier | contract X | barrier | contract Y | barrier | epilogue | tile total)\n", name);
+  for (int t = 0; t < nit && st[t * 8 + 7] != 0; ++t) {
+    printf("   tile %2d:", t);
+    for (int i = 0; i < 7; ++i) printf(" %6.2f", (st[t * 8 + i + 1] - st[t * 8 + i]) / 2090.0);
+    printf("  | %6.2f", (st[t * 8 + 7] - st[t * 8]) / 2090.0);
+    if (t > 0) printf("  (gap %5.2f)", (st[t * 8] - st[(t - 1) * 8 + 7]) / 2090.0);
+    printf("\n");
+  }
+  int big = 1 << 20;
+  CK(hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_it), &big, sizeof big));
+}
+static void run_all(int rounds) {
+  for (int i = 0; i < 300; ++i) g_cands[i % g_cands.size()].launch();      // spin-up
+  CK(hipDeviceSynchronize());
+  for (int r = 0; r < rounds; ++r)
+    for (auto& c : g_cands) c.ms.push_back(time_ms(c.launch));
+  for (auto& c : g_cands) {
+    std::sort(c.ms.begin(), c.ms.end());
+    const double med = c.ms[c.ms.size() / 2];
+    printf("%-56s %.4f ms (min %.4f max %.4f)  %.2f TB/s  maxrel %.2e\n", c.name.c_str(), med, c.ms.front(), c.ms.back(), c.bytes / med / 1e9,
+           c.check ? c.check() : 0.0);
+  }
+  g_cands.clear();
+}
+
+__global__ void max_rel_diff(const double* a, const double* b, long long n, double* out) {
+  double m = 0.0;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const double d = fabs(a[i] - b[i]) / fmax(fabs(b[i]), 1e-300);
+    m = fmax(m, d != d ? 1e300 : d);
+  }
+  for (int s = 32; s > 0; s >>= 1) m = fmax(m, __shfl_xor(m, s));
+  if ((threadIdx.x & 63) == 0) atomicMax((unsigned long long*)out, (unsigned long long)__double_as_longlong(m));
+}
+static double diff(const double* a, const double* b, long long n) {
+  static double* d = nullptr;
+  if (!d) CK(hipMalloc(&d, 8));
+  CK(hipMemset(d, 0, 8));
+  max_rel_diff<<<1024, 256>>>(a, b, n, d);
+  double h; CK(hipMemcpy(&h, d, 8, hipMemcpyDeviceToHost));
+  return h;
+}
+
+int main(int argc, char** argv) {
+  const int n = argc > 1 ? atoi(argv[1]) : 20;
+  if (n != 20 && n != 16) { printf("n = 16 or 20\n"); return 1; }
+  const long long N = (long long)n * n * n * n * n * n;
+  int ncu = 0; hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, 0);
+  printf("grid %d^6 = %lld points, %d CUs\n", n, N, ncu);
+  std::mt19937_64 rng(1);
+  std::uniform_real_distribution<double> U(0.0, 1.0);
+  std::vector<double> hw((size_t)N);
+  for (auto& x : hw) x = 400.0 + 500.0 * U(rng);
+  auto mkQ = [&]() {
+    std::vector<double> q((size_t)n * n);
+    for (int i = 0; i < n; ++i) { double s = 0; for (int j = 0; j < n; ++j) { q[i * n + j] = U(rng) + (i == j ? 3.0 : 0.0); s += q[i * n + j]; } for (int j = 0; j < n; ++j) q[i * n + j] /= s; }
+    return q;
+  };
+  double *w, *tmpA, *tmpB, *outA, *outB, *Q[4], *a3;
+  CK(hipMalloc(&w, N * 8)); CK(hipMalloc(&tmpA, N * 8)); CK(hipMalloc(&tmpB, N * 8)); CK(hipMalloc(&outA, N * 8)); CK(hipMalloc(&outB, N * 8));
+  CK(hipMemcpy(w, hw.data(), N * 8, hipMemcpyHostToDevice));
+  for (int i = 0; i < 4; ++i) { auto q = mkQ(); CK(hipMalloc(&Q[i], q.size() * 8)); CK(hipMemcpy(Q[i], q.data(), q.size() * 8, hipMemcpyHostToDevice)); }
+  const long long n2 = (long long)n * n, n4 = n2 * n2;
+  // a3[b, c, e, a] as in GCY: strides a:1, e:n, c:n^2, b:n^3
+  std::vector<double> ha3((size_t)n4);
+  for (auto& x : ha3) x = 0.5 + U(rng);
+  CK(hipMalloc(&a3, n4 * 8)); CK(hipMemcpy(a3, ha3.data(), n4 * 8, hipMemcpyHostToDevice));
+  const double theta = -36.03, beta = 0.998;
+  unsigned long long* resid; CK(hipMalloc(&resid, 8));
+  unsigned* sched; CK(hipMalloc(&sched, TK_WORDS * 4)); CK(hipMemset(sched, 0, TK_WORDS * 4));
+
+  // ---- pass 1: slices over the two fastest axes ------------------------------------------------------
+  SliceDesc sd; memset(&sd, 0, sizeof sd);
+  sd.nslices = N / n2; sd.Qf = Q[0]; sd.Qe = Q[1]; sd.theta = theta;
+  const size_t slds = slice_lds_bytes(n);
+  const long long swt = (sd.nslices + slice_tile_slices(n) - 1) / slice_tile_slices(n);
+  const unsigned sgrid0 = (unsigned)((swt + 3) / 4);
+  typedef std::function<void()> Launch;
+  // registers a candidate; `ref` (if given) is the launch whose output `refbuf` the candidate's `out` is compared with
+  auto add = [&](const std::string& name, Launch l, double bytes, double* out, Launch ref, double* refbuf) {
+    Cand c; c.name = name; c.bytes = bytes; c.launch = l;
+    if (ref) c.check = [=]() { ref(); l(); return diff(out, refbuf, N); };
+    g_cands.push_back(c);
+  };
+  auto slice_launch = [&](slice_fn fn, unsigned grid, const double* in, double* out) -> Launch {
+    hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)slds);
+    SliceIO io; memset(&io, 0, sizeof io); io.in = in; io.out = out; io.sched = sched;
+    return [=]() { hipLaunchKernelGGL(fn, dim3(grid), dim3(256), slds, 0, sd, io); };
+  };
+  const double b2 = 16.0 * N, b3 = 24.0 * N;
+  auto mk_line = [&](int ax0) {
+    LineDesc L; memset(&L, 0, sizeof L);
+    long long stride[6]; { long long st = 1; for (int a = 5; a >= 0; --a) { stride[a] = st; st *= n; } }
+    L.lrest = stride[ax0 + 1]; L.nchunks = (int)(L.lrest / LINE_R); L.nouter = N / (n2 * L.lrest); L.ntiles = L.nouter * L.nchunks;
+    L.Qx = Q[2]; L.Qy = Q[3]; L.inv_theta = 1.0 / theta; L.beta = beta; L.theta = theta; L.cbt = pow(beta, theta);
+    const int a3s[6] = {1, (int)(n * n2), (int)n2, 0, n, 0};
+    L.a3x = a3s[ax0]; L.a3y = a3s[ax0 + 1];
+    std::vector<int> outv((size_t)L.nouter), restv((size_t)L.lrest);
+    for (long long o = 0; o < L.nouter; ++o) { long long r = o; int idx = 0; for (int c = ax0 - 1; c >= 0; --c) { idx += (int)(r % n) * a3s[c]; r /= n; } outv[(size_t)o] = idx; }
+    for (long long q = 0; q < L.lrest; ++q) { long long r = q; int idx = 0; for (int c = 5; c > ax0 + 1; --c) { idx += (int)(r % n) * a3s[c]; r /= n; } restv[(size_t)q] = idx; }
+    int *od, *rd; CK(hipMalloc(&od, outv.size() * 4)); CK(hipMalloc(&rd, restv.size() * 4));
+    CK(hipMemcpy(od, outv.data(), outv.size() * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(rd, restv.data(), restv.size() * 4, hipMemcpyHostToDevice));
+    L.a3 = a3; L.out_idx = od; L.rest_idx = rd;
+    return L;
+  };
+  const size_t llds = line_lds_bytes(n);
+  const int blk = line_block(n);
+  auto line_launch = [&](line_fn fn, const LineDesc& L, unsigned grid, const double* in, double* out, const double* old, bool res, int blk = 256) -> Launch {
+    hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)llds);
+    LineIO io; memset(&io, 0, sizeof io); io.in = in; io.out = out; io.old = old; io.resid = res ? resid : nullptr; io.sched = sched;
+    return [=]() { hipLaunchKernelGGL(fn, dim3(grid), dim3(blk), llds, 0, L, io); };
+  };
+  const int rounds = 7;
+  { int big = 1 << 20; CK(hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_it), &big, sizeof big)); }
+  if (n != 20) { printf("only n = 20 is wired up\n"); return 0; }
+  const LineDesc L2 = mk_line(0), L3 = mk_line(2);
+  const unsigned C = (unsigned)ncu;
+  // S = w^theta contracted over (e, f): the input of the later passes
+  slice_launch((slice_fn)slice_kernel<20, S_TFIRST, false>, sgrid0, w, tmpA)();
+  CK(hipDeviceSynchronize());
+  {
+    Launch base = slice_launch((slice_fn)slice_kernel<20, S_TFIRST, false>, sgrid0, w, outA);
+    add("slice_kernel<20,TFIRST> baseline", base, b2, nullptr, nullptr, nullptr);
+    for (unsigned wg : {3u * C, 11u * C / 4u / 8u * 8u, 10u * C / 4u, 2u * C})
+      add("slice_stream<20,TFIRST> wgs " + std::to_string(wg), slice_launch((slice_fn)slice_stream_kernel<20, S_TFIRST>, wg, w, outB), b2, outB, base, outA);
+    Launch basem = slice_launch((slice_fn)slice_kernel<20, S_MID, false>, sgrid0, w, outA);
+    add("slice_kernel<20,MID> baseline", basem, b2, nullptr, nullptr, nullptr);
+    for (unsigned wg : {3u * C, 2u * C})
+      add("slice_stream<20,MID> wgs " + std::to_string(wg), slice_launch((slice_fn)slice_stream_kernel<20, S_MID>, wg, w, outB), b2, outB, basem, outA);
+    run_all(rounds);
+  }
+  {
+    Launch base = line_launch((line_fn)line_kernel<20, L_MID, false, true, false>, L2, (unsigned)L2.ntiles, tmpA, outA, nullptr, false);
+    add("line_kernel<20,MID> pair (a,b) baseline", base, b2, nullptr, nullptr, nullptr);
+    for (unsigned wg : {3u * C, 2u * C})
+      add("line_stream<20,MID,3> pair (a,b) wgs " + std::to_string(wg), line_launch((line_fn)line_stream_kernel<20, L_MID, 3>, L2, wg, tmpA, outB, nullptr, false), b2, outB, base, outA);
+    Launch base3 = line_launch((line_fn)line_kernel<20, L_MID, false, true, false>, L3, (unsigned)L3.ntiles, tmpA, outA, nullptr, false);
+    add("line_kernel<20,MID> pair (c,d) baseline", base3, b2, nullptr, nullptr, nullptr);
+    for (unsigned wg : {3u * C, 2u * C})
+      add("line_stream<20,MID,3> pair (c,d) wgs " + std::to_string(wg), line_launch((line_fn)line_stream_kernel<20, L_MID, 3>, L3, wg, tmpA, outB, nullptr, false), b2, outB, base3, outA);
+    run_all(rounds);
+  }
+  {
+    // row spacing sweep: the same line kernels on synthetic geometries (400 rows per tile, spacing lrest doubles)
+    for (long long lr : {400LL, 1600LL, 8000LL, 32000LL, 160000LL}) {
+      LineDesc L = L2; L.lrest = lr; L.nchunks = (int)(lr / LINE_R); L.nouter = N / (n2 * lr); L.ntiles = L.nouter * L.nchunks;
+      add("line_kernel<20,MID> rows " + std::to_string(lr * 8) + " B apart", line_launch((line_fn)line_kernel<20, L_MID, false, true, false>, L, (unsigned)L.ntiles, tmpA, outA, nullptr, false), b2, nullptr, nullptr, nullptr);
+      add("line_stream<20,MID,3> rows " + std::to_string(lr * 8) + " B apart, wgs 768", line_launch((line_fn)line_stream_kernel<20, L_MID, 3>, L, 3 * C, tmpA, outB, nullptr, false), b2, nullptr, nullptr, nullptr);
+    }
+    run_all(rounds);
+  }
+  {
+    Launch base = line_launch((line_fn)line_kernel<20, L_TLAST, false, true, false>, L3, (unsigned)L3.ntiles, tmpA, outA, w, true);
+    add("line_kernel<20,TLAST> pair (c,d) baseline", base, b3, nullptr, nullptr, nullptr);
+    add("line_stream<20,TLAST,2> pair (c,d) wgs " + std::to_string(2 * C), line_launch((line_fn)line_stream_kernel<20, L_TLAST, 2>, L3, 2 * C, tmpA, outB, w, true), b3, outB, base, outA);
+    add("line_stream<20,TLAST,3,OLDPF,256,nonpersist> pair (c,d)", line_launch((line_fn)line_stream_kernel<20, L_TLAST, 3, true, 256, false>, L3, (unsigned)L3.ntiles, tmpA, outB, w, true), b3, outB, base, outA);
+    add("line_stream<20,TLAST,2,OLDPF,256,nonpersist> pair (c,d)", line_launch((line_fn)line_stream_kernel<20, L_TLAST, 2, true, 256, false>, L3, (unsigned)L3.ntiles, tmpA, outB, w, true), b3, outB, base, outA);
+    add("line_stream<20,TLAST,1,OLDPF,512,nonpersist> pair (c,d)", line_launch((line_fn)line_stream_kernel<20, L_TLAST, 1, true, 512, false>, L3, (unsigned)L3.ntiles, tmpA, outB, w, true, 512), b3, outB, base, outA);
+    add("line_stream<20,TLAST,2,OLDPF,512,nonpersist> pair (c,d)", line_launch((line_fn)line_stream_kernel<20, L_TLAST, 2, true, 512, false>, L3, (unsigned)L3.ntiles, tmpA, outB, w, true, 512), b3, outB, base, outA);
+    add("line_stream<20,TLAST,1,OLDPF,512thr> pair (c,d) wgs " + std::to_string(C), line_launch((line_fn)line_stream_kernel<20, L_TLAST, 1, true, 512>, L3, C, tmpA, outB, w, true, 512), b3, outB, base, outA);
+    add("line_stream<20,TLAST,1,512thr> pair (c,d) wgs " + std::to_string(C), line_launch((line_fn)line_stream_kernel<20, L_TLAST, 1, false, 512>, L3, C, tmpA, outB, w, true, 512), b3, outB, base, outA);
+    add("line_stream<20,TLAST,2,OLDPF> pair (c,d) wgs " + std::to_string(2 * C), line_launch((line_fn)line_stream_kernel<20, L_TLAST, 2, true>, L3, 2 * C, tmpA, outB, w, true), b3, outB, base, outA);
+    dump_stamps("line_stream<20,TLAST,2,OLDPF> wgs 512", line_launch((line_fn)line_stream_kernel<20, L_TLAST, 2, true>, L3, 2 * C, tmpA, outB, w, true));
+    dump_stamps("line_stream<20,TLAST,1,OLDPF,512thr> wgs 256", line_launch((line_fn)line_stream_kernel<20, L_TLAST, 1, true, 512>, L3, C, tmpA, outB, w, true, 512));
+    dump_stamps("line_stream<20,TLAST,2> wgs 512", line_launch((line_fn)line_stream_kernel<20, L_TLAST, 2>, L3, 2 * C, tmpA, outB, w, true));
+    dump_stamps("line_stream<20,MID,3> (c,d) wgs 512", line_launch((line_fn)line_stream_kernel<20, L_MID, 3>, L3, 2 * C, tmpA, outB, nullptr, false));
+    dump_stamps("line_stream<20,MID,3> (a,b) wgs 512", line_launch((line_fn)line_stream_kernel<20, L_MID, 3>, L2, 2 * C, tmpA, outB, nullptr, false));
+    add("line_kernel<20,TLAST> pair (c,d), no residual", line_launch((line_fn)line_kernel<20, L_TLAST, false, true, false>, L3, (unsigned)L3.ntiles, tmpA, outA, w, false), b2, nullptr, nullptr, nullptr);
+    run_all(rounds);
+  }
+  return 0;
+}
