@@ -12,10 +12,13 @@ Default workload: GCY (20,)*6 fp64 (BASELINE.json configs[3] grid; the grid the
 north_star roofline/CPU targets are quoted on), synthetic w = 400 + 500*U(0,1).
 
 Prints ONE JSON line (rank 0).  Extra objects:
-  roofline     dominant kernel: algorithmic bytes per launch / mean launch duration,
-               measured with HIP events on the library's stream inside the timed region
+  roofline     dominant kernel: algorithmic bytes per launch / mean launch duration, measured with HIP events on
+               the library's stream in a second loop of the same steps right behind the timed one (the timed loop
+               itself runs without the two hipEventRecord per launch); also the in-run rate of a
+               plain device copy of the same grid, so that the fraction of spec AND of this box's ceiling show
   cpu_baseline the oracle's C/OpenMP port of the same operator, timed on this box's cores
-  secondary    time-to-converge runs (SSY 15^4 SA / Newton) for context
+  secondary    time-to-converge runs, each GPU solve with its CPU twin (oracle solver through the C operator;
+               bounded sample + stated extrapolation where a full CPU solve would take minutes)
 """
 import argparse
 import json
@@ -64,6 +67,60 @@ def cpu_baseline(model, shapes, params, arrays, w_host, budget_s=12.0):
             "sample": f"{n} applications of T on the same {'x'.join(map(str, shapes))} grid "
                       f"(oracle/c/wc_oracle.c, factorised, OpenMP), {dt:.1f} s",
             "dram_GBps_of_its_own_sweeps": sweep_bytes * n / dt / 1e9}
+
+
+def cpu_time_to_converge(model, shapes, params, arrays, gpu_iters, gpu_applies, full, budget_s=10.0):
+    """The CPU twin of a Newton-Krylov time-to-converge entry: the oracle's newton_solver (oracle/solvers.py, which
+    follows code/solvers.py:51-95) through the C/OpenMP operator.  full = True runs the whole solve; otherwise a
+    bounded sample times T and J.v on the grid and the solve is EXTRAPOLATED with the application counts of the
+    GPU solve (one T + one residual per Newton step, two J.v per BiCGSTAB iteration; the C oracle's J.v
+    re-linearises at every call, as jax.jvp does in the reference)."""
+    from oracle.c_oracle import COperator, num_threads
+    from oracle import solvers as osol
+    op = COperator(model, shapes, params, arrays)
+    w0 = np.full(shapes, 800.0)
+    if full:
+        stats = {}
+        t0 = time.perf_counter()
+        x, n = osol.newton_solver(op, w0, tol=1e-8, bicgstab_tol=1e-6, bicgstab_atol=0.0, verbose=False, jvp=op.jvp, stats=stats)
+        t = time.perf_counter() - t0
+        return {"kind": "measured", "seconds": t, "iterations": n, "matvecs": stats.get("matvecs"), "cores": num_threads(),
+                "final_step": float(np.max(np.abs(op(x) - x)))}
+    w = 400 + 500 * np.random.default_rng(0).random(shapes)
+    v = np.random.default_rng(1).standard_normal(shapes)
+    op(w); op.jvp(w, v)
+    nT = nJ = 0
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < budget_s / 2 and nT < 20:
+        op(w); nT += 1
+    tT = (time.perf_counter() - t0) / nT
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < budget_s / 2 and nJ < 20:
+        op.jvp(w, v); nJ += 1
+    tJ = (time.perf_counter() - t0) / nJ
+    n_jv = max(gpu_applies - gpu_iters, 0)
+    return {"kind": "extrapolated", "seconds": gpu_iters * tT + n_jv * tJ, "cores": num_threads(),
+            "sample": f"{nT} T and {nJ} J.v applications timed ({tT:.3f} s, {tJ:.3f} s each); solve = {gpu_iters} T + "
+                      f"{n_jv} J.v, the counts of the GPU solve beside it"}
+
+
+def cpu_literal_apply():
+    """The reference's own formulation (8-D broadcast product summed over the next-state axes,
+    code/ssy/discrete/ssy_wc_ratio.py:143-145) restated in numpy (oracle/ssy.py: T_ssy), one application at SSY 10^4 --
+    where it still fits in memory (10^8 doubles per temporary); O(N^2), so it does not exist at the bench grid."""
+    from oracle import models, ssy
+    shp = (10,) * 4
+    p = models.ssy_params(); arr = ssy.discretize_ssy(p, shp)
+    w = 400 + 500 * np.random.default_rng(0).random(shp)
+    t0 = time.perf_counter()
+    ssy.T_ssy(w, shp, p, arr)
+    t_lit = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    for _ in range(20):
+        ssy.T_ssy_factorised(w, shp, p, arr)
+    t_fac = (time.perf_counter() - t0) / 20
+    return {"grid": "SSY 10x10x10x10", "literal_numpy_s_per_apply": t_lit, "factorised_numpy_s_per_apply": t_fac,
+            "note": "literal = the reference's O(N^2) broadcast formulation, single numpy thread pool"}
 
 
 def spawn_ranks(n, backend):
@@ -160,20 +217,38 @@ def main():
     for i in range(SPINUP):
         step(i)
     torch.cuda.synchronize()
-    op.set_profiling(True)       # HIP events around every launch, on the launch stream; switched on before
-    for i in range(args.warmup):  # the warm-up so that the event pool exists when the timed region starts
+    for i in range(args.warmup):
         step(i)
-    torch.cuda.synchronize()
-    op.reset_counters()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(args.warmup + i)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    last_resid = float(resid.item())
+    # per-kernel durations: the same steps once more with HIP events around every launch (on the launch stream)
+    op.set_profiling(True)
+    for i in range(8):            # (creates the event pool)
+        step(i)
+    torch.cuda.synchronize()
+    op.reset_counters()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    torch.cuda.synchronize()
+    dt_prof = time.perf_counter() - t0
     counters = op.counters()
     op.set_profiling(False)
-    last_resid = float(resid.item())
+    # this box's copy ceiling, in the same run: a plain device-to-device copy of the grid (read N + write N doubles)
+    torch.cuda.synchronize()
+    for _ in range(3):
+        bufs[1].copy_(bufs[0])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(20):
+        bufs[1].copy_(bufs[0])
+    torch.cuda.synchronize()
+    copy_gbs = 20 * 16.0 * N / (time.perf_counter() - t0) / 1e9
 
     dom = max(counters, key=lambda c: c["total_ms"])
     avg_ms = dom["total_ms"] / max(dom["launches"], 1)
@@ -184,7 +259,7 @@ def main():
     traffic, traffic_source = None, "no committed PMC profile of this workload"
     plan_now = op.describe_plan().strip().split("\n")
     try:
-        pfile = os.path.join("profiles", f"round2_{args.workload}_pmc.json")
+        pfile = os.path.join("profiles", f"round3_{args.workload}_pmc.json")
         pmc = json.load(open(os.path.join(ROOT, pfile)))
         if pmc.get("plan") != plan_now:
             traffic_source = f"{pfile} was taken on a different kernel plan: dropped"
@@ -213,7 +288,13 @@ def main():
         "roofline": {"bound": "hbm", "kernel": dom["name"], "achieved": achieved, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "traffic_source": traffic_source,
-                     "avg_launch_ms": avg_ms, "alg_bytes_per_launch": dom["alg_bytes"]},
+                     "avg_launch_ms": avg_ms, "alg_bytes_per_launch": dom["alg_bytes"],
+                     "events_from": f"a second loop of the same {args.steps} steps with HIP events around every launch "
+                                    f"({dt_prof / args.steps * 1e3:.4f} ms per step against {dt / args.steps * 1e3:.4f} without)",
+                     "copy_ceiling_GBps": copy_gbs, "frac_of_copy_ceiling": achieved / copy_gbs,
+                     "step_alg_bytes": sum(c["alg_bytes"] for c in counters),
+                     "step_frac": sum(c["alg_bytes"] for c in counters) / (dt / args.steps) / 1e9 / HBM_PEAK_GBS,
+                     "step_frac_of_copy_ceiling": sum(c["alg_bytes"] for c in counters) / (dt / args.steps) / 1e9 / copy_gbs},
         # secondary bound: an fp64 MFMA holds its SIMD for its full 64 / 20 cycles and every VALU
         # instruction of the same SIMD shares that issue slot, so a pass costs MFMA + VALU issue cycles; the
         # nominal fp64 peak is 78.6 TFLOP/s.  Algorithmic flops = contraction MACs x 2 plus the two powers of
@@ -241,6 +322,8 @@ def main():
             t = time.perf_counter() - t0
             sec["gcy20_newton_1e-8"] = {"iterations": n, "operator_applies": info["n_apply"], "seconds": t,
                                         "applies_per_s": info["n_apply"] / t, "final_err": info["final_err"]}
+            if not args.no_cpu:
+                sec["gcy20_newton_1e-8"]["cpu_twin"] = cpu_time_to_converge(model, shapes, params, arrays, n, info["n_apply"], full=False)
             # BASELINE config 5: the same solve with fp32 Krylov storage (fp64 arithmetic and outer residual)
             t0 = time.perf_counter()
             x, n, info = op.solve(w800, "newton", tol=1e-8, inner_rtol=1e-6, inner_atol=0.0, krylov_f32=1)
@@ -295,6 +378,10 @@ def main():
             sec[f"ssy15_{algo}"] = {"iterations": n, "operator_applies": info["n_apply"], "seconds": t,
                                     "iterations_per_s": n / t, "applies_per_s": info["n_apply"] / t,
                                     "final_err": info["final_err"]}
+            if algo == "newton" and not args.no_cpu:
+                sec["ssy15_newton"]["cpu_twin"] = cpu_time_to_converge("ssy", shp, m.params, S.discretize_ssy(m, shp), n, info["n_apply"], full=True)
+        if not args.no_cpu:
+            sec["cpu_literal_formulation"] = cpu_literal_apply()
         # continuous-state SSY at the reference's default size (10, 10, 10, 20; Gauss-Hermite d = 5)
         grids = S.build_grid(m, 10, 10, 10, 20)
         nodes, weights = S.qnwnorm([5] * 4)

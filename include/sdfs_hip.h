@@ -186,6 +186,14 @@ int64_t sdfs_error_trace(sdfs_handle* h, double* out, int64_t cap);
 int sdfs_apply_stage_dev(sdfs_handle* h, int stage, int mode, const double* in_dev,
                          double* out_dev, const double* w_old_dev, double* resid_dev);
 
+/* The same launch behind a device-side gate (multi-GPU successive approximation without a host read per iteration:
+ * sdfs_via_autodiff_amd/distributed.py; the loop it serves is code/solvers.py:34-36).  gate_dev points at a device
+ * double -- the all-reduced error of the previous iteration; if *gate_dev <= gate_tol (both non-negative) every
+ * kernel of the stage returns at once and `out_dev` keeps its contents, and resid_dev, if given, is left at 0, which
+ * keeps every later gate on it closed.  gate_dev == NULL: ungated. */
+int sdfs_apply_stage_gated_dev(sdfs_handle* h, int stage, int mode, const double* in_dev, double* out_dev,
+                               const double* w_old_dev, double* resid_dev, const double* gate_dev, double gate_tol);
+
 /* Exchange buffers of the re-shard between two stage calls (sdfs_via_autodiff_amd/distributed.py; the reference has no
  * multi-GPU path).  The grid is viewed as [outer][n_axis][inner] in C order; `packed` is the concatenation
  * over the nblocks blocks j (axis indices offs[j] .. offs[j+1], offs[0] = 0, offs[nblocks] = n_axis) of

@@ -12,6 +12,7 @@ LIB_PATH = os.path.join(_HERE, os.environ.get("SDFS_LIB_NAME", "libsdfs_hip.so")
 
 SDFS_MODEL_SSY, SDFS_MODEL_GCY = 0, 1
 SDFS_ALGO_SA, SDFS_ALGO_NEWTON, SDFS_ALGO_ANDERSON = 0, 1, 2
+SDFS_ERR_UNSUPPORTED = -3
 SDFS_ERR_NUMERIC = -4
 SDFS_MAX_KERNELS = 16
 
@@ -72,6 +73,7 @@ SYMBOLS = {
     "sdfs_solve_dev": (C.c_int, [_P, C.c_int, C.POINTER(sdfs_opts), _P, _I64, _I64, _D]),
     "sdfs_error_trace": (C.c_int64, [_P, _P, C.c_int64]),
     "sdfs_apply_stage_dev": (C.c_int, [_P, C.c_int, C.c_int, _P, _P, _P, _P]),
+    "sdfs_apply_stage_gated_dev": (C.c_int, [_P, C.c_int, C.c_int, _P, _P, _P, _P, _P, C.c_double]),
     "sdfs_pack_blocks": (C.c_int, [_P, C.c_int, _P, _P, C.c_int64, C.c_int64, C.c_int64, C.c_int, C.POINTER(C.c_int64), C.c_int]),
     "sdfs_krylov_step": (C.c_int, [_P, C.c_int, C.c_int64, C.c_int, C.POINTER(_P), _P, C.c_double, C.c_double]),
     "sdfs_krylov_scalars": (C.c_int, [_P, _P]),

@@ -2479,23 +2479,30 @@ int64_t sdfs_error_trace(sdfs_handle* h, double* out, int64_t cap) {
   return n;
 }
 
-int sdfs_apply_stage_dev(sdfs_handle* h, int stage, int mode, const double* in, double* out,
-                         const double* old, double* resid_dev) {
+int sdfs_apply_stage_gated_dev(sdfs_handle* h, int stage, int mode, const double* in, double* out,
+                               const double* old, double* resid_dev, const double* gate_dev, double gate_tol) {
   int rc = check(h); if (rc) return rc;
   if (!h->sharded) return fail(h, SDFS_ERR_ARG, "not a sharded handle");
   if (stage < 0 || stage > 1 || mode < 0 || mode > 2) return fail(h, SDFS_ERR_ARG, "bad stage/mode");
   if (!in || !out) return fail(h, SDFS_ERR_ARG, "NULL grid pointer");
+  // (a closed gate leaves the cleared word at zero, so every later gate on it stays closed)
   if (resid_dev && stage == 1) HIPCHK(h, hipMemsetAsync(resid_dev, 0, 8, h->stream));
   return run_plan(h, h->plan[stage], mode, stage == 0, stage == 1, in, out, old,
-                  stage == 1 ? (unsigned long long*)resid_dev : nullptr, nullptr, 0.0,
+                  stage == 1 ? (unsigned long long*)resid_dev : nullptr, (const unsigned long long*)gate_dev, gate_tol,
                   (mode == MODE_JVP && old) ? 1 : 0);
+}
+
+int sdfs_apply_stage_dev(sdfs_handle* h, int stage, int mode, const double* in, double* out,
+                         const double* old, double* resid_dev) {
+  return sdfs_apply_stage_gated_dev(h, stage, mode, in, out, old, resid_dev, nullptr, 0.0);
 }
 
 int sdfs_pack_blocks(sdfs_handle* h, int unpack, const void* src, void* dst, int64_t outer, int64_t n_axis, int64_t inner,
                      int nblocks, const int64_t* offs, int elem_bytes) {
   int rc = check(h); if (rc) return rc;
   if (!src || !dst || !offs) return fail(h, SDFS_ERR_ARG, "NULL argument");
-  if (nblocks < 1 || nblocks > PACK_MAX_BLOCKS) return fail(h, SDFS_ERR_ARG, "1..%d blocks", PACK_MAX_BLOCKS);
+  if (nblocks < 1) return fail(h, SDFS_ERR_ARG, "at least one block");
+  if (nblocks > PACK_MAX_BLOCKS) return fail(h, SDFS_ERR_UNSUPPORTED, "pack: at most %d blocks", PACK_MAX_BLOCKS);
   if (elem_bytes != 8 && elem_bytes != 4) return fail(h, SDFS_ERR_ARG, "elements of 4 or 8 bytes");
   if (outer < 1 || n_axis < 1 || inner < 1 || offs[0] != 0 || offs[nblocks] != n_axis) return fail(h, SDFS_ERR_ARG, "bad block table");
   PackBlocks B;

@@ -91,15 +91,22 @@ class HipStages:
         check(lib.sdfs_set_krylov_f32(self._h, int(on), float(w_ref)), self._h)
         self.f32 = bool(on)
 
-    def run(self, stage, mode, x, old=None, resid=None):
-        """resid: 1-element device tensor that receives max|out - old| (stage 1, T modes)."""
+    def run(self, stage, mode, x, old=None, resid=None, out=None, gate=None, gate_tol=0.0):
+        """resid: 1-element device tensor that receives max|out - old| (stage 1, T modes).  out: preallocated result
+        (contiguous, the stage's shape).  gate: 1-element device tensor; if its value is <= gate_tol the stage's kernels
+        return at once, `out` keeps its contents and `resid` stays 0 (sdfs_apply_stage_gated_dev)."""
         dt = torch.float32 if (getattr(self, "f32", False) and mode == MODE_JVP) else torch.float64
         if x.dtype != dt:
             raise TypeError(f"stage input is {x.dtype}, expected {dt}")
-        out = torch.empty(self.shape0 if stage == 0 else self.shape1, dtype=dt, device=self.device)
-        check(lib.sdfs_apply_stage_dev(self._h, stage, mode, x.data_ptr(), out.data_ptr(),
-                                       old.data_ptr() if old is not None else None,
-                                       resid.data_ptr() if resid is not None else None), self._h)
+        shp = self.shape0 if stage == 0 else self.shape1
+        if out is None:
+            out = torch.empty(shp, dtype=dt, device=self.device)
+        elif out.dtype != dt or list(out.shape) != list(shp) or not out.is_contiguous():
+            raise ValueError("stage output buffer has the wrong dtype / shape")
+        check(lib.sdfs_apply_stage_gated_dev(self._h, stage, mode, x.data_ptr(), out.data_ptr(),
+                                             old.data_ptr() if old is not None else None,
+                                             resid.data_ptr() if resid is not None else None,
+                                             gate.data_ptr() if gate is not None else None, float(gate_tol)), self._h)
         return out
 
     def pack_blocks(self, grid, packed, axis, offs, unpack=False):
@@ -110,8 +117,12 @@ class HipStages:
         inner = int(np.prod(shp[axis + 1:], dtype=np.int64)) if axis + 1 < len(shp) else 1
         o = (C.c_int64 * len(offs))(*[int(v) for v in offs])
         src, dst = (packed, grid) if unpack else (grid, packed)
-        check(lib.sdfs_pack_blocks(self._h, int(unpack), src.data_ptr(), dst.data_ptr(), outer, shp[axis], inner,
-                                   len(offs) - 1, o, grid.element_size()), self._h)
+        rc = lib.sdfs_pack_blocks(self._h, int(unpack), src.data_ptr(), dst.data_ptr(), outer, shp[axis], inner,
+                                  len(offs) - 1, o, grid.element_size())
+        if rc == _lib.SDFS_ERR_UNSUPPORTED:
+            return False                      # more blocks / bigger units than the kernel takes: the caller copies per peer
+        check(rc, self._h)
+        return True
 
     def describe_plan(self):
         buf = C.create_string_buffer(4096)
@@ -166,6 +177,7 @@ class ShardedKoopmans:
         self.local_shape = tuple(self.local_shape)
         self._use_a2a = dist.get_backend(group) == "nccl"
         self.n_exchanges = 0
+        self._bufs = {}              # exchange / stage buffers, allocated once per (role, shape, dtype)
         # mirror orientation: input sharded on B, stage 0 contracts every axis but B, stage 1 contracts B and
         # leaves the result sharded on A.  Needs A's own tensor to be unconditional (true for Rouwenhorst /
         # Tauchen tensors, whose slices are identical); otherwise only the fixed-layout form is available.
@@ -212,23 +224,42 @@ class ShardedKoopmans:
             if host:
                 parts[src].copy_(buf)
 
-    def _reshard(self, x, src_axis, src_sizes, src_off, dst_axis, dst_sizes, dst_off):
+    def buf(self, role, shape, dtype, device):
+        """A buffer that lives as long as the operator: one per (role, shape, dtype).  Two alternating roles
+        ("x0" / "x1") give a result that stays valid across the next call of the same kind."""
+        key = (role, tuple(int(v) for v in shape), dtype, str(device))
+        b = self._bufs.get(key)
+        if b is None:
+            b = self._bufs[key] = torch.empty(key[1], dtype=dtype, device=device)
+        return b
+
+    def _flip(self, role):
+        n = self._bufs.get(("flip", role), 0) ^ 1
+        self._bufs[("flip", role)] = n
+        return f"{role}{n}"
+
+    def _reshard(self, x, src_axis, src_sizes, src_off, dst_axis, dst_sizes, dst_off, out=None):
         """x is sharded on src_axis (this rank's block) with dst_axis full; return the grid sharded
         on dst_axis with src_axis full.  Rank r receives block (all src, its dst block).
         Blocks along axis 0 are contiguous slabs: they are sent / received in place, the other
-        side goes through one packed copy."""
+        side goes through one packed copy.  Result and pack buffers are allocated once (`out`, or two
+        alternating buffers per direction: the result stays valid across the next re-shard of the same kind)."""
         r = self.rank
         shp = list(x.shape)
         shp[src_axis] = sum(src_sizes)
         shp[dst_axis] = dst_sizes[r]
-        out = torch.empty(shp, dtype=x.dtype, device=x.device)
+        if out is None:
+            out = self.buf(self._flip(f"reshard{src_axis}"), shp, x.dtype, x.device)
         # device grids: one pack / unpack launch for the whole shard (sdfs_pack_blocks) instead of a strided copy per peer
-        fused = x.is_cuda and x.is_contiguous() and hasattr(self.backend, "pack_blocks") and self.world <= 16
+        fused = x.is_cuda and x.is_contiguous() and hasattr(self.backend, "pack_blocks")
         send = [x.narrow(dst_axis, dst_off[j], dst_sizes[j]) for j in range(self.world)]
         if dst_axis != 0:
+            packed = None
             if fused:
-                packed = torch.empty(x.numel(), dtype=x.dtype, device=x.device)
-                self.backend.pack_blocks(x, packed, dst_axis, list(dst_off) + [x.shape[dst_axis]])
+                packed = self.buf("packed", (x.numel(),), x.dtype, x.device)
+                if not self.backend.pack_blocks(x, packed, dst_axis, list(dst_off) + [x.shape[dst_axis]]):
+                    fused, packed = False, None
+            if packed is not None:
                 send = [p.view(t.shape) for p, t in zip(torch.split(packed, [t.numel() for t in send]), send)]
             else:
                 send = [t.contiguous() for t in send]                  # pack
@@ -237,7 +268,7 @@ class ShardedKoopmans:
         if src_axis == 0:
             recv = slots
         elif fused:
-            rflat = torch.empty(out.numel(), dtype=x.dtype, device=x.device)
+            rflat = self.buf("rflat", (out.numel(),), x.dtype, x.device)
             recv = [p.view(t.shape) for p, t in zip(torch.split(rflat, [t.numel() for t in slots]), slots)]
         else:
             recv = [torch.empty(t.shape, dtype=x.dtype, device=x.device) for t in slots]
@@ -262,61 +293,76 @@ class ShardedKoopmans:
                 for t, h_ in zip(recv, hr):
                     t.copy_(h_)
         if src_axis != 0:
-            if rflat is not None:
-                self.backend.pack_blocks(out, rflat, src_axis, list(src_off) + [out.shape[src_axis]], unpack=True)
+            if rflat is not None and self.backend.pack_blocks(out, rflat, src_axis, list(src_off) + [out.shape[src_axis]], unpack=True):
+                pass
             else:
                 for slot, t in zip(slots, recv):                           # unpack
                     slot.copy_(t)
         self.n_exchanges += 1
         return out
 
-    def a_to_b(self, x):
-        return self._reshard(x, self.axis_a, self.a_sizes, self.a_off, self.axis_b, self.b_sizes, self.b_off)
+    def a_to_b(self, x, out=None):
+        return self._reshard(x, self.axis_a, self.a_sizes, self.a_off, self.axis_b, self.b_sizes, self.b_off, out=out)
 
-    def b_to_a(self, x):
-        return self._reshard(x, self.axis_b, self.b_sizes, self.b_off, self.axis_a, self.a_sizes, self.a_off)
+    def b_to_a(self, x, out=None):
+        return self._reshard(x, self.axis_b, self.b_sizes, self.b_off, self.axis_a, self.a_sizes, self.a_off, out=out)
 
     @property
     def mirror_ok(self):
         return self.backend_m is not None
 
-    def apply_mirror(self, w, orient, old=None):
+    def _stage(self, be, stage, mode, x, role, **kw):
+        """A stage launch into an operator-owned buffer (two alternate per role and shape)."""
+        shp = be.shape0 if stage == 0 else be.shape1
+        dt = torch.float32 if (getattr(be, "f32", False) and mode == MODE_JVP) else x.dtype
+        return be.run(stage, mode, x, out=self.buf(self._flip(role), shp, dt, x.device), **kw)
+
+    def apply_mirror(self, w, orient, old=None, out=None, res=None, gate=None, gate_tol=0.0):
         """One application with ONE exchange.  orient 0: w sharded on A -> result sharded on B; orient 1 the
         other way round.  `old`: an iterate in the OUTPUT layout (the one from two applications back); if given,
-        max|result - old| is fused into stage 1 and all-reduced.  Returns (result, residual tensor or None)."""
+        max|result - old| is fused into stage 1 and all-reduced (into `res`, a 1-element device tensor, if given).
+        `gate`: 1-element device tensor; while its value is <= gate_tol the stage kernels are no-ops and `out`
+        keeps its contents (the exchange still runs, on stale buffers).  Returns (result, residual tensor or None)."""
         be = self.backend if orient == 0 else self.backend_m
-        y = be.run(0, MODE_T, w)
+        y = self._stage(be, 0, MODE_T, w, f"m{orient}s0", gate=gate, gate_tol=gate_tol)
         z = self.a_to_b(y) if orient == 0 else self.b_to_a(y)
+        kw = dict(gate=gate, gate_tol=gate_tol)
+        if out is not None:
+            kw["out"] = out
         if old is None:
-            return be.run(1, MODE_T, z), None
-        res = torch.zeros(1, dtype=torch.float64, device=w.device)
-        t = be.run(1, MODE_T, z, old=old, resid=res)
+            return (be.run(1, MODE_T, z, **kw) if out is not None else self._stage(be, 1, MODE_T, z, f"m{orient}s1", **kw)), None
+        if res is None:
+            res = torch.zeros(1, dtype=torch.float64, device=w.device)
+        t = be.run(1, MODE_T, z, old=old, resid=res, **kw) if out is not None else \
+            self._stage(be, 1, MODE_T, z, f"m{orient}s1", old=old, resid=res, **kw)
         self.allreduce_max(res)
         return t, res
 
     # -- operator -------------------------------------------------------------------
     def _apply(self, mode, x):
-        y = self.backend.run(0, mode, x)
+        y = self._stage(self.backend, 0, mode, x, "s0")
         z = self.a_to_b(y)
-        t = self.backend.run(1, mode, z)
+        t = self._stage(self.backend, 1, mode, z, "s1")
         return self.b_to_a(t)
 
     def apply_T(self, w_loc):
         return self._apply(MODE_T, w_loc)
 
-    def apply_T_resid(self, w_loc, w_b=None):
+    def apply_T_resid(self, w_loc, w_b=None, res=None, gate=None, gate_tol=0.0, out=None):
         """T(w) plus the sup-norm step max|T(w) - w| (all-reduced).  The difference is taken in
         the B-sharded layout inside stage 1's last kernel against ``w_b`` = w re-sharded on B, which
         is simply the stage-1 output of the previous application (returned as the third value), so
-        the residual costs no extra exchange after the first iteration."""
+        the residual costs no extra exchange after the first iteration.  res / gate: as in apply_mirror (a closed
+        gate turns the stage kernels into no-ops; the exchanges then move the previous, identical, data)."""
         if w_b is None:
             w_b = self.a_to_b(w_loc)
-        y = self.backend.run(0, MODE_T, w_loc)
+        y = self._stage(self.backend, 0, MODE_T, w_loc, "s0", gate=gate, gate_tol=gate_tol)
         z = self.a_to_b(y)
-        res = torch.zeros(1, dtype=torch.float64, device=w_loc.device)
-        t_b = self.backend.run(1, MODE_T, z, old=w_b, resid=res)
+        if res is None:
+            res = torch.zeros(1, dtype=torch.float64, device=w_loc.device)
+        t_b = self._stage(self.backend, 1, MODE_T, z, "s1", old=w_b, resid=res, gate=gate, gate_tol=gate_tol)
         self.allreduce_max(res)
-        return self.b_to_a(t_b), res, t_b
+        return self.b_to_a(t_b, out=out), res, t_b
 
     def linearize(self, w_loc):
         """T(w) with the two diagonal scalings of dT(w) cached on every rank."""
@@ -362,40 +408,189 @@ class ShardedKoopmans:
 SCREEN = 2.5
 
 
-def successive_approx_sharded(op, w_loc, tol=1e-7, max_iter=1000000, errors=None, mirror=True, stats=None):
+def _first_at_most(vals, thr):
+    """index of the first value that is <= thr or not finite (NaN maps to inf in the kernels), else None"""
+    for j, v in enumerate(vals):
+        if not (v > thr) or not np.isfinite(v):
+            return j
+    return None
+
+
+def successive_approx_sharded(op, w_loc, tol=1e-7, max_iter=1000000, errors=None, mirror=True, stats=None, check_every=16):
     """Successive approximation on a sharded grid, the reference's stopping rule (code/solvers.py:34-36).
 
-    Mirror phase (one exchange per iteration): the two-step difference is the screen (see SCREEN: exact
-    stopping iteration for every map whose errors shrink by less than a factor 1.5 per iteration -- the
-    contraction modulus here is 0.9988; a faster map may run a few iterations past the reference's stop).
-    Exact phase (two exchanges): the reference's loop verbatim.  `errors` receives the one-step error where it was
-    computed and the two-step screen (as a negative number) elsewhere."""
-    it, err = 0, tol + 1
-    if mirror and op.mirror_ok:
-        orient, prev, two = 0, None, None
-        w = w_loc
-        while it < max_iter:
-            w_next, res = op.apply_mirror(w, orient, old=prev)
-            it += 1
-            two = float(res.item()) if res is not None else None
-            if errors is not None:
-                errors.append(-two if two is not None else float("nan"))
-            prev, w, orient = w, w_next, 1 - orient
-            if two is not None and not (two > SCREEN * tol):       # also leaves on NaN / inf
-                break
+    Mirror phase (one exchange per iteration): the two-step difference max|w_(k+1) - w_(k-1)| is the screen (see
+    SCREEN: exact stopping iteration for every map whose errors shrink by less than a factor 1.5 per iteration --
+    the contraction modulus here is 0.9988; a faster map may run a few iterations past the reference's stop).
+    Exact phase (two exchanges): the reference's loop verbatim.
+
+    The loop never reads a scalar per iteration: iteration k leaves its all-reduced error in slot k of a device
+    ring, the stage kernels of iteration k+1 are gated on that slot (sdfs_apply_stage_gated_dev: once it is at or
+    below the threshold they are no-ops and the iterate buffers keep their contents), and the host reads the ring
+    every `check_every` iterations -- as the single-GPU loop does (csrc/sdfs_api.hip, solve_sa).  Iterates live in
+    buffers allocated once.  `errors` receives the one-step error where it was computed and the two-step screen (as
+    a negative number) elsewhere; stats: mirror_iters, host_syncs."""
+    dev = w_loc.device
+    check_every = max(int(check_every), 1)
+    host_syncs = 0
+    slots = torch.zeros(check_every + 1, dtype=torch.float64, device=dev)
+    inf = float("inf")
+    it = 0
+    diverged = False
+    if mirror and op.mirror_ok and max_iter > 0:
+        thr = SCREEN * tol
+        shape_b = list(op.shapes); shape_b[op.axis_b] = op.b_sizes[op.rank]
+        # w_(2m) lives in A[m & 1] (sharded on A), w_(2m+1) in B[m & 1] (sharded on B)
+        A = [w_loc.contiguous().clone(), torch.empty_like(w_loc)]
+        B = [torch.empty(shape_b, dtype=w_loc.dtype, device=dev) for _ in range(2)]
+        done = False
+        slots[0] = inf                        # the first gate is open
+        while it < max_iter and not done:
+            n = min(check_every, max_iter - it)
+            for j in range(n):
+                k = it + j
+                if k & 1 == 0:
+                    src, dst, old = A[(k >> 1) & 1], B[(k >> 1) & 1], (B[((k >> 1) - 1) & 1] if k >= 2 else None)
+                else:
+                    src, dst, old = B[(k >> 1) & 1], A[((k + 1) >> 1) & 1], A[(k >> 1) & 1]
+                gate = slots[j:j + 1]            # the previous iteration's screen (slot 0: the chunk before, or open)
+                res = slots[j + 1:j + 2]
+                if old is None:
+                    res.fill_(inf)               # iteration 0 has nothing to compare with: its slot stays open
+                    op.apply_mirror(src, k & 1, out=dst, gate=gate, gate_tol=thr)
+                else:
+                    op.apply_mirror(src, k & 1, old=old, out=dst, res=res, gate=gate, gate_tol=thr)
+            vals = slots[1:n + 1].tolist()       # the one host read of the chunk
+            host_syncs += 1
+            first = 0 if it > 0 else 1           # iteration 0's slot is the open sentinel
+            j = _first_at_most(vals[first:], thr)
+            if j is not None:
+                j += first
+                if errors is not None:
+                    errors.extend(-v for v in vals[:j + 1])
+                it += j + 1
+                done = True
+                diverged = not np.isfinite(vals[j])
+            else:
+                if errors is not None:
+                    errors.extend(-v for v in vals)
+                it += n
+                slots[0:1].copy_(slots[n:n + 1])                  # gate of the next chunk's first iteration
         if stats is not None:
             stats["mirror_iters"] = it
-        w_loc = w if orient == 0 else op.b_to_a(w)                   # back to the A-sharded layout
-        if two is not None and not np.isfinite(two):
+        w = A[(it >> 1) & 1] if it & 1 == 0 else B[(it >> 1) & 1]     # w_it
+        w_loc = w if it & 1 == 0 else op.b_to_a(w)                   # back to the A-sharded layout
+        if diverged:
+            if stats is not None:
+                stats["host_syncs"] = host_syncs
             return w_loc, it
+    # exact phase: fixed layout, one-step error, the same ring and gate
+    W = [w_loc.contiguous(), torch.empty_like(w_loc)]
+    cur = 0
     w_b = None
+    err = tol + 1
+    slots[0] = inf
     while err > tol and it < max_iter:
-        w_loc, res, w_b = op.apply_T_resid(w_loc, w_b)
-        err = float(res.item())
+        n = min(check_every, max_iter - it)
+        for j in range(n):
+            gate = slots[j:j + 1]
+            res = slots[j + 1:j + 2]
+            if w_b is None:
+                w_b = op.a_to_b(W[cur])
+            # (a closed gate re-delivers the previous application's result: the same data lands in W[cur ^ 1])
+            _, _, w_b = op.apply_T_resid(W[cur], w_b, res=res, gate=gate, gate_tol=tol, out=W[cur ^ 1])
+            cur ^= 1
+        vals = slots[1:n + 1].tolist()
+        host_syncs += 1
+        j = _first_at_most(vals, tol)
+        if j is not None:
+            if errors is not None:
+                errors.extend(vals[:j + 1])
+            it += j + 1
+            err = vals[j]
+            # iterations j+1 .. n-1 of the chunk were no-ops that flipped `cur`: w_(it) sits where iteration j wrote it
+            if (n - 1 - j) & 1:
+                cur ^= 1
+            break
         if errors is not None:
-            errors.append(err)
+            errors.extend(vals)
+        it += n
+        err = vals[-1]
+        slots[0:1].copy_(slots[n:n + 1])
+    if stats is not None:
+        stats["host_syncs"] = host_syncs
+    return W[cur], it
+
+
+def anderson_sharded(op, w_loc, tol=1e-7, max_iter=10000, history_size=10, mixing_frequency=4, beta=8.0, ridge=1e-6,
+                     errors=None, stats=None):
+    """Anderson acceleration (code/solvers.py:98-124: jaxopt.AndersonAcceleration with m = 10, mixing every 4th
+    iteration, beta = 8, ridge 1e-6; semantics restated in oracle/solvers.py, iterate parity UNPINNED) on a sharded
+    grid, fixed layout.  Per iteration: one sharded application of T (two exchanges), the history write, and ONE
+    all-reduce (SUM) of m + 1 doubles -- the new Gram row <r_pos, r_j> with |r|^2 as its last entry.  The
+    (m+1)^2 system is solved redundantly on every rank from the all-reduced Gram matrix (identical inputs, identical
+    result), the extrapolation is local.  A mixing step that leaves the domain (w <= 0 or not finite; at large grids
+    N r^2 dwarfs the absolute ridge) is rejected as in the single-GPU loop: plain step, history restarted.
+    Returns (w_loc, n_iter); the error is the reference's: the Euclidean norm of T(w) - w."""
+    m = int(history_size)
+    dev = w_loc.device
+    n = w_loc.numel()
+    X = torch.zeros((m, n), dtype=torch.float64, device=dev)
+    R = torch.zeros((m, n), dtype=torch.float64, device=dev)
+    G = np.zeros((m, m))
+    x = w_loc.contiguous().clone()
+    it, error, filled, pause = 0, float("inf"), 0, 0
+    n_rejected = 0
+    while error > tol and it < max_iter:
+        fx = op.apply_T(x)
+        pos = it % m
+        r = R[pos]
+        torch.sub(fx.reshape(-1), x.reshape(-1), out=r)
+        X[pos].copy_(x.reshape(-1))
+        row = torch.empty(m + 1, dtype=torch.float64, device=dev)
+        torch.mv(R, r, out=row[:m])                     # <r_j, r_pos> for every slot (stale slots are zero rows)
+        row[m] = row[pos]
+        op.allreduce_sum(row)
+        rowh = row.tolist()                               # the one host read of the iteration
+        G[pos, :] = rowh[:m]
+        G[:, pos] = rowh[:m]
+        error = float(np.sqrt(rowh[m])) if rowh[m] == rowh[m] else float("inf")
+        if errors is not None:
+            errors.append(error)
+        filled = min(filled + 1, m)
+        mixed = False
+        if pause > 0:
+            pause -= 1
+        elif it + 1 >= m and (it + 1) % mixing_frequency == 0 and filled == m and np.isfinite(error):
+            Hm = np.zeros((m + 1, m + 1))
+            Hm[0, 1:] = 1.0
+            Hm[1:, 0] = 1.0
+            Hm[1:, 1:] = G + ridge * np.eye(m)
+            rhs = np.zeros(m + 1)
+            rhs[0] = 1.0
+            try:
+                alphas = np.linalg.solve(Hm, rhs)[1:]
+            except np.linalg.LinAlgError:
+                alphas = None
+            if alphas is not None and np.all(np.isfinite(alphas)):
+                a = torch.from_numpy(alphas).to(dev)
+                cand = torch.mv(X.t(), a).add_(torch.mv(R.t(), a), alpha=beta)
+                # reject a step that leaves the domain (every rank must agree: all-reduced flag)
+                bad = torch.stack([(~torch.isfinite(cand)).any() | (cand <= 0).any()]).to(torch.float64)
+                op.allreduce_max(bad)
+                if float(bad.item()) == 0.0:
+                    x = cand.reshape(x.shape)
+                    mixed = True
+                else:
+                    n_rejected += 1
+                    R.zero_(); X.zero_(); G[:] = 0.0
+                    filled, pause = 0, m
+        if not mixed:
+            x = fx.clone()
         it += 1
-    return w_loc, it
+    if stats is not None:
+        stats["rejected_mixes"] = n_rejected
+    return x, it
 
 
 KS_INIT, KS_INIT_FIN, KS_UPDATE_P, KS_DOT_RQ, KS_ALPHA_S, KS_S_FIN, KS_DOT_TS, KS_OMEGA_XR, KS_ITER_FIN, KS_SUB_DOT, \
@@ -592,19 +787,47 @@ def bench_sharded(S, model, shapes, params, arrays, args, rank, local_rank, worl
     w_full = torch.from_numpy(400 + 500 * np.random.default_rng(0).random(shapes))
     w = op.scatter_from_full(w_full).cuda()
     del w_full
-    state = {"w_b": None, "res": None, "prev": None, "orient": 0}
     mirror = op.mirror_ok and os.environ.get("SDFS_BENCH_MIRROR", "1") != "0"
+    # every rank reports itself: the line carries what actually ran, and a short count fails the run
+    me = torch.tensor([rank, local_rank, torch.cuda.current_device()], dtype=torch.int64, device="cuda")
+    seen = [torch.zeros_like(me) for _ in range(world)]
+    if dist.get_backend() == "nccl":
+        dist.all_gather(seen, me)
+    else:
+        hs = [torch.zeros(3, dtype=torch.int64) for _ in range(world)]
+        dist.all_gather(hs, me.cpu())
+        seen = hs
+    ranks_seen = sorted(int(t[0]) for t in seen)
+    if ranks_seen != list(range(world)) or dist.get_world_size() != world:
+        raise SystemExit(f"bench.py: {world} ranks requested, the process group reports {ranks_seen}")
+    devices = [int(t[2]) for t in sorted(seen, key=lambda t: int(t[0]))]
+    # iterates in buffers allocated once (as successive_approx_sharded keeps them); the all-reduced error stays on
+    # the device, nothing is read back inside the timed region
+    res = torch.zeros(1, dtype=torch.float64, device="cuda")
+    shape_b = list(op.shapes); shape_b[op.axis_b] = op.b_sizes[op.rank]
+    A = [w.contiguous(), torch.empty_like(w)]
+    B = [torch.empty(shape_b, dtype=w.dtype, device="cuda") for _ in range(2)]
+    state = {"k": 0, "w_b": None, "cur": 0, "have_res": False}
 
-    def step(w):
+    def step(_w):
+        k = state["k"]
         if mirror:
             # one exchange per iteration; residual = two-step difference, fused into stage 1 and all-reduced
-            w_new, res = op.apply_mirror(w, state["orient"], old=state["prev"])
-            state["prev"], state["orient"] = w, 1 - state["orient"]
-            if res is not None:
-                state["res"] = res
-            return w_new
-        w_new, state["res"], state["w_b"] = op.apply_T_resid(w, state["w_b"])
-        return w_new
+            if k & 1 == 0:
+                src, dst, old = A[(k >> 1) & 1], B[(k >> 1) & 1], (B[((k >> 1) - 1) & 1] if k >= 2 else None)
+            else:
+                src, dst, old = B[(k >> 1) & 1], A[((k + 1) >> 1) & 1], A[(k >> 1) & 1]
+            op.apply_mirror(src, k & 1, old=old, out=dst, res=res if old is not None else None)
+            state["have_res"] = state["have_res"] or old is not None
+        else:
+            cur = state["cur"]
+            if state["w_b"] is None:
+                state["w_b"] = op.a_to_b(A[cur])
+            _, _, state["w_b"] = op.apply_T_resid(A[cur], state["w_b"], res=res, out=A[cur ^ 1])
+            state["cur"] = cur ^ 1
+            state["have_res"] = True
+        state["k"] = k + 1
+        return _w
 
     op.backend.set_profiling(True)
     for _ in range(max(args.warmup, 2)):
@@ -641,7 +864,9 @@ def bench_sharded(S, model, shapes, params, arrays, args, rank, local_rank, worl
                                                     f"{'mirror schedule' if mirror else 'fixed layout'}), "
                                                     f"{(op.n_exchanges - x0) / max(args.steps, 1):.2f} all-to-all re-shards + 1 all-reduce "
                                                     f"per iteration, backend {dist.get_backend()}",
-                   "ranks": world,
+                   "ranks": world, "ranks_seen": ranks_seen, "backend": dist.get_backend(), "devices_by_rank": devices,
+                   "measured_on": "RCCL over xGMI" if dist.get_backend() == "nccl" and len(set(devices)) == world
+                                  else "REHEARSAL (not a multi-GPU measurement): ranks share a device or exchange through the host",
                    "shard_sizes": op.a_sizes,
                    "plan_rank0": op.backend.describe_plan().strip().split("\n")},
         "roofline": {"bound": "hbm", "kernel": dom["name"], "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
@@ -651,6 +876,6 @@ def bench_sharded(S, model, shapes, params, arrays, args, rank, local_rank, worl
         "exchange": {"per_iteration": (op.n_exchanges - x0) / max(args.steps, 1),
                      "bytes_sent_per_rank_per_exchange": 8.0 * N / world * (world - 1) / world,
                      "bytes_per_peer_link_per_exchange": 8.0 * N / world / world},
-        "last_residual": float(state["res"].item()) if state["res"] is not None else None,
+        "last_residual": float(res.item()) if state["have_res"] else None,
         "residual_kind": "two-step max|w_(k+1) - w_(k-1)| (mirror schedule)" if mirror else "one-step max|w_(k+1) - w_k|",
     }

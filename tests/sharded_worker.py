@@ -34,6 +34,8 @@ class OracleStages:
         self.order = [int(g) for g in meta.order]
         self.A, self.B = axis_a, axis_b
         self.a_sl, self.b_sl = slice(a_lo, a_lo + a_len), slice(b_lo, b_lo + b_len)
+        self.shape0 = list(self.shapes); self.shape0[axis_a] = a_len
+        self.shape1 = list(self.shapes); self.shape1[axis_b] = b_len
         # dense per-point tables on the full grid, sliced per stage (tiny test grids only)
         idx = np.indices(self.shapes)
         self.a1_full = meta.a1.ravel()[sum(idx[a] * meta.a1s[a] for a in range(self.D))]
@@ -50,7 +52,20 @@ class OracleStages:
         sub_q = "".join(LETTERS[c] for c in cond) + LETTERS[g] + "Z"
         return np.einsum(f"{sub_q},{sub_x}->{LETTERS[:self.D]}", q, x)
 
-    def run(self, stage, mode, x, old=None, resid=None):
+    def run(self, stage, mode, x, old=None, resid=None, out=None, gate=None, gate_tol=0.0):
+        if gate is not None and not (float(gate[0]) > gate_tol):
+            # closed gate (sdfs_apply_stage_gated_dev): nothing is written, the residual word stays 0
+            if resid is not None:
+                resid[0] = 0.0
+            assert out is not None
+            return out
+        res = self._run(stage, mode, x, old, resid)
+        if out is not None:
+            out.copy_(res)
+            return out
+        return res
+
+    def _run(self, stage, mode, x, old=None, resid=None):
         x = x.numpy()
         sl0 = [slice(None)] * self.D; sl0[self.A] = self.a_sl
         sl1 = [slice(None)] * self.D; sl1[self.B] = self.b_sl
@@ -154,13 +169,32 @@ def body(rank, model, shapes, use_hip, plain=False):
         errs, stats = [], {}
         x0 = op.n_exchanges
         sa_tol, sa_max = (2e-2, 4000) if plain else (1e-3, 120)
+        ce = 7
         xa_loc, na = D.successive_approx_sharded(op, op.scatter_from_full(torch.full(shapes, 800.0, dtype=torch.float64)).to(dev),
-                                                 tol=sa_tol, max_iter=sa_max, errors=errs, stats=stats)
+                                                 tol=sa_tol, max_iter=sa_max, errors=errs, stats=stats, check_every=ce)
         out["sa_exchanges"] = op.n_exchanges - x0
         out["sa_mirror_iters"] = stats.get("mirror_iters", 0)
+        out["sa_host_syncs"] = stats.get("host_syncs", -1)
+        out["sa_check_every"] = ce
+        out["sa_n_errors"] = len(errs)
         xo, no = osol.successive_approx(T, np.full(shapes, 800.0), tol=sa_tol, max_iter=sa_max, verbose=False)
         out["sa_iters"] = (na, no)
         out["sa_err"] = float(np.max(np.abs(op.gather_full(xa_loc).cpu().numpy() - xo)))
+        # one-iteration-per-read form of the same loop: identical iterates and iteration count
+        xb_loc, nb = D.successive_approx_sharded(op, op.scatter_from_full(torch.full(shapes, 800.0, dtype=torch.float64)).to(dev),
+                                                 tol=sa_tol, max_iter=sa_max, check_every=1)
+        out["sa_check1"] = (nb, float(np.max(np.abs(op.gather_full(xb_loc).cpu().numpy() - op.gather_full(xa_loc).cpu().numpy()))))
+        # Anderson on the sharded grid against the single-process oracle loop (jaxopt semantics restated, unpinned):
+        # same iteration count and iterate on these small, well-conditioned histories
+        a_tol = 1e-6
+        st = {}
+        xa2, n_and = D.anderson_sharded(op, op.scatter_from_full(torch.full(shapes, 800.0, dtype=torch.float64)).to(dev),
+                                        tol=a_tol, max_iter=3000, stats=st)
+        xo2, n_ando = osol.anderson_solver(T, np.full(shapes, 800.0), tol=a_tol, max_iter=3000, verbose=False)
+        out["anderson_iters"] = (n_and, n_ando)
+        out["anderson_err"] = float(np.max(np.abs(op.gather_full(xa2).cpu().numpy() - xo2)))
+        out["anderson_resid"] = float(np.max(np.abs(T(op.gather_full(xa2).cpu().numpy()) - op.gather_full(xa2).cpu().numpy())))
+        out["anderson_rejected"] = st.get("rejected_mixes", -1)
         return out
 
 

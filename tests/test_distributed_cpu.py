@@ -47,6 +47,19 @@ def test_sharded_operator_world2_gloo(model, shapes):
     assert sum(a_sizes) == shapes[0] and max(a_sizes) - min(a_sizes) <= 1
     assert out["newton_err"] < 1e-8 and out["newton_iters"] < 20, out
     assert out["sa_iters"][0] == out["sa_iters"][1] and out["sa_err"] < 1e-9, out
+    check_sa_gating_and_anderson(out)
+
+
+def check_sa_gating_and_anderson(out):
+    """Device-gated loop: one host read per check_every iterations (+ one per phase), the same iterates as the
+    one-read-per-iteration form; Anderson: the oracle's iteration count and fixed point."""
+    na = out["sa_iters"][0]
+    assert out["sa_host_syncs"] <= na // out["sa_check_every"] + 3, out
+    assert out["sa_n_errors"] == na, out
+    assert out["sa_check1"][0] == na and out["sa_check1"][1] == 0.0, out
+    n_and, n_ando = out["anderson_iters"]
+    assert out["anderson_resid"] < 1e-5, out
+    assert abs(n_and - n_ando) <= max(2, n_ando // 10) and out["anderson_err"] < 1e-4, out
 
 
 def test_sharded_operator_world4_uneven_blocks():
@@ -55,6 +68,7 @@ def test_sharded_operator_world4_uneven_blocks():
     assert out["T"] < 1e-13 and out["Tlin"] < 1e-13 and out["jvp"] < 1e-12, out
     assert out["sizes"] == [[2, 1, 1, 1], [2, 2, 1, 1]]
     assert out["newton_err"] < 1e-8 and out["sa_iters"][0] == out["sa_iters"][1]
+    check_sa_gating_and_anderson(out)
 
 
 @pytest.mark.parametrize("model,shapes,world", [("ssy", (4, 5, 3, 3), 2), ("gcy", (4, 2, 2, 5, 2, 3), 2),
@@ -72,7 +86,10 @@ def test_mirror_schedule_one_exchange_per_iteration(model, shapes, world):
     assert m > 0.5 * na, out                                   # most iterations ran in mirror form
     # mirror iterations: one exchange each; the switch back to layout A: at most one; exact iterations: two each
     # (the first exact iteration re-shards w as well)
-    assert out["sa_exchanges"] <= m + 1 + 2 * (na - m) + 1, out
+    # (the gated loop enqueues whole chunks: up to check_every - 1 no-op iterations, with their exchanges, per phase)
+    ce = out["sa_check_every"]
+    assert out["sa_exchanges"] <= m + (ce - 1) + 1 + 2 * (na - m + ce - 1) + 1, out
+    check_sa_gating_and_anderson(out)
 
 
 def test_block_sizes():

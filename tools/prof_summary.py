@@ -25,7 +25,7 @@ def short(n):
 
 
 out = {"passes": {}, "kernels": {}, "launch_order": []}
-FAST = ("slice_kernel", "line_kernel")
+FAST = ("slice_kernel", "line_kernel", "line_stream_kernel")
 
 
 def is_fast(name):
