@@ -330,6 +330,13 @@ def main():
             t = time.perf_counter() - t0
             sec["gcy20_newton_1e-8_krylov_f32"] = {"iterations": n, "operator_applies": info["n_apply"], "seconds": t,
                                                    "applies_per_s": info["n_apply"] / t, "final_err": info["final_err"]}
+            # ... and the fastest setting of the config-5 sweep that still reaches 1e-8 (profiles/round3_mixed_precision_sweep.txt):
+            # fp32 Krylov storage with the inner solves at 1e-4 (inexact Newton: one more outer step, fewer matvecs)
+            t0 = time.perf_counter()
+            x, n, info = op.solve(w800, "newton", tol=1e-8, inner_rtol=1e-4, inner_atol=0.0, krylov_f32=1)
+            t = time.perf_counter() - t0
+            sec["gcy20_newton_1e-8_krylov_f32_inner_1e-4"] = {"iterations": n, "operator_applies": info["n_apply"], "seconds": t,
+                                                              "applies_per_s": info["n_apply"] / t, "final_err": info["final_err"]}
             del x, w800
             # the device-resident successive-approximation loop on the bench grid (what solver(...) runs): per
             # iteration one plain slice pass + one fused line pass (end of one application + start of the next)

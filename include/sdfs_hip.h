@@ -63,7 +63,9 @@ typedef struct sdfs_opts {
   int32_t record_errors; /* 1: keep the per-iteration error trace (sdfs_error_trace) */
   int32_t krylov_f32;    /* Newton: 1 = inner BiCGSTAB in fp32 storage (Krylov vectors, J.v streams), fp64
                           * arithmetic and reductions, fp64 outer residual and iterate -- the mixed-precision
-                          * configuration of BASELINE.json (config 5).  Default 0 (everything fp64).    */
+                          * configuration of BASELINE.json (config 5).  2 = the same with every store of those fp32
+                          * containers rounded to bfloat16: the NUMERICS of bf16 storage at the bytes of fp32 (evaluation
+                          * mode of the config-5 sweep).  Default 0 (everything fp64).    */
 } sdfs_opts;
 
 /* Per-kernel counters for the roofline line of bench.py. */

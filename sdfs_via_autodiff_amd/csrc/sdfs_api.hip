@@ -110,7 +110,9 @@ struct Knobs {
   int small_wpt = 0;           // SDFS_SMALL_WPT: force its waves per tile (1 or 4)
   int no_bicg_merge = 0;       // SDFS_NO_BICG_MERGE: 1 = BiCGSTAB keeps its finishing kernels as launches of their own on small grids too
   int and_host = 0;            // SDFS_AND_HOST: 1 = Anderson with the Gram solve on the host (one synchronisation per iteration)
-  int sa_fused = 1;            // SDFS_SA_FUSED: 0 = successive approximation on the small-grid plan keeps one launch per pass
+  int sa_fused = -1;           // SDFS_SA_FUSED: 0 = successive approximation keeps one launch per pass; 1 = fused end + start kernels;
+                               // default (-1): fused, except on the 6-D pair plan when its line passes run the streamed forms
+                               // (three streamed launches, 0.805 ms at GCY 20^6, beat slices + fused lines, 0.83 ms)
   int ablate = 0;              // SDFS_ABLATE, honoured only by -DSDFS_DIAG builds
 };
 
@@ -153,6 +155,7 @@ struct sdfs_handle {
 
   // Newton-Krylov with fp32 Krylov vectors / J.v streams (opts.krylov_f32); set while such a solve runs
   bool krylov_f32 = false;
+  bool krylov_bf16 = false;          // ... with every store of those fp32 containers rounded to bfloat16 (opts.krylov_f32 = 2: bf16r, vec_kernels.hpp)
   double lin_ref = 0.0;              // sharded handles: reference value of the fp32 linearisation scale (sdfs_set_krylov_f32)
 
   // continuous-state operator (sdfs_create_continuous): no plan, one kernel per application
@@ -256,7 +259,7 @@ Knobs read_knobs() {
   k.line_stream = env_int("SDFS_LINE_STREAM", 3);
   k.small_plan = env_int("SDFS_SMALL_PLAN", 1);
   k.small_r = env_int("SDFS_SMALL_R", 0);
-  k.sa_fused = env_int("SDFS_SA_FUSED", 1);
+  k.sa_fused = env_int("SDFS_SA_FUSED", -1);
   k.small_wpt = env_int("SDFS_SMALL_WPT", 0);
   k.and_host = env_int("SDFS_AND_HOST", 0);
   k.no_bicg_merge = env_int("SDFS_NO_BICG_MERGE", 0);
@@ -939,6 +942,14 @@ unsigned line_grid(const sdfs_handle* h, const FastPass& P) {
   return (unsigned)std::min<long long>(P.ld.ntiles, (long long)line_blocks_per_cu(P.n) * h->num_cus);
 }
 
+// bf16r emulation (opts.krylov_f32 = 2): round an fp32 stream a J.v / linearising pass has just written
+int round_stream_bf16_n(sdfs_handle* h, void* p, long long n, const unsigned long long* gate) {
+  hipLaunchKernelGGL(k_round_bf16, dim3(std::min<long long>((n / 4 + 255) / 256 + 1, 8192)), dim3(256), 0, h->stream, (float*)p, n, gate);
+  HIPCHK(h, hipGetLastError());
+  return 0;
+}
+int round_stream_bf16(sdfs_handle* h, void* p, const unsigned long long* gate) { return round_stream_bf16_n(h, p, (long long)h->N, gate); }
+
 int run_fast_plan(sdfs_handle* h, int mode, const double* in, double* out, const double* old,
                   unsigned long long* resid, const unsigned long long* gate, double gate_tol, int minus_identity,
                   double* dotp) {
@@ -1035,6 +1046,12 @@ int run_fast_plan(sdfs_handle* h, int mode, const double* in, double* out, const
       hipLaunchKernelGGL(fn, dim3(grid), dim3(line_block(P.n)), line_lds_bytes(P.n), h->stream, d, io);
     }
     HIPCHK(h, hipGetLastError());
+    if (f32 && h->krylov_bf16) {
+      // bf16r emulation: what this pass stored as floats is rounded to bfloat16 (the BiCGSTAB gate is a zero word when closed)
+      if (mode == MODE_JVP && (rc = round_stream_bf16(h, pout, gate))) return rc;
+      if (mode == MODE_T_LIN && i == 0 && (rc = round_stream_bf16(h, h->c1, nullptr))) return rc;
+      if (mode == MODE_T_LIN && last && (rc = round_stream_bf16(h, h->c2, nullptr))) return rc;
+    }
   }
   return 0;
 }
@@ -1107,6 +1124,11 @@ int run_plan(sdfs_handle* h, Plan& plan, int mode, bool has_first, bool has_last
     const char* tag = vjp ? "vjp" : (mode == MODE_JVP) ? (h->krylov_f32 ? "jvp32" : "jvp") : (mode == MODE_T_LIN ? "Tlin" : "T");
     rc = launch_pass(h, P, pro, epi, io, minus_identity, tag, bytes, prec, vjp);
     if (rc) return rc;
+    if (prec && h->krylov_bf16) {
+      if (mode == MODE_JVP && (rc = round_stream_bf16_n(h, io.out, plan.nloc, gate))) return rc;
+      if (mode == MODE_T_LIN && first && (rc = round_stream_bf16_n(h, h->c1, plan.nloc, nullptr))) return rc;
+      if (mode == MODE_T_LIN && last && (rc = round_stream_bf16_n(h, h->c2, plan.nloc, nullptr))) return rc;
+    }
   }
   return 0;
 }
@@ -1262,7 +1284,10 @@ int solve_sa(sdfs_handle* h, const sdfs_opts& o, double* w, int64_t* n_iter, int
   const bool fused = h->fast.ok && h->fast.small && !h->cont && !h->dense && h->knobs.sa_fused != 0;
   if (fused && (rc = small_sa_prologue(h, h->buf0))) return rc;
   // 6-D pair plan: plain slice pass + fused line pass per iteration
-  const bool fusedbig = h->fast.ok && !h->fast.small && h->fast.passes.size() == 3 && !h->cont && !h->dense && h->knobs.sa_fused != 0;
+  bool streamed = h->fast.ok && !h->fast.small && h->fast.passes.size() == 3 && (h->knobs.line_stream & 3) == 3;
+  for (const FastPass& P : h->fast.passes) if (P.line && !P.stream) streamed = false;
+  const bool fusedbig = h->fast.ok && !h->fast.small && h->fast.passes.size() == 3 && !h->cont && !h->dense && h->knobs.sa_fused != 0 &&
+                        !(h->knobs.sa_fused < 0 && streamed);
   if (fusedbig && (rc = big_sa_line(h, 2, true, h->buf0, nullptr, nullptr, nullptr, nullptr, 0.0))) return rc;
   // ... and the residual without atomics: per-workgroup maxima, reduced by the next iteration's kernels
   bool ring = false;
@@ -1385,7 +1410,8 @@ int bicgstab_dev_t(sdfs_handle* h, const sdfs_opts& o, int64_t* matvecs) {
   // <t, s> and <t, t> come out of the last J.v pass when its tiles fit the partial-sum buffer
   const long long last_tiles = jvp_last_tiles(h);
   const bool fused_dots = last_tiles > 0 && 2 * last_tiles <= (long long)MAX_PARTIAL_BLOCKS * AND_MAX_M &&
-                          (h->plan[0].passes.size() > 1 || (h->fast.ok && (!h->krylov_f32 || h->fast.f32_ok))) && h->knobs.no_dot_fusion == 0;
+                          (h->plan[0].passes.size() > 1 || (h->fast.ok && (!h->krylov_f32 || h->fast.f32_ok))) && h->knobs.no_dot_fusion == 0 &&
+                          !h->krylov_bf16;      // (the fused sums would see the J.v output before its rounding)
   // small grids are launch-bound: the finishing kernels merge into the vector kernels behind them (vec_kernels.hpp),
   // each reduction with its own region of the partial-sum buffer
   constexpr int PR = 2 * MAX_PARTIAL_BLOCKS;
@@ -1443,7 +1469,7 @@ int bicgstab_dev_t(sdfs_handle* h, const sdfs_opts& o, int64_t* matvecs) {
   // breakdown / convergence test for long.
   const int chunk = (int)std::min<long long>(maxit, n <= (1LL << 22) ? 8 : 1);
   const int gslot = std::is_same<T, float>::value ? 1 : 0;
-  const bool graph = o.use_graph && !h->profiling && st != nullptr && chunk > 1;
+  const bool graph = o.use_graph && !h->profiling && st != nullptr && chunk > 1 && !std::is_same<T, bf16r>::value;
   if (graph && (h->bicg_graph[gslot] == nullptr || h->bicg_graph_chunk[gslot] != chunk)) {
     if (h->bicg_graph[gslot]) { hipGraphExecDestroy(h->bicg_graph[gslot]); h->bicg_graph[gslot] = nullptr; }
     hipGraph_t gr = nullptr;
@@ -1481,6 +1507,7 @@ int bicgstab_dev_t(sdfs_handle* h, const sdfs_opts& o, int64_t* matvecs) {
 // the successive_approx stopping rule on the Newton map.
 
 int bicgstab_dev(sdfs_handle* h, const sdfs_opts& o, int64_t* matvecs) {
+  if (h->krylov_f32 && h->krylov_bf16) return bicgstab_dev_t<bf16r>(h, o, matvecs);
   return h->krylov_f32 ? bicgstab_dev_t<float>(h, o, matvecs) : bicgstab_dev_t<double>(h, o, matvecs);
 }
 
@@ -1506,10 +1533,11 @@ int solve_newton(sdfs_handle* h, const sdfs_opts& o, double* w, int64_t* n_iter,
   // opts.krylov_f32: inexact Newton with the inner solve in fp32 storage (Krylov vectors, c1 / c2, the
   // J.v intermediates) and fp64 arithmetic / reductions; the outer residual T(x) - x and the iterate
   // stay fp64, so the fixed point is reached to the same tolerance.  Discretised, unsharded handles only.
-  struct F32Guard { sdfs_handle* h; ~F32Guard() { h->krylov_f32 = false; } } f32_guard{h};
+  struct F32Guard { sdfs_handle* h; ~F32Guard() { h->krylov_f32 = false; h->krylov_bf16 = false; } } f32_guard{h};
   const bool want_f32 = o.krylov_f32 != 0 && !h->cont && !h->dense && !h->sharded;
   int f32_failures = 0;
   h->krylov_f32 = want_f32;
+  h->krylov_bf16 = want_f32 && o.krylov_f32 == 2;
   while (err > o.tol && it < o.max_iter) {
     // g(x) = T(x) - x, linearisation cached for the J.v products
     if ((rc = run_plan(h, h->plan[0], MODE_T_LIN, true, true, x, Tx, x, nullptr, nullptr, 0.0, 0))) return rc;
@@ -1527,7 +1555,15 @@ int solve_newton(sdfs_handle* h, const sdfs_opts& o, double* w, int64_t* n_iter,
     HIPCHK(h, hipMemcpyAsync(h->slots_host, h->slots, 8, hipMemcpyDeviceToHost, st));
     HIPCHK(h, hipStreamSynchronize(st));
     err = bits_to_double(h->slots_host[0]);
-    if (!std::isfinite(err) && h->krylov_f32) {
+    // A BiCGSTAB breakdown (rho, omega or alpha = 0) leaves a zero step, which the stopping rule below -- the
+    // reference's, code/solvers.py:36 -- would read as convergence wherever the iterate happens to be (seen with fp32
+    // storage at inner_rtol 1e-2: "converged" 352 away from the fixed point).  Such a step did nothing: in reduced
+    // storage it is redone in fp64 like an overflowed one; in fp64 the solve ends with a numeric error.  (A zero step
+    // because |g|_2 <= inner_atol is the reference's own rule and stays.)
+    // (a NaN right-hand side closes the solve's gate at once: also a zero step)
+    const bool broke = err == 0.0 && (h->sc_host[SC_BREAK] != 0.0 || !(h->sc_host[SC_BB] == h->sc_host[SC_BB]));
+    if (broke && !h->krylov_f32) { status = SDFS_ERR_NUMERIC; ++it; break; }
+    if ((!std::isfinite(err) || broke) && h->krylov_f32) {
       HIPCHK(h, hipMemcpyAsync(x, Tx, nb, hipMemcpyDeviceToDevice, st));
       h->krylov_f32 = false;                 // redo this step in fp64
       ++f32_failures;
@@ -1544,7 +1580,7 @@ int solve_newton(sdfs_handle* h, const sdfs_opts& o, double* w, int64_t* n_iter,
   HIPCHK(h, hipMemcpyAsync(w, x, nb, hipMemcpyDeviceToDevice, st));
   HIPCHK(h, hipStreamSynchronize(st));
   *n_iter = it; *n_apply = applies; *final_err = err;
-  if (status) return fail(h, status, "non-finite Newton step at iteration %lld", it);
+  if (status) return fail(h, status, "non-finite Newton step or BiCGSTAB breakdown with no progress at iteration %lld", it);
   return 0;
 }
 

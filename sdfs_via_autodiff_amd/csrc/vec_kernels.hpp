@@ -105,6 +105,22 @@ k_sub_dot(const double* __restrict__ a, const double* __restrict__ b, double* __
 // 16-byte packets: W consecutive elements per lane and access (2 doubles / 4 floats); a stream of
 // another type rides along in as many 16-byte pieces as it needs.  Converted to double in registers.
 template <typename T> struct PkW { static constexpr int W = 16 / (int)sizeof(T); };
+
+// bf16r: an fp32 container whose STORES round to bfloat16 (round to nearest even on the upper 16 bits) -- the numerics
+// of bf16 storage of the Krylov vectors and J.v streams (opts.krylov_f32 = 2, BASELINE config 5's bf16 question) at the
+// bytes of fp32: what a 2-byte container would converge like, measured before anyone builds it.
+__device__ __forceinline__ float round_bf16(float f) {
+  unsigned u = __float_as_uint(f);
+  if ((u & 0x7f800000u) == 0x7f800000u) return f;           // Inf / NaN
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return __uint_as_float(u & 0xffff0000u);
+}
+struct bf16r {
+  float v;
+  bf16r() = default;
+  __device__ __forceinline__ explicit bf16r(double d) : v(round_bf16((float)d)) {}     // "(T)x": the value as it will be stored
+  __device__ __forceinline__ explicit operator double() const { return (double)v; }
+};
 template <int W>
 __device__ __forceinline__ void ldv(const double* __restrict__ p, long long e, double (&v)[W]) {
 #pragma unroll
@@ -125,6 +141,16 @@ template <int W>
 __device__ __forceinline__ void stv(float* __restrict__ p, long long e, const double (&v)[W]) {
   static_assert(W == 4, "float packets hold four elements");
   float4 t; t.x = (float)v[0]; t.y = (float)v[1]; t.z = (float)v[2]; t.w = (float)v[3];
+  *reinterpret_cast<float4*>(p + e) = t;
+}
+template <int W>
+__device__ __forceinline__ void ldv(const bf16r* __restrict__ p, long long e, double (&v)[W]) {
+  ldv<W>(reinterpret_cast<const float*>(p), e, v);
+}
+template <int W>
+__device__ __forceinline__ void stv(bf16r* __restrict__ p, long long e, const double (&v)[W]) {
+  static_assert(W == 4, "float packets hold four elements");
+  float4 t; t.x = round_bf16((float)v[0]); t.y = round_bf16((float)v[1]); t.z = round_bf16((float)v[2]); t.w = round_bf16((float)v[3]);
   *reinterpret_cast<float4*>(p + e) = t;
 }
 // grid-stride over packets, then over the < W leftover elements; BODY(e, W_) sees `e` (first element)
@@ -153,6 +179,25 @@ __device__ __forceinline__ void STx(double* __restrict__ p, long long e, const d
 template <int W>
 __device__ __forceinline__ void STx(float* __restrict__ p, long long e, const double (&v)[W]) {
   if constexpr (W == 1) p[e] = (float)v[0]; else stv<W>(p, e, v);
+}
+template <int W>
+__device__ __forceinline__ void LDx(const bf16r* __restrict__ p, long long e, double (&v)[W]) {
+  LDx<W>(reinterpret_cast<const float*>(p), e, v);
+}
+template <int W>
+__device__ __forceinline__ void STx(bf16r* __restrict__ p, long long e, const double (&v)[W]) {
+  if constexpr (W == 1) p[e].v = round_bf16((float)v[0]); else stv<W>(p, e, v);
+}
+// the J.v kernels write fp32 streams: under bf16r emulation their output is rounded by a launch of its own
+__global__ void __launch_bounds__(256) k_round_bf16(float* __restrict__ p, long long n, const unsigned long long* __restrict__ gate) {
+  if (gate != nullptr && *gate == 0ULL) return;
+  const long long n4 = n / 4;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+    float4 t = reinterpret_cast<float4*>(p)[i];
+    t.x = round_bf16(t.x); t.y = round_bf16(t.y); t.z = round_bf16(t.z); t.w = round_bf16(t.w);
+    reinterpret_cast<float4*>(p)[i] = t;
+  }
+  for (long long i = n4 * 4 + (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) p[i] = round_bf16(p[i]);
 }
 
 // BiCGSTAB kernels.  T is the storage type of the Krylov vectors (double, or float for

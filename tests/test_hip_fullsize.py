@@ -44,11 +44,18 @@ def c_oracle(gcy20):
     return COperator("gcy", SHAPES, params, arr)
 
 
-def test_device_sa_loop_gcy20_vs_c_oracle(S, gcy20, c_oracle):
-    """max_iter = k, tol = 0: the fused loop's k-th iterate and its last error against k applications of the C
-    oracle on the full grid."""
+@pytest.mark.parametrize("fused", [None, "1"])
+def test_device_sa_loop_gcy20_vs_c_oracle(S, gcy20, c_oracle, fused):
+    """max_iter = k, tol = 0: the device loop's k-th iterate and its last error against k applications of the C
+    oracle on the full grid.  Default at 20^6: three streamed launches per iteration (what solver() runs);
+    SDFS_SA_FUSED=1: slices + fused line kernel (end of one application and start of the next)."""
     params, arr = gcy20
-    T = S.KoopmansOperator("gcy", SHAPES, params, arr)
+    if fused is not None:
+        os.environ["SDFS_SA_FUSED"] = fused
+    try:
+        T = S.KoopmansOperator("gcy", SHAPES, params, arr)
+    finally:
+        os.environ.pop("SDFS_SA_FUSED", None)
     assert "pair plan pass" in T.describe_plan()
     w0 = np.full(SHAPES, 800.0)
     want, prev = w0, None
@@ -69,13 +76,19 @@ def test_device_sa_loop_gcy20_vs_c_oracle(S, gcy20, c_oracle):
     T.close()
 
 
+@pytest.mark.parametrize("fused", [None, "1"])
 @pytest.mark.parametrize("shapes", [(20, 20, 16, 16, 20, 20), (20, 20, 20, 20, 16, 16)])
-def test_device_sa_loop_small_twin_vs_oracle(S, shapes):
-    """20-extent slice pair and 20-extent line pairs on a grid the numpy oracle handles (2.6e7 / 1.6e7 points run
-    through the C oracle)."""
+def test_device_sa_loop_small_twin_vs_oracle(S, shapes, fused):
+    """20-extent slice pair and 20-extent line pairs on smaller grids (2.6e7 / 1.6e7 points, C oracle), both forms
+    of the device loop."""
     from oracle.c_oracle import COperator
     g = S.GCY(); arr = S.discretize_gcy(g, shapes)
-    T = S.KoopmansOperator("gcy", shapes, g.params, arr)
+    if fused is not None:
+        os.environ["SDFS_SA_FUSED"] = fused
+    try:
+        T = S.KoopmansOperator("gcy", shapes, g.params, arr)
+    finally:
+        os.environ.pop("SDFS_SA_FUSED", None)
     assert "pair plan pass" in T.describe_plan()
     oc = COperator("gcy", shapes, g.params, arr)
     w0 = np.full(shapes, 800.0)

@@ -670,3 +670,26 @@ def test_other_calibrations(S, model, shapes, beta, gamma, psi, level):
     for _ in range(5):
         w5 = To(w5)
     np.testing.assert_allclose(x5, w5, rtol=1e-11)
+
+
+def test_mixed_precision_storage_error_bounds(S):
+    """BASELINE config 5 (new work: the reference is fp64 only).  Newton-Krylov at GCY 12^6 from w = 800, outer tol
+    1e-8, per storage of the Krylov path: fp64 and fp32 storage reach the fp64 fixed point to 1e-8 at inner tolerances
+    1e-4 and 1e-6; bf16-rounded storage (krylov_f32 = 2) does not (its rounding, 2^-8, exceeds 1 - modulus = 1.2e-3:
+    the rounded Jacobian's I - J is no longer definite) -- the solve must then say so, not return a wrong point."""
+    shapes = (12,) * 6
+    T, _, _ = make_op(S, "gcy", shapes)
+    w0 = np.full(shapes, 800.0)
+    xs, _, info = T.solve(w0, "newton", tol=1e-11, inner_rtol=1e-9, inner_atol=0.0, max_iter=40)
+    assert info["status"] == 0
+    for inner in (1e-4, 1e-6):
+        for mode in (0, 1):
+            x, n, info = T.solve(w0, "newton", tol=1e-8, inner_rtol=inner, inner_atol=0.0, krylov_f32=mode, max_iter=40)
+            assert info["status"] == 0 and n < 30, (inner, mode, info)
+            assert np.max(np.abs(x - xs)) < 1e-8, (inner, mode)
+    # a loose inner solve must never be reported as converged at a wrong point
+    for mode in (0, 1, 2):
+        x, n, info = T.solve(w0, "newton", tol=1e-8, inner_rtol=1e-2, inner_atol=0.0, krylov_f32=mode, max_iter=40, inner_max_iter=200)
+        if info["status"] == 0 and info["final_err"] <= 1e-8:
+            assert np.max(np.abs(x - xs)) < 1e-6, (mode, info)
+    T.close()
