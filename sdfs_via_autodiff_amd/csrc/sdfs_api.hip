@@ -101,8 +101,9 @@ struct Knobs {
   int tile_budget = 0, filler_chunk = -1, force_waves = 0, no_occ_blocks = 0, no_pad = 0, no_vec2 = 0, no_vec4 = 0;
   int no_dot_fusion = 0, no_slice_merge = 0, cont_no_tensor = 0, cont_lds_cap = 4000;
   int line_persist = 0;        // SDFS_LINE_PERSIST bit 0: middle line passes persistent, bit 1: last line pass persistent
-  int line_stream = 3;         // SDFS_LINE_STREAM: stream_kernels.hpp forms of the fp64 line passes; bit 0: middle pass, bit 1: T's last pass (both: extents they were measured on), bit 2: every extent
-                               // (measured equal to one tile per workgroup at GCY 20^6, tools/ab_plan.py: off by default)
+                               // (round 2's look-ahead form; measured equal to one tile per workgroup at GCY 20^6: off by default)
+  int line_stream = 3;         // SDFS_LINE_STREAM: stream_kernels.hpp forms of the fp64 line passes; bit 0: middle pass, bit 1: T's
+                               // last pass (both: on the extents they were measured on, n = 20), bit 2: on every extent
   int pair_order = 1;          // SDFS_PAIR_ORDER: 1 = line passes slowest pair first (the last pass then walks the faster pair), 0 = fastest first
   int plan = 0;                // SDFS_PLAN: 0 = automatic, 1 = "classic" (generic tiles only), 2 = "pair" (pair plan whenever legal)
   int small_plan = 1;          // SDFS_SMALL_PLAN: 0 = never use the small-grid pair plan
@@ -243,6 +244,9 @@ int env_int(const char* name, int dflt) {
 
 Knobs read_knobs() {
   Knobs k;
+#ifdef SDFS_DIAG
+  // planner / kernel-shape experiments of rounds 1-2: no test or tool sets them any more, so the shipped library does
+  // not read them (a stray variable cannot change the kernels that run); -DSDFS_DIAG builds still do
   k.tile_budget = env_int("SDFS_TILE_BUDGET", 0);
   k.filler_chunk = env_int("SDFS_FILLER_CHUNK", -1);
   k.force_waves = env_int("SDFS_FORCE_WAVES", 0);
@@ -251,9 +255,11 @@ Knobs read_knobs() {
   k.no_vec2 = env_int("SDFS_NO_VEC2", 0);
   k.no_vec4 = env_int("SDFS_NO_VEC4", 0);
   k.no_dot_fusion = env_int("SDFS_NO_DOT_FUSION", 0);
-  k.no_slice_merge = env_int("SDFS_NO_SLICE_MERGE", 0);
   k.cont_no_tensor = env_int("SDFS_CONT_NO_TENSOR", 0);
   k.cont_lds_cap = env_int("SDFS_CONT_LDS_CAP", 4000);
+  k.no_bicg_merge = env_int("SDFS_NO_BICG_MERGE", 0);
+#endif
+  k.no_slice_merge = env_int("SDFS_NO_SLICE_MERGE", 0);
   k.pair_order = env_int("SDFS_PAIR_ORDER", 1);
   k.line_persist = env_int("SDFS_LINE_PERSIST", 0);
   k.line_stream = env_int("SDFS_LINE_STREAM", 3);
@@ -262,7 +268,6 @@ Knobs read_knobs() {
   k.sa_fused = env_int("SDFS_SA_FUSED", -1);
   k.small_wpt = env_int("SDFS_SMALL_WPT", 0);
   k.and_host = env_int("SDFS_AND_HOST", 0);
-  k.no_bicg_merge = env_int("SDFS_NO_BICG_MERGE", 0);
   const char* pl = getenv("SDFS_PLAN");
   if (pl && !strcmp(pl, "classic")) k.plan = 1;
   else if (pl && !strcmp(pl, "pair")) k.plan = 2;

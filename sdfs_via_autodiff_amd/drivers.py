@@ -1,14 +1,12 @@
 """
-The reference's discrete drivers, call for call
-(code/ssy/discrete/ssy_wc_ratio.py:216-240, code/gcy/discrete/gcy_wc_ratio.py:319-340):
+The reference's two discrete drivers (code/ssy/discrete/ssy_wc_ratio.py:216-240,
+code/gcy/discrete/gcy_wc_ratio.py:319-340) under their own names and signatures.
 
-    SSY() / GCY()  ->  discretize_*  ->  T = lambda w: T_*(w, shapes, params, arrays)
-                   ->  w_init = 800 * ones(shapes)  ->  solver(T, w_init, algorithm=algo)
-
-``T`` is the reference's plain closure, not an operator object: ``solver`` recognises that it is
-one device operator (solvers._resolve_operator) and runs the whole iteration on the GPU.
-The reference moves the arrays to the device with ``jax.device_put``; here the operator uploads
-them once when the closure is first called.
+Both do the same five things -- calibration object, discretisation, the closure
+``T = lambda w: T_*(w, shapes, params, arrays)``, a constant start at 800 and ``solver(T, w_init, algorithm=algo)`` --
+so one helper carries them.  The closure is deliberately the reference's plain lambda, not an operator object:
+``solver`` finds the device operator behind it (solvers._resolve_operator) and runs the whole iteration on the GPU.
+Where the reference calls ``jax.device_put`` on the arrays, the operator here uploads them once, on first use.
 """
 import time
 
@@ -19,46 +17,29 @@ from .discretize import discretize_ssy, discretize_gcy
 from .operators import T_ssy, T_gcy
 from .solvers import solver
 
+START_LEVEL = 800.0      # ssy_wc_ratio.py:233, gcy_wc_ratio.py:336
 
-def test_compute_wc_ratio_ssy(shapes=(2, 3, 4, 5), algo="successive_approx"):
-    """Solve a small version of the model using T_ssy."""
-    ssy = SSY()
 
-    # Build discrete rep of SSY
-    params = ssy.params
-    arrays = discretize_ssy(ssy, shapes)
-
-    # Marginalize T
-    T = lambda w: T_ssy(w, shapes, params, arrays)
-
-    # Call the solver
-    init_val = 800.0
-    w_init = np.ones(shapes) * init_val
+def _solve_discrete(model_cls, discretize, T_model, shapes, algo, timed):
+    model = model_cls()
+    params, arrays = model.params, discretize(model, shapes)
+    T = lambda w: T_model(w, shapes, params, arrays)           # what the reference hands to its solvers
+    w_init = np.full(shapes, START_LEVEL)
     t0 = time.time()
     w_star = solver(T, w_init, algorithm=algo)
-    t = time.time() - t0
-    print(f"Computed solution in {t} seconds.")
-
+    if timed:                                                   # only the SSY driver reports its time (qe.tic / qe.toc there)
+        print(f"Computed solution in {time.time() - t0} seconds.")
     return w_star
+
+
+def test_compute_wc_ratio_ssy(shapes=(2, 3, 4, 5), algo="successive_approx"):
+    """Wealth-consumption ratio of the SSY model on a small grid (the reference's smoke solve)."""
+    return _solve_discrete(SSY, discretize_ssy, T_ssy, shapes, algo, timed=True)
 
 
 def test_compute_wc_ratio_gcy(shapes=(3, 3, 3, 3, 3, 3), algo="successive_approx"):
-    """Solve a small version of the model using T_gcy."""
-    gcy = GCY()
-
-    # Build discrete rep of GCY
-    params = gcy.params
-    arrays = discretize_gcy(gcy, shapes)
-
-    # Marginalize T
-    T = lambda w: T_gcy(w, shapes, params, arrays)
-
-    # Call the solver
-    init_val = 800.0
-    w_init = np.ones(shapes) * init_val
-    w_star = solver(T, w_init, algorithm=algo)
-
-    return w_star
+    """Wealth-consumption ratio of the GCY model on a small grid."""
+    return _solve_discrete(GCY, discretize_gcy, T_gcy, shapes, algo, timed=False)
 
 
 # pytest must not collect the reference-named drivers when this module is imported into a test file

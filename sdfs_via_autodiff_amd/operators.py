@@ -235,14 +235,17 @@ _CACHE_MAX = 8
 def _fingerprint(a):
     """Cheap content stamp of one model array: the reference's closure re-reads its arrays at every
     call, so an array changed in place between two calls must not hit the cached device copy.  Small
-    arrays are hashed whole; the two big conditional tensors (25.6 MB at 20^6) by a strided sample
-    plus their sum."""
+    arrays are hashed whole; the two big conditional tensors (25.6 MB at 20^6) by a strided sample of 4096
+    entries plus the bit pattern of their sum (bits, not the value: a NaN would never compare equal and the
+    operator would be rebuilt on every call).  Limit of the sample: an in-place edit outside it that leaves
+    the sum's bits unchanged goes unnoticed -- build a new arrays tuple, or a KoopmansOperator, to be sure."""
     a = np.asarray(a)
     flat = a.reshape(-1)
     if flat.size <= 65536:
         return (a.shape, zlib.crc32(np.ascontiguousarray(flat).view(np.uint8)))
     step = flat.size // 4096
-    return (a.shape, zlib.crc32(np.ascontiguousarray(flat[::step]).view(np.uint8)), float(flat.sum()))
+    return (a.shape, zlib.crc32(np.ascontiguousarray(flat[::step]).view(np.uint8)),
+            np.float64(flat.sum()).tobytes())
 
 
 def _cached(model, shapes, params, arrays):
@@ -250,12 +253,14 @@ def _cached(model, shapes, params, arrays):
            tuple(id(a) for a in arrays))
     stamp = tuple(_fingerprint(a) for a in arrays)
     hit = _cache.get(key)
+    # (a replaced operator is only dropped from the cache: a running solver or the caller may still hold it, its
+    # weakref finalizer frees the device memory when the last reference goes)
     if hit is not None and hit._stamp != stamp:       # same objects, new contents: rebuild
-        _cache.pop(key).close()
+        _cache.pop(key)
         hit = None
     if hit is None:
         if len(_cache) >= _CACHE_MAX:
-            _cache.pop(next(iter(_cache))).close()
+            _cache.pop(next(iter(_cache)))
         hit = KoopmansOperator(model, shapes, params, arrays)
         hit._keepalive = list(arrays)    # the id()-based key stays valid while these live
         hit._stamp = stamp

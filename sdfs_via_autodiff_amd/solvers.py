@@ -34,24 +34,17 @@ default_tolerance = 1e-7
 default_max_iter = int(1e6)
 
 
-def _same_array(a, b):
-    if a is b:
-        return True
-    try:
-        a = np.asarray(a); b = np.asarray(b)
-        return a.shape == b.shape and np.array_equal(a, b)
-    except Exception:
-        return False
-
-
 def _traced_single_apply(f, x):
     """Call f(x) under a trace.  Returns (y, op) where op is the device operator when the call
-    was exactly ``op(x)`` passed through unchanged, else None."""
+    was exactly ``op(x)`` passed through unchanged -- the operator must have received the very object
+    ``x`` (equal values are not enough: ``lambda w: T(np.clip(w, lo, hi))`` is the identity on its
+    argument at the start value and at the fixed point, and only there) and its result must come back
+    as the very object it returned -- else None."""
     with trace_calls() as calls:
         y = f(x)
     if len(calls) == 1:
         op, w_in, out = calls[0]
-        if out is y and _same_array(w_in, x):
+        if out is y and w_in is x:
             return y, op
     return y, None
 
@@ -105,11 +98,13 @@ def _report(verbose, current_iter, max_iter):
 
 
 def successive_approx(f, x_init, tol=default_tolerance, max_iter=default_max_iter,
-                      verbose=True, print_skip=1000, **device_opts):
+                      verbose=True, print_skip=1000, _host_only=False, **device_opts):
     "Uses successive approximation on f."
     if verbose:
         print("Beginning iteration\n\n")
-    done = _on_device(f, x_init, "successive_approx", verbose, print_skip, max_iter, tol=tol, **device_opts)
+    # (_host_only: the Newton map of a foreign callable is known not to be a device operator -- tracing it would cost
+    # one whole inner solve whose result is thrown away)
+    done = None if _host_only else _on_device(f, x_init, "successive_approx", verbose, print_skip, max_iter, tol=tol, **device_opts)
     if done is not None:
         return done
 
@@ -192,7 +187,7 @@ def newton_solver(f, x_init, tol=default_tolerance, max_iter=default_max_iter,
                 return (np.asarray(f(x + eps * v), dtype=np.float64) - fx) / eps - v
         return x - _host_bicgstab(mv, gx, atol=bicgstab_atol)
 
-    return successive_approx(q, x_init, tol, max_iter, verbose, print_skip)
+    return successive_approx(q, x_init, tol, max_iter, verbose, print_skip, _host_only=True)
 
 
 def anderson_solver(f, x_init, tol=default_tolerance, max_iter=10000, verbose=True,
