@@ -171,7 +171,11 @@ def test_closure_over_a_device_operator_is_resolved(capsys):
     x0 = np.zeros(3)
     assert _resolve_operator(op, x0) is op
     assert _resolve_operator(lambda w: op(w), x0) is op
-    assert _resolve_operator(lambda w: op(w * 1.0), x0) is op            # same values, new object: still op(w)
+    # the operator must receive the very object: equal values are not enough (a clipping closure is
+    # the identity on its argument at the start value and at the fixed point, and only there)
+    assert _resolve_operator(lambda w: op(w * 1.0), x0) is None
+    assert _resolve_operator(lambda w: op(np.clip(w, -1.0, 1.0)), x0) is None
+    assert _resolve_operator(lambda w: op(np.asarray(w)), x0) is op
     assert _resolve_operator(lambda w: op(w) + 0.0, x0) is None          # result touched
     assert _resolve_operator(lambda w: op(w + 1.0), x0) is None          # argument changed
     assert _resolve_operator(lambda w: op(op(w)), x0) is None            # two applications
