@@ -66,6 +66,11 @@ typedef struct sdfs_opts {
                           * configuration of BASELINE.json (config 5).  2 = the same with every store of those fp32
                           * containers rounded to bfloat16: the NUMERICS of bf16 storage at the bytes of fp32 (evaluation
                           * mode of the config-5 sweep).  Default 0 (everything fp64).    */
+  int32_t t_f32;         /* Successive approximation on the pair plan (extents 16/20/24/32, whole 16-element chunks): 1 = the
+                          * applications of T keep the intermediates between their passes as scaled floats while the step
+                          * is above ~64 * 2^-24 * w / |theta| (what that storage can resolve), then the loop finishes in
+                          * fp64 to `tol`: config 5 for the T passes.  The iteration count is then this configuration's
+                          * own.  Ignored where the plan has no fp32 forms.  Default 0.                                 */
 } sdfs_opts;
 
 /* Per-kernel counters for the roofline line of bench.py. */

@@ -28,7 +28,7 @@ class sdfs_opts(C.Structure):
                 ("history", C.c_int32), ("mixing_freq", C.c_int32),
                 ("beta", C.c_double), ("ridge", C.c_double),
                 ("check_every", C.c_int32), ("use_graph", C.c_int32),
-                ("record_errors", C.c_int32), ("krylov_f32", C.c_int32)]
+                ("record_errors", C.c_int32), ("krylov_f32", C.c_int32), ("t_f32", C.c_int32)]
 
 
 class sdfs_kernel_counter(C.Structure):

@@ -42,7 +42,9 @@ namespace sdfs {
 // tile goes out as the next application's intermediate.  With LineDesc::first_only only the second half runs (the
 // prologue of the loop).  The contraction order of an application is free, so successive approximation on a 6-D
 // grid runs [slices, plain] [lines, fused] per iteration, the fused pass alternating between the two line pairs.
-enum SliceMode { S_TFIRST = 0, S_TFIRST_LIN = 1, S_JFIRST = 2, S_MID = 3, S_NMODES = 4 };
+// S_TFIRST32: the first pass of T with its OUTPUT (the intermediate between the passes) stored as scaled floats
+// (opts.t_f32, BASELINE config 5): x = w^theta * 2^k with k from the mid-grid point, see t32_scale_of.
+enum SliceMode { S_TFIRST = 0, S_TFIRST_LIN = 1, S_JFIRST = 2, S_MID = 3, S_TFIRST32 = 4, S_NMODES = 5 };
 enum LineMode { L_MID = 0, L_TLAST = 1, L_TLAST_LIN = 2, L_JLAST = 3, L_TFUSED = 4, L_NMODES = 5 };
 
 template <int N> struct MShape {
@@ -114,6 +116,19 @@ __device__ __forceinline__ double lin_scale_of(double wref, double theta, const 
   double xr[1];
   pow_fast_n<true, 1>(wr, theta, PT, xr);
   const int k = -ilogb(xr[0] / wref);
+  return ldexp(1.0, inverse ? -k : k);
+}
+
+// fp32 intermediates of T (opts.t_f32): w^theta is ~1e-50 .. 1e-100 at theta = -16 .. -36 -- outside fp32 -- but T is
+// linear between its two powers, so the first pass stores x * 2^k (k = -ilogb(w_mid^theta): the spread
+// (w / w_mid)^theta then sits around 1) and the last pass multiplies its sums by 2^-k before the aggregator's power.
+// Both derive k from the same value, the iterate at the mid-grid point (the last pass reads it from the grid it forms
+// the residual against).
+__device__ __forceinline__ double t32_scale_of(double wref, double theta, const PowLane& PT, bool inverse) {
+  const double wr[1] = {wref};
+  double xr[1];
+  pow_fast_n<true, 1>(wr, theta, PT, xr);
+  const int k = -ilogb(xr[0]);
   return ldexp(1.0, inverse ? -k : k);
 }
 
@@ -204,10 +219,12 @@ template <int N, int MODE, bool F32>
 __global__ void __launch_bounds__(256, 3)
 slice_kernel(const SliceDesc P, const SliceIO io) {
   using Geo = SliceGeo<N>;
-  constexpr bool POWP = MODE == S_TFIRST || MODE == S_TFIRST_LIN;
+  constexpr bool T32 = MODE == S_TFIRST32;                        // fp64 in, scaled floats out
+  constexpr bool POWP = MODE == S_TFIRST || MODE == S_TFIRST_LIN || T32;
   constexpr bool LIN = MODE == S_TFIRST_LIN;
   constexpr bool MULP = MODE == S_JFIRST;
   constexpr bool JV32 = F32 && MULP;
+  static_assert(!T32 || !F32, "S_TFIRST32 is its own storage form");
   static_assert(!F32 || (MODE != S_TFIRST && MODE != S_MID), "plain T has no fp32 form");
   extern __shared__ double lds[];
   if (io.gate != nullptr) {
@@ -284,6 +301,7 @@ slice_kernel(const SliceDesc P, const SliceIO io) {
     const PowLane PT = pow_lane_init(lane);
     double lin_scale = 1.0;
     if (LIN && F32) lin_scale = lin_scale_of(io.in[P.ref_off], P.theta, PT, false);
+    const double t32_scale = T32 ? t32_scale_of(io.in[P.ref_off], P.theta, PT, false) : 1.0;
     char* const auxo = LIN ? (F32 ? reinterpret_cast<char*>(reinterpret_cast<float*>(io.aux_out) + gbase)
                                   : reinterpret_cast<char*>(io.aux_out + gbase)) : nullptr;
 #pragma unroll 1
@@ -296,7 +314,7 @@ slice_kernel(const SliceDesc P, const SliceIO io) {
       double xw[2];
       pow_fast_n<true, 2>(xin, P.theta, PT, xw);
       if (in_tile) {
-        *reinterpret_cast<double2*>(wl + lo) = make_double2(xw[0], xw[1]);
+        *reinterpret_cast<double2*>(wl + lo) = T32 ? make_double2(xw[0] * t32_scale, xw[1] * t32_scale) : make_double2(xw[0], xw[1]);
         if (LIN && u < nvalid) {                                  // c1 = w^(theta-1)
           if (F32) *reinterpret_cast<float2*>(auxo + ((unsigned)lane * 8u + 512u * k)) =
               make_float2((float)(xw[0] / xin[0] * lin_scale), (float)(xw[1] / xin[1] * lin_scale));
@@ -328,7 +346,7 @@ slice_kernel(const SliceDesc P, const SliceIO io) {
   }
   wave_lds_fence();
   // ---- stream out -------------------------------------------------------------------------------------
-  if (JV32) {
+  if (JV32 || T32) {
     const int nvalid4 = nvalid / 2;
     char* const outb = reinterpret_cast<char*>(reinterpret_cast<float*>(io.out) + gbase);
 #pragma unroll
@@ -1194,6 +1212,7 @@ template <int N> inline slice_fn slice_variant_n(int mode, bool f32) {
     case S_TFIRST_LIN: return f32 ? (slice_fn)slice_kernel<N, S_TFIRST_LIN, true> : (slice_fn)slice_kernel<N, S_TFIRST_LIN, false>;
     case S_JFIRST: return f32 ? (slice_fn)slice_kernel<N, S_JFIRST, true> : (slice_fn)slice_kernel<N, S_JFIRST, false>;
     case S_MID: return f32 ? nullptr : (slice_fn)slice_kernel<N, S_MID, false>;
+    case S_TFIRST32: return f32 ? nullptr : (slice_fn)slice_kernel<N, S_TFIRST32, false>;
     default: return nullptr;
   }
 }

@@ -315,6 +315,133 @@ line_stream_kernel(const LineDesc P, const LineIO io) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// line_tlast32_kernel: the last pass of T on an fp32 intermediate (opts.t_f32, BASELINE config 5; first pass:
+// slice_kernel<N, S_TFIRST32>, middle pass: line_kernel's fp32 L_MID form).  The tile arrives as scaled floats in
+// 16-byte units of four (row u >> 2, float4 u & 3 of its 16 elements), is contracted in fp64, multiplied by 2^-k
+// (t32_scale_of) and goes through the aggregator; w (for the residual) and T w are fp64 streams, two 16-byte
+// pieces per unit.  One tile per workgroup, the residual's w loaded for the whole tile before the contractions.
+template <int N, int WPC>
+__global__ void __launch_bounds__(LineGeo<N>::B, WPC * LineGeo<N>::B / 256)
+line_tlast32_kernel(const LineDesc P, const LineIO io) {
+  using Geo = LineGeo<N>;
+  constexpr int B = Geo::B;
+  constexpr int NW = B / 64;
+  constexpr int EPT4 = Geo::EPT4;
+  constexpr bool PART4 = Geo::UNITS4 % B != 0;
+  extern __shared__ double lds[];
+  __shared__ double red[16];
+  if (io.gate != nullptr) {
+    const unsigned long long g = *io.gate;
+    if (g <= (unsigned long long)__double_as_longlong(io.gate_tol)) return;
+  }
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 15, lk = lane >> 4;
+  const unsigned t = (unsigned)xcd_remap((long long)blockIdx.x, P.ntiles);
+  unsigned o; int chunk;
+  const long long tbase = line_tile_base(P, t, N * N, o, chunk);
+  const unsigned e0 = (unsigned)(tid >> 2) * (unsigned)P.lrest + 4u * (tid & 3);      // element offset of unit 0 against the tile base
+  const unsigned estep = (unsigned)(B / 4) * (unsigned)P.lrest;
+  const char* const inb = reinterpret_cast<const char*>(reinterpret_cast<const float*>(io.in) + tbase);
+  const char* const oldb = reinterpret_cast<const char*>(io.old + tbase);
+  char* const outb = reinterpret_cast<char*>(io.out + tbase);
+  const bool need_old = io.resid != nullptr;
+  float4 v[EPT4];
+#pragma unroll
+  for (int k = 0; k < EPT4; ++k) {
+    const bool rowok = !PART4 || tid + k * B < Geo::UNITS4;
+    v[k] = *reinterpret_cast<const float4*>(inb + (rowok ? e0 + k * estep : e0) * 4u);
+  }
+  QFrag<N> q;
+  q.load(P.Qx, lane);
+#pragma unroll
+  for (int k = 0; k < EPT4; ++k) {
+    const int u = tid + k * B;
+    if (!PART4 || u < Geo::UNITS4) {
+      *reinterpret_cast<v2d*>(lds + 4 * u) = (v2d){(double)v[k].x, (double)v[k].y};
+      *reinterpret_cast<v2d*>(lds + 4 * u + 2) = (v2d){(double)v[k].z, (double)v[k].w};
+    }
+  }
+  v2d wv[EPT4][2];
+  if (need_old) {
+#pragma unroll
+    for (int k = 0; k < EPT4; ++k) {
+      const bool rowok = !PART4 || tid + k * B < Geo::UNITS4;
+      const char* const pk = oldb + (size_t)(rowok ? e0 + k * estep : e0) * 8u;
+      wv[k][0] = *reinterpret_cast<const v2d*>(pk);
+      wv[k][1] = *reinterpret_cast<const v2d*>(pk + 16);
+    }
+  }
+  const PowLane PT = pow_lane_init(lane);
+  const double unscale = t32_scale_of(io.old[P.ref_off], P.theta, PT, true);
+  __syncthreads();
+  {
+    double* const p0 = lds + li + lk * Geo::LX;
+#pragma unroll
+    for (int j = 0; j < (N + NW - 1) / NW; ++j) { if (N % NW == 0 || wave + j * NW < N) ctile<N, Geo::LX>(p0 + (wave + j * NW) * 16, q); __builtin_amdgcn_sched_barrier(0); }
+  }
+  q.load(P.Qy, lane);
+  __syncthreads();
+  {
+    double* const p0 = lds + li + lk * LINE_R;
+#pragma unroll
+    for (int j = 0; j < (N + NW - 1) / NW; ++j) { if (N % NW == 0 || wave + j * NW < N) ctile<N, LINE_R>(p0 + (wave + j * NW) * Geo::LX, q); __builtin_amdgcn_sched_barrier(0); }
+  }
+  __syncthreads();
+  const char* const a3b = reinterpret_cast<const char*>(P.a3);
+  const unsigned a3x = (unsigned)P.a3x, a3y = (unsigned)P.a3y;
+  unsigned ia3[4];
+  {
+    const long long pos = (long long)chunk * LINE_R + 4 * (tid & 3);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) ia3[j] = (unsigned)(P.out_idx[o] + P.rest_idx[pos + j]);
+  }
+  double rmax = 0.0;
+  bool rnan = false;
+#pragma unroll
+  for (int k = 0; k < EPT4; ++k) {
+    const int u = tid + k * B;
+    const bool rowok = !PART4 || u < Geo::UNITS4;
+    const int row = rowok ? (u >> 2) : 0;
+    const int x = row / N, y = row - x * N;
+    const unsigned ixy = __umul24((unsigned)x, a3x) + __umul24((unsigned)y, a3y);
+    double a3v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) a3v[j] = *reinterpret_cast<const double*>(a3b + (ia3[j] + ixy) * 8u);
+    const v2d s0 = *reinterpret_cast<const v2d*>(lds + 4 * (rowok ? u : tid)), s1 = *reinterpret_cast<const v2d*>(lds + 4 * (rowok ? u : tid) + 2);
+    const double ksa[2] = {a3v[0] * (s0.x * unscale), a3v[1] * (s0.y * unscale)};
+    const double ksb[2] = {a3v[2] * (s1.x * unscale), a3v[3] * (s1.y * unscale)};
+    double ua[2], ub[2];
+    pow_fast_n<false, 2>(ksa, P.inv_theta, PT, ua);
+    pow_fast_n<false, 2>(ksb, P.inv_theta, PT, ub);
+    const v2d ya = (v2d){1.0 + P.beta * ua[0], 1.0 + P.beta * ua[1]}, yb = (v2d){1.0 + P.beta * ub[0], 1.0 + P.beta * ub[1]};
+    if (rowok) {
+      if (need_old) {
+        const double r0 = fabs(ya.x - wv[k][0].x), r1 = fabs(ya.y - wv[k][0].y), r2 = fabs(yb.x - wv[k][1].x), r3 = fabs(yb.y - wv[k][1].y);
+        rnan |= (r0 != r0) | (r1 != r1) | (r2 != r2) | (r3 != r3);
+        rmax = fmax(fmax(rmax, fmax(r0, r1)), fmax(r2, r3));
+      }
+      char* const pk = outb + (size_t)(e0 + k * estep) * 8u;
+      *reinterpret_cast<v2d*>(pk) = ya;
+      *reinterpret_cast<v2d*>(pk + 16) = yb;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  if (io.resid != nullptr) {
+    if (rnan) rmax = __longlong_as_double(0x7ff0000000000000LL);
+#pragma unroll
+    for (int s = 32; s > 0; s >>= 1) rmax = fmax(rmax, __shfl_xor(rmax, s));
+    if (lane == 0) red[wave] = rmax;
+    __syncthreads();
+    if (tid == 0) {
+      double r = red[0];
+      for (int w = 1; w < NW; ++w) r = fmax(r, red[w]);
+      atomicMax(io.resid, (unsigned long long)__double_as_longlong(r));
+    }
+  }
+}
+
 #ifndef SDFS_NO_VARIANT_TABLES
 // whole chunks only (lrest % 16 == 0); fp64 streams
 template <int N> struct StreamGeo {
@@ -341,6 +468,15 @@ inline line_fn line_stream_variant(int n, int mode) {
   }
 }
 inline int line_stream_wpc_mid(int n) { return n == 32 ? 1 : 2; }
+inline line_fn line_tlast32_variant(int n) {
+  switch (n) {
+    case 16: return (line_fn)line_tlast32_kernel<16, 3>;
+    case 20: return (line_fn)line_tlast32_kernel<20, 3>;
+    case 24: return (line_fn)line_tlast32_kernel<24, 2>;
+    case 32: return (line_fn)line_tlast32_kernel<32, 1>;
+    default: return nullptr;
+  }
+}
 #endif
 
 }  // namespace sdfs

@@ -346,3 +346,35 @@ def test_streamed_line_passes_match_plain_ones(S, shapes):
     assert np.max(np.abs(xs - xp)) < 1e-9
     for T in (Ts, Tp, Tsu, Tpu):
         T.close()
+
+
+@pytest.mark.parametrize("shapes", [(16,) * 6, (20, 20, 16, 16, 16, 16), (16, 16, 24, 24), (32, 32, 16, 16)])
+def test_sa_with_fp32_intermediates(S, shapes):
+    """BASELINE config 5 for the T passes (opts.t_f32; new work, the reference is fp64 only): phase A applies T with
+    the intermediates between its passes stored as scaled floats, phase B finishes in fp64.  One application differs
+    from the fp64 one by the rounding of two stored floats divided by |theta| (tolerance here: 2e-8 relative); the
+    converged iterate satisfies the fp64 stopping rule and sits within tol / (1 - modulus) of the all-fp64 result."""
+    model = "gcy" if len(shapes) == 6 else "ssy"
+    m = S.GCY() if model == "gcy" else S.SSY()
+    arr = (S.discretize_gcy if model == "gcy" else S.discretize_ssy)(m, shapes)
+    with plan_env("pair"):
+        T = S.KoopmansOperator(model, shapes, m.params, arr)
+    w = wbench(shapes, seed=31)
+    want = T(w)
+    x1, n1, i1 = T.solve(w, "successive_approx", tol=0.0, max_iter=1, t_f32=1)
+    assert n1 == 1
+    rel = np.max(np.abs(x1 - want) / want)
+    assert 0.0 < rel < 2e-8, rel
+    assert abs(i1["final_err"] - T.residual()) <= 1e-6 * T.residual()
+    w0 = np.full(shapes, 800.0)
+    tol = 1e-7
+    xa, na, ia = T.solve(w0, "successive_approx", tol=tol, t_f32=1, record_errors=True)
+    xb, nb, ib = T.solve(w0, "successive_approx", tol=tol)
+    assert ia["status"] == 0 and ia["final_err"] <= tol
+    assert len(ia["errors"]) == na
+    assert np.max(np.abs(T(xa) - xa)) <= tol * 1.001                      # the fp64 rule holds at the result
+    # (the rounding noise of phase A, accumulated over 1 / (1 - modulus) iterations, costs phase B a few per cent more
+    # iterations at theta = -16; none at theta = -36)
+    assert abs(na - nb) <= max(20, nb // 12), (na, nb)
+    assert np.max(np.abs(xa - xb)) < 1e-3 * 1.0, np.max(np.abs(xa - xb))      # both within tol / (1 - modulus) ~ 1e-4 of the fixed point
+    T.close()
