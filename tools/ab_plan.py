@@ -18,6 +18,9 @@ VARIANTS = {
     "stream 0 (plain line kernels)": {"SDFS_LINE_STREAM": "0"},
     "stream 1 (middle only)": {"SDFS_LINE_STREAM": "1"},
     "stream 2 (last only)": {"SDFS_LINE_STREAM": "2"},
+    "stream 7 (both, every extent)": {"SDFS_LINE_STREAM": "7"},
+    "stream 5 (middle, every extent)": {"SDFS_LINE_STREAM": "5"},
+    "stream 6 (last, every extent)": {"SDFS_LINE_STREAM": "6"},
     "pair o1 p2": {"SDFS_LINE_PERSIST": "2"},
     "pair o1 p3": {"SDFS_LINE_PERSIST": "3"},
     "pair o0 p2": {"SDFS_PAIR_ORDER": "0"},
