@@ -99,7 +99,8 @@ typedef double v4d __attribute__((ext_vector_type(4)));
 // Absolute error of y*log2 x stays below ~2^-58 |y|, i.e. ~1 ulp of the result for
 // |y| <= 64 (theta = -16, -36 here); tests/test_hip_parity.py checks it against long double.
 // The tables live one entry per lane in registers and are gathered with ds_bpermute
-// (no LDS memory, no bank conflicts): EVERY lane of the wave must be active at a call.
+// (no LDS memory, no bank conflicts): EVERY lane of the wave must be active at a call.  Six gathers per power since
+// round 3 (1/c and the low log part have a zero low word; eight before): the LDS pipe was busy 68 % of the first pass.
 // Inputs outside the fast range (x <= 0, NaN, Inf, subnormal, overflow/underflow) take libm pow().
 struct PowLane { double invc, lchi, lclo, e2t; };
 
@@ -113,6 +114,10 @@ __device__ __forceinline__ double gather64(double v, int idx) {
   const int lo = __builtin_amdgcn_ds_bpermute(idx << 2, __double2loint(v));
   const int hi = __builtin_amdgcn_ds_bpermute(idx << 2, __double2hiint(v));
   return __hiloint2double(hi, lo);
+}
+// table entries whose low word is zero by construction (POW_INVC, POW_LOGC_LO: tools/gen_pow_tables.py): one gather
+__device__ __forceinline__ double gather_hi(double v, int idx) {
+  return __hiloint2double(__builtin_amdgcn_ds_bpermute(idx << 2, __double2hiint(v)), 0);
 }
 
 // d = a * b + c with the constant c held in an SGPR pair.  gfx950 VOP3 takes no literal, so a plain
@@ -137,14 +142,14 @@ __device__ __forceinline__ double pow_core(double x, double y, const PowLane& T)
   const int i = (int)((tmp >> 46) & 63);
   const double kd = (double)((int)((long long)tmp >> 52) - (tiny ? 64 : 0));
   const double z = __longlong_as_double((long long)(ix - (tmp & 0xfff0000000000000ULL)));
-  const double invc = gather64(T.invc, i);
+  const double invc = gather_hi(T.invc, i);
   const double lchi = gather64(T.lchi, i);
   const double r = fma(z, invc, -1.0);
   const double t1 = kd + lchi;                         // exact: lchi is a multiple of 2^-40, |kd| < 2^12
   double q = fma_sc(r, POW_L10, POW_L9);
   q = fma_sc(q, r, POW_L8); q = fma_sc(q, r, POW_L7); q = fma_sc(q, r, POW_L6);
   q = fma_sc(q, r, POW_L5); q = fma_sc(q, r, POW_L4); q = fma_sc(q, r, POW_L3); q = fma_sc(q, r, POW_L2);
-  const double lclo = gather64(T.lclo, i);
+  const double lclo = gather_hi(T.lclo, i);
   double ehi, elo;
   if (HIPREC) {
     const double p1 = r * POW_INVLN2_HI;
@@ -210,6 +215,9 @@ __device__ __forceinline__ double gather64b(double v, int byte_idx) {
   const int hi = __builtin_amdgcn_ds_bpermute(byte_idx, __double2hiint(v));
   return __hiloint2double(hi, lo);
 }
+__device__ __forceinline__ double gather_hib(double v, int byte_idx) {      // low word zero by construction
+  return __hiloint2double(__builtin_amdgcn_ds_bpermute(byte_idx, __double2hiint(v)), 0);
+}
 // pow_fast_try: the straight-line path alone.  Returns (per lane) whether any of its N inputs needs the
 // full routine; `ehi` is y log2 x as the fast path saw it (the caller's fix-up test).
 template <bool HIPREC, int N>
@@ -231,9 +239,9 @@ __device__ __forceinline__ bool pow_fast_try(const double (&x)[N], double y, con
     kd[j] = (double)(tmph >> 20);
     z[j] = __hiloint2double(hx - (tmph & (int)0xfff00000), __double2loint(x[j]));
   }
-  SDFS_FORJ invc[j] = gather64b(T.invc, i4[j]);
+  SDFS_FORJ invc[j] = gather_hib(T.invc, i4[j]);
   SDFS_FORJ lchi[j] = gather64b(T.lchi, i4[j]);
-  SDFS_FORJ lclo[j] = gather64b(T.lclo, i4[j]);
+  SDFS_FORJ lclo[j] = gather_hib(T.lclo, i4[j]);
   SDFS_FORJ r[j] = fma(z[j], invc[j], -1.0);
   SDFS_FORJ t1[j] = kd[j] + lchi[j];                 // exact: lchi is a multiple of 2^-40, |kd| < 2^11
   if (HIPREC) {
