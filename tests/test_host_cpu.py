@@ -36,7 +36,8 @@ def test_opts_struct_layout_and_defaults():
     o = _lib.default_opts()
     assert (o.tol, o.max_iter, o.inner_rtol, o.inner_atol) == (1e-7, 1000000, 1e-5, 1e-4)
     assert (o.history, o.mixing_freq, o.beta, o.ridge) == (10, 4, 8.0, 1e-6)
-    assert ctypes.sizeof(_lib.sdfs_opts) == 80
+    assert (o.krylov_f32, o.t_f32) == (0, 0)
+    assert ctypes.sizeof(_lib.sdfs_opts) == 88          # round 3: + t_f32 (and padding to 8)
 
 
 def test_no_gpu_fails_loudly():
