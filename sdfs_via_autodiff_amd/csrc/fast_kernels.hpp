@@ -388,6 +388,9 @@ struct LineDesc {
   int a3x, a3y;
   int minus_identity;
   long long ref_off;        // C-order offset of the mid-grid point (fp32 linearisation scale)
+  // a3 as two small tables where it factorises (build_fast_plan): a3 = f1[o * n + x] * f2[o * lrest + position]; else null
+  const double* f1;
+  const double* f2;
 };
 
 struct LineIO {

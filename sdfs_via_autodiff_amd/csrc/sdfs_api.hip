@@ -111,6 +111,7 @@ struct Knobs {
   int small_wpt = 0;           // SDFS_SMALL_WPT: force its waves per tile (1 or 4)
   int no_bicg_merge = 0;       // SDFS_NO_BICG_MERGE: 1 = BiCGSTAB keeps its finishing kernels as launches of their own on small grids too
   int and_host = 0;            // SDFS_AND_HOST: 1 = Anderson with the Gram solve on the host (one synchronisation per iteration)
+  int a3_tables = 1;           // SDFS_A3_TABLES: 0 = the streamed last pass gathers a3 even where it factorises into two small tables
   int sa_fused = -1;           // SDFS_SA_FUSED: 0 = successive approximation keeps one launch per pass; 1 = fused end + start kernels;
                                // default (-1): fused, except on the 6-D pair plan when its line passes run the streamed forms
                                // (three streamed launches, 0.805 ms at GCY 20^6, beat slices + fused lines, 0.83 ms)
@@ -156,6 +157,7 @@ struct sdfs_handle {
 
   // Newton-Krylov with fp32 Krylov vectors / J.v streams (opts.krylov_f32); set while such a solve runs
   bool krylov_f32 = false;
+  std::vector<double> a3_host;       // host copy of the a3 table (the pair plan looks for its two-table form)
   bool t32_active = false;           // successive approximation, opts.t_f32: T applications keep their intermediates as scaled floats
   bool krylov_bf16 = false;          // ... with every store of those fp32 containers rounded to bfloat16 (opts.krylov_f32 = 2: bf16r, vec_kernels.hpp)
   double lin_ref = 0.0;              // sharded handles: reference value of the fp32 linearisation scale (sdfs_set_krylov_f32)
@@ -264,6 +266,7 @@ Knobs read_knobs() {
   k.pair_order = env_int("SDFS_PAIR_ORDER", 1);
   k.line_persist = env_int("SDFS_LINE_PERSIST", 0);
   k.line_stream = env_int("SDFS_LINE_STREAM", 3);
+  k.a3_tables = env_int("SDFS_A3_TABLES", 1);
   k.small_plan = env_int("SDFS_SMALL_PLAN", 1);
   k.small_r = env_int("SDFS_SMALL_R", 0);
   k.sa_fused = env_int("SDFS_SA_FUSED", -1);
@@ -808,6 +811,37 @@ int build_fast_plan(sdfs_handle* h) {
     int rc;
     if ((rc = upload_ints(h, outv, &od)) || (rc = upload_ints(h, restv, &rd))) return rc;
     P.ld.a3 = h->a3; P.ld.out_idx = od; P.ld.rest_idx = rd;
+    // The aggregator's scale as two small tables (lever iii): for Rouwenhorst / Tauchen grids of the
+    // GCY model z_states = sigma_z[h_z] g[z] + m[h_zpi, z_pi], so a3 = exp((1 - gamma)(mu_c + z_states)) is, for every
+    // outer index o of this pass, a product F1[o][x] * F2[o][position behind Y] (and does not depend on Y).  Checked
+    // entry by entry; where it holds the last pass reads 20 doubles and one 16-byte piece per tile instead of two
+    // gathers and their index arithmetic per unit (stream_kernels.hpp, A3F).  The product differs from the table by
+    // its own rounding (tolerance 64 ulp here; |theta| times less on T w).
+    if (!h->a3_host.empty() && h->ax[a + 1].a3s == 0 && P.ld.lrest % LINE_R == 0) {
+      const long long no_ = P.ld.nouter, lr = P.ld.lrest;
+      const int n = P.n, a3x = h->ax[a].a3s;
+      std::vector<double> f1((size_t)(no_ * n)), f2((size_t)(no_ * lr));
+      bool ok = true;
+      const double tol = 64.0 * 2.220446049250313e-16;
+      for (long long o = 0; o < no_ && ok; ++o) {
+        const double* M = h->a3_host.data() + outv[(size_t)o];
+        const double piv = M[restv[0]];
+        if (!(piv > 0.0) || !std::isfinite(piv)) { ok = false; break; }
+        for (int x = 0; x < n; ++x) f1[(size_t)(o * n + x)] = M[(long long)x * a3x + restv[0]];
+        for (long long q = 0; q < lr; ++q) f2[(size_t)(o * lr + q)] = M[restv[(size_t)q]] / piv;
+        for (int x = 0; x < n && ok; ++x)
+          for (long long q = 0; q < lr; ++q) {
+            const double want = M[(long long)x * a3x + restv[(size_t)q]];
+            const double got = f1[(size_t)(o * n + x)] * f2[(size_t)(o * lr + q)];
+            if (!(std::fabs(got - want) <= tol * std::fabs(want))) { ok = false; break; }
+          }
+      }
+      if (ok) {
+        double *d1 = nullptr, *d2 = nullptr;
+        if ((rc = upload(h, &d1, f1.data(), f1.size())) || (rc = upload(h, &d2, f2.data(), f2.size()))) return rc;
+        P.ld.f1 = d1; P.ld.f2 = d2;
+      }
+    }
   }
   // dynamic LDS above 64 KB has to be allowed per kernel variant
   for (const FastPass& P : passes) {
@@ -843,8 +877,8 @@ int build_fast_plan(sdfs_handle* h) {
     }
     P.stream = P.line && P.ld.lrest % LINE_R == 0 && (h->knobs.line_stream & 3) != 0 && ((h->knobs.line_stream & 4) != 0 || P.n == 20);
     if (!P.stream) continue;
-    for (int m : {(int)L_MID, (int)L_TLAST, (int)L_TLAST_LIN}) {
-      line_fn f = line_stream_variant(P.n, m);
+    for (int m : {(int)L_MID, (int)L_TLAST, (int)L_TLAST_LIN}) for (int a3f = 0; a3f < 2; ++a3f) {
+      line_fn f = line_stream_variant(P.n, m, a3f != 0);
       if (!f) return 0;
       hipFuncSetAttribute((const void*)f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)line_lds_bytes(P.n));
     }
@@ -1053,7 +1087,7 @@ int run_fast_plan(sdfs_handle* h, int mode, const double* in, double* out, const
         bytes -= last ? 0.5 * n8 : n8;
       } else if (P.stream && !lf32 && ((lm == L_MID && (h->knobs.line_stream & 1)) || ((lm == L_TLAST || lm == L_TLAST_LIN) && (h->knobs.line_stream & 2)))) {
         // stream_kernels.hpp: persistent middle pass with the next tile in flight; last pass with its side stream loaded early
-        fn = line_stream_variant(P.n, lm);
+        fn = line_stream_variant(P.n, lm, d.f1 != nullptr && h->knobs.a3_tables != 0);
         grid = lm == L_MID ? stream_mid_grid(h, P) : (unsigned)d.ntiles;
       }
       if (!fn) return fail(h, SDFS_ERR_UNSUPPORTED, "no line kernel variant");
@@ -1928,6 +1962,7 @@ int setup_model(sdfs_handle* h, int model, int ndim, const int64_t* shapes, cons
     }
     if (z_same) {
       if ((rc = upload(h, &h->a3, a3.data(), a3.size()))) return rc;
+      h->a3_host = a3;
       h->ax[2].a3s = nj; h->ax[3].a3s = 1;            // a3[i, j]
     } else {
       h->ax[3].qs[2] = 1;               // z_Q[i, j, J] conditioned on the current h_z index
@@ -1972,6 +2007,7 @@ int setup_model(sdfs_handle* h, int model, int ndim, const int64_t* shapes, cons
     }
     if (z_same) {
       if ((rc = upload(h, &h->a3, a3.data(), a3.size()))) return rc;
+      h->a3_host = a3;
       h->ax[0].a3s = 1; h->ax[4].a3s = (int)na; h->ax[2].a3s = (int)(ne * na); h->ax[1].a3s = (int)(nc * ne * na);  // a3[b,c,e,a]
     } else {
       // z_Q[b, c, e, a, A]: conditioned on current (z_pi, h_z, h_zpi)

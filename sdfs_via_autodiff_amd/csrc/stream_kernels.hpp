@@ -99,7 +99,9 @@ __device__ __forceinline__ void line_tile_load(v2d (&v)[EPT], const double* base
 // B = threads per workgroup (a multiple of 64; the column tiles of a contraction go round the B / 64 waves).
 // PERSIST = false: one tile per workgroup (grid = ntiles, XCD-contiguous order), no next-tile prefetch, one Q fragment
 // set at a time -- the OLDPF side-stream load on its own, at a register budget that admits three workgroups per CU.
-template <int N, int MODE, int WPC, bool OLDPF = false, int B = LineGeo<N>::B, bool PERSIST = true>
+// A3F (one tile per workgroup): the aggregator's scale from the two small tables of LineDesc::f1 / f2 -- 20 doubles per
+// tile through LDS and one 16-byte piece per thread -- instead of two gathers and their index arithmetic per unit.
+template <int N, int MODE, int WPC, bool OLDPF = false, int B = LineGeo<N>::B, bool PERSIST = true, bool A3F = false>
 __global__ void __launch_bounds__(B, WPC * B / 256)
 line_stream_kernel(const LineDesc P, const LineIO io) {
   using Geo = LineGeo<N>;
@@ -109,9 +111,11 @@ line_stream_kernel(const LineDesc P, const LineIO io) {
   constexpr bool LINE = MODE == L_TLAST_LIN;
   constexpr bool MULE = MODE == L_JLAST;
   constexpr bool PARTIAL = Geo::UNITS % B != 0;
-  static_assert(MODE != L_TFUSED, "see line_fused_stream_kernel");
+  static_assert(MODE != L_TFUSED, "the fused end + start form stays with line_kernel");
+  static_assert(!A3F || (CES && !PERSIST), "two-table a3: the last pass of T, one tile per workgroup");
   extern __shared__ double lds[];
   __shared__ double red[16];
+  __shared__ double sF1[A3F ? 32 : 1];
   if (io.gate != nullptr) {
     const unsigned long long g = *io.gate;
     if (g <= (unsigned long long)__double_as_longlong(io.gate_tol)) return;
@@ -162,6 +166,11 @@ line_stream_kernel(const LineDesc P, const LineIO io) {
       const bool has_next = PERSIST && nxt != NO_TILE;            // uniform over the workgroup
       unsigned o; int chunk;
       const long long tbase = line_tile_base(P, cur, N * N, o, chunk);
+      v2d f2v = (v2d){1.0, 1.0};
+      if constexpr (A3F) {
+        if (tid < N) sF1[tid] = P.f1[(long long)o * N + tid];      // (read behind this tile's barriers)
+        f2v = *reinterpret_cast<const v2d*>(P.f2 + (long long)o * P.lrest + (long long)chunk * LINE_R + 2 * c2);
+      }
       if constexpr (OLDPF) { if (need_old) line_tile_load<EPT, B, Geo::UNITS>(wv, io.old + tbase, tid, b0, bstep); }
       unsigned o1; int ch1;
       const char* const nxb = reinterpret_cast<const char*>(io.in + line_tile_base(P, has_next ? nxt : cur, N * N, o1, ch1));
@@ -205,7 +214,7 @@ line_stream_kernel(const LineDesc P, const LineIO io) {
         const char* const auxb = reinterpret_cast<const char*>(io.aux_in + tbase);
         char* const auxo = reinterpret_cast<char*>(io.aux_out + tbase);
         unsigned ia3a = 0u, ia3b = 0u;
-        if (CES) {
+        if (CES && !A3F) {
           const long long pos = (long long)chunk * LINE_R + 2 * c2;
           ia3a = (unsigned)(P.out_idx[o] + P.rest_idx[pos]);
           ia3b = (unsigned)(P.out_idx[o] + P.rest_idx[pos + 1]);
@@ -216,7 +225,11 @@ line_stream_kernel(const LineDesc P, const LineIO io) {
           const bool rowok = k < EPT && (!PARTIAL || u < Geo::UNITS);
           const unsigned offc = rowok ? b0 + (unsigned)k * bstep : b0;
           if (!OLDPF && need_old) s1 = *reinterpret_cast<const double2*>(oldb + offc);
-          if (CES) {
+          if (CES && A3F) {
+            const int row = rowok ? (u >> 3) : 0;
+            const double fx = sF1[row / N];
+            s2 = make_double2(fx * f2v.x, fx * f2v.y);
+          } else if (CES) {
             const int row = rowok ? (u >> 3) : 0;
             const int x = row / N, y = row - x * N;
             const unsigned ixy = __umul24((unsigned)x, a3x) + __umul24((unsigned)y, a3y);
@@ -449,6 +462,14 @@ template <int N> struct StreamGeo {
   static constexpr int WPC_MID = N == 32 ? 1 : 2;                       // persistent middle pass: workgroups per CU launched
   static constexpr int WPC_LAST = N == 16 ? 3 : LineGeo<N>::BPC;        // one tile per workgroup: register budget of the last pass
 };
+template <int N> inline line_fn line_stream_variant_a3f_n(int mode) {
+  using G = StreamGeo<N>;
+  switch (mode) {
+    case L_TLAST: return (line_fn)line_stream_kernel<N, L_TLAST, G::WPC_LAST, true, G::B, false, true>;
+    case L_TLAST_LIN: return (line_fn)line_stream_kernel<N, L_TLAST_LIN, G::WPC_LAST, true, G::B, false, true>;
+    default: return nullptr;
+  }
+}
 template <int N> inline line_fn line_stream_variant_n(int mode) {
   using G = StreamGeo<N>;
   switch (mode) {
@@ -458,7 +479,17 @@ template <int N> inline line_fn line_stream_variant_n(int mode) {
     default: return nullptr;
   }
 }
-inline line_fn line_stream_variant(int n, int mode) {
+// a3f: LineDesc::f1 / f2 are set (the aggregator's scale factorises for this pass)
+inline line_fn line_stream_variant(int n, int mode, bool a3f = false) {
+  if (a3f && (mode == L_TLAST || mode == L_TLAST_LIN)) {
+    switch (n) {
+      case 16: return line_stream_variant_a3f_n<16>(mode);
+      case 20: return line_stream_variant_a3f_n<20>(mode);
+      case 24: return line_stream_variant_a3f_n<24>(mode);
+      case 32: return line_stream_variant_a3f_n<32>(mode);
+      default: return nullptr;
+    }
+  }
   switch (n) {
     case 16: return line_stream_variant_n<16>(mode);
     case 20: return line_stream_variant_n<20>(mode);

@@ -15,6 +15,7 @@ import sdfs_via_autodiff_amd as S  # noqa: E402
 
 VARIANTS = {
     "pair o1 p0 (default)": {},
+    "a3 gathers (SDFS_A3_TABLES=0)": {"SDFS_A3_TABLES": "0"},
     "stream 0 (plain line kernels)": {"SDFS_LINE_STREAM": "0"},
     "stream 1 (middle only)": {"SDFS_LINE_STREAM": "1"},
     "stream 2 (last only)": {"SDFS_LINE_STREAM": "2"},
