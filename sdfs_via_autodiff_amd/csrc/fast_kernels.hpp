@@ -388,7 +388,9 @@ struct LineDesc {
   int a3x, a3y;
   int minus_identity;
   long long ref_off;        // C-order offset of the mid-grid point (fp32 linearisation scale)
-  // a3 as two small tables where it factorises (build_fast_plan): a3 = f1[o * n + x] * f2[o * lrest + position]; else null
+  // a3 as two small tables where it factorises (build_fast_plan): a3 = f1[o * n + x] * f2[o * lrest + position]; else null.
+  // Read by the streamed last pass (stream_kernels.hpp, A3F).  The same form as a run-time branch in line_kernel's own
+  // epilogue lost at GCY 16^6 (last pass 0.0905 against 0.0863 ms): that kernel stays with the gathers.
   const double* f1;
   const double* f2;
 };

@@ -1070,6 +1070,7 @@ int run_fast_plan(sdfs_handle* h, int mode, const double* in, double* out, const
       io.sched = h->sched + SCHED_WORDS * i;
       LineDesc d = P.ld;
       d.minus_identity = minus_identity;
+      if (h->knobs.a3_tables == 0) { d.f1 = nullptr; d.f2 = nullptr; }
       if (vjp) { d.Qx = h->ax[P.ax0].Qt; d.Qy = h->ax[P.ax1].Qt; }
       int lm = L_MID;
       if (last) {
@@ -1087,7 +1088,7 @@ int run_fast_plan(sdfs_handle* h, int mode, const double* in, double* out, const
         bytes -= last ? 0.5 * n8 : n8;
       } else if (P.stream && !lf32 && ((lm == L_MID && (h->knobs.line_stream & 1)) || ((lm == L_TLAST || lm == L_TLAST_LIN) && (h->knobs.line_stream & 2)))) {
         // stream_kernels.hpp: persistent middle pass with the next tile in flight; last pass with its side stream loaded early
-        fn = line_stream_variant(P.n, lm, d.f1 != nullptr && h->knobs.a3_tables != 0);
+        fn = line_stream_variant(P.n, lm, d.f1 != nullptr);
         grid = lm == L_MID ? stream_mid_grid(h, P) : (unsigned)d.ntiles;
       }
       if (!fn) return fail(h, SDFS_ERR_UNSUPPORTED, "no line kernel variant");
@@ -1227,6 +1228,7 @@ int big_sa_line(sdfs_handle* h, int pass, bool first_only, const double* in, dou
   io.sched = h->sched + SCHED_WORDS * pass;
   LineDesc d = P.ld;
   d.first_only = first_only ? 1 : 0;
+  if (h->knobs.a3_tables == 0) { d.f1 = nullptr; d.f2 = nullptr; }
   line_fn fn = line_variant(P.n, L_TFUSED, false, P.ld.lrest % LINE_R == 0);
   if (!fn) return fail(h, SDFS_ERR_UNSUPPORTED, "no fused line kernel variant");
   int cid = -1;
