@@ -63,7 +63,7 @@ def cpu_baseline(model, shapes, params, arrays, w_host, budget_s=12.0):
             break
     # the port makes D axis sweeps and two power sweeps, each reading and writing the grid once (16 B / point)
     sweep_bytes = 16.0 * (len(shapes) + 2) * float(np.prod(shapes))
-    return {"value": n / dt, "unit": "iterations/s", "cores": num_threads(), "kind": "port",
+    return {"value": n / dt, "unit": "iterations/s", "cores": num_threads(), "host_cpu_count": os.cpu_count(), "kind": "port",
             "sample": f"{n} applications of T on the same {'x'.join(map(str, shapes))} grid "
                       f"(oracle/c/wc_oracle.c, factorised, OpenMP), {dt:.1f} s",
             "dram_GBps_of_its_own_sweeps": sweep_bytes * n / dt / 1e9}

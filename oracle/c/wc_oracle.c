@@ -173,6 +173,16 @@ int wc_oracle_apply(int D, const int64_t* n, const int* order, const double* con
   return 0;
 }
 
+/* the CPU baseline runs on the cores this process may actually use (a container's CPU quota can be far below the
+ * machine's core count, and 128 threads on a 16-core quota only fight each other) */
+void wc_oracle_set_threads(int n) {
+#ifdef _OPENMP
+  if (n >= 1) omp_set_num_threads(n);
+#else
+  (void)n;
+#endif
+}
+
 int wc_oracle_num_threads(void) {
 #ifdef _OPENMP
   return omp_get_max_threads();

@@ -18,6 +18,25 @@ _SO = os.path.join(_DIR, "libwc_oracle.so")
 _lib = None
 
 
+def usable_cores():
+    """Cores this process may use: the affinity mask, cut down to the cgroup CPU quota if there is one (v2:
+    /sys/fs/cgroup/cpu.max "quota period"; v1: cpu.cfs_quota_us / cpu.cfs_period_us; "max" / -1 = no quota)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(per))))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // per))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
 def _load():
     global _lib
     if _lib is None:
@@ -26,6 +45,8 @@ def _load():
         _lib = C.CDLL(_SO)
         _lib.wc_oracle_apply.restype = C.c_int
         _lib.wc_oracle_num_threads.restype = C.c_int
+        if "OMP_NUM_THREADS" not in os.environ and hasattr(_lib, "wc_oracle_set_threads"):
+            _lib.wc_oracle_set_threads(C.c_int(usable_cores()))
     return _lib
 
 
