@@ -1644,8 +1644,8 @@ int solve_newton(sdfs_handle* h, const sdfs_opts& o, double* w, int64_t* n_iter,
     // storage at inner_rtol 1e-2: "converged" 352 away from the fixed point).  Such a step did nothing: in reduced
     // storage it is redone in fp64 like an overflowed one; in fp64 the solve ends with a numeric error.  (A zero step
     // because |g|_2 <= inner_atol is the reference's own rule and stays.)
-    // (a NaN right-hand side closes the solve's gate at once: also a zero step)
-    const bool broke = err == 0.0 && (h->sc_host[SC_BREAK] != 0.0 || !(h->sc_host[SC_BB] == h->sc_host[SC_BB]));
+    // (a NaN or infinite right-hand side -- an iterate that left the domain -- closes the solve's gate at once: also a zero step)
+    const bool broke = err == 0.0 && (h->sc_host[SC_BREAK] != 0.0 || !std::isfinite(h->sc_host[SC_BB]));
     if (broke && !h->krylov_f32) { status = SDFS_ERR_NUMERIC; ++it; break; }
     if ((!std::isfinite(err) || broke) && h->krylov_f32) {
       HIPCHK(h, hipMemcpyAsync(x, Tx, nb, hipMemcpyDeviceToDevice, st));
