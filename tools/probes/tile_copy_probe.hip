@@ -144,6 +144,16 @@ int main(int argc, char** argv) {
       run("LT  P3: (a,b|16 of cdef) 3 streams", p, 256, in, in2, out, gb3);
       p.third = 0;
       run("LT  P3: (a,b|16 of cdef) 2 streams", p, 320, in, in2, out, gb2); }
+    // B8: 8-double chunks (64-B rows): half-size line tiles, twice the workgroups per CU (round 3: is a 128-byte line split over
+    // two tiles that run side by side still fetched once?)
+    { Pat p = {400, 20, n3, n2, 8, 3, {20, 20, 50, 1}, {n5, n4, 8, 0}, 20000, 0, sleep};
+      run("LT  P2: (c,d|8 of ef) 64-B rows", p, 256, in, in2, out, gb2);
+      run("LT  P2: (c,d|8 of ef) 64-B rows", p, 128, in, in2, out, gb2);
+      p.third = 1;
+      run("LT  P3: (c,d|8 of ef) 64-B rows, 3 streams", p, 256, in, in2, out, gb3);
+      run("LT  P3: (c,d|8 of ef) 64-B rows, 3 streams", p, 128, in, in2, out, gb3); }
+    { Pat p = {400, 20, n3, n2, 16, 3, {20, 20, 25, 1}, {n5, n4, 16, 0}, 10000, 1, sleep};
+      run("LT  P3: (c,d|16 of ef) 128-B rows, 3 streams", p, 256, in, in2, out, gb3); }
     // B32: 32-double chunks (256-B runs), one block per CU
     { Pat p = {400, 20, n3, n2, 32, 3, {20, 20, 12, 1}, {n5, n4, 32, 0}, 4800, 0, sleep};
       run("LT  P2: (c,d|32 of ef) 256-B runs [partial]", p, 512, in, in2, out, gb2 * 4800 * 12800 / (double)N); }
