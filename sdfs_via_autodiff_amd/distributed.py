@@ -829,10 +829,8 @@ def bench_sharded(S, model, shapes, params, arrays, args, rank, local_rank, worl
         state["k"] = k + 1
         return _w
 
-    op.backend.set_profiling(True)
     for _ in range(max(args.warmup, 2)):
         w = step(w)
-    op.backend.reset_counters()
     x0 = op.n_exchanges
     dist.barrier()
     torch.cuda.synchronize()
@@ -844,8 +842,23 @@ def bench_sharded(S, model, shapes, params, arrays, args, rank, local_rank, worl
     dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
     dist.all_reduce(dt, op=dist.ReduceOp.MAX)
     dt = float(dt.item())
-    counters = op.backend.counters()
-    op.backend.set_profiling(False)
+    n_exch = op.n_exchanges - x0
+    # per-kernel durations of rank 0's stages: a second, shorter loop with HIP events around every launch (the timed
+    # loop above runs without them), both orientations of the mirror schedule
+    backends = [b for b in (op.backend, op.backend_m if mirror else None) if b is not None]
+    for b in backends:
+        b.set_profiling(True)
+    for _ in range(4):
+        w = step(w)
+    torch.cuda.synchronize()
+    for b in backends:
+        b.reset_counters()
+    for _ in range(min(args.steps, 40)):
+        w = step(w)
+    torch.cuda.synchronize()
+    counters = [c for b in backends for c in b.counters()]
+    for b in backends:
+        b.set_profiling(False)
     N = int(np.prod(shapes))
     dom = max(counters, key=lambda c: c["total_ms"])
     avg_ms = dom["total_ms"] / max(dom["launches"], 1)
@@ -862,7 +875,7 @@ def bench_sharded(S, model, shapes, params, arrays, args, rank, local_rank, worl
                                f"(sharded T apply + all-reduced sup-norm residual), default calibration, Rouwenhorst",
                    "grid_points": N, "parallelism": f"grid block-sharded over {world} ranks (axes {op.axis_a} / {op.axis_b}, "
                                                     f"{'mirror schedule' if mirror else 'fixed layout'}), "
-                                                    f"{(op.n_exchanges - x0) / max(args.steps, 1):.2f} all-to-all re-shards + 1 all-reduce "
+                                                    f"{n_exch / max(args.steps, 1):.2f} all-to-all re-shards + 1 all-reduce "
                                                     f"per iteration, backend {dist.get_backend()}",
                    "ranks": world, "ranks_seen": ranks_seen, "backend": dist.get_backend(), "devices_by_rank": devices,
                    "measured_on": "RCCL over xGMI" if dist.get_backend() == "nccl" and len(set(devices)) == world
@@ -873,7 +886,7 @@ def bench_sharded(S, model, shapes, params, arrays, args, rank, local_rank, worl
                      "frac": achieved / 8000.0, "traffic": None,
                      "traffic_source": "PMC counters need rocprofv3; no committed profile of the sharded stage kernels",
                      "avg_launch_ms": avg_ms, "alg_bytes_per_launch": dom["alg_bytes"], "note": "rank 0's local shard"},
-        "exchange": {"per_iteration": (op.n_exchanges - x0) / max(args.steps, 1),
+        "exchange": {"per_iteration": n_exch / max(args.steps, 1),
                      "bytes_sent_per_rank_per_exchange": 8.0 * N / world * (world - 1) / world,
                      "bytes_per_peer_link_per_exchange": 8.0 * N / world / world},
         "last_residual": float(res.item()) if state["have_res"] else None,
