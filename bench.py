@@ -175,7 +175,15 @@ def main():
         raise SystemExit(f"bench.py: --gpus {args.gpus} needs {args.gpus} devices, {ndev} visible")
     local_rank = local_rank % max(ndev, 1)
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    # SDFS_BENCH_SHARDED=1 with --gpus 1: the N > 1 code path (sharded operator, exchanges, all-reduces) on a process
+    # group of one rank -- the only way to run that path on RCCL with one GPU; a rehearsal, labelled as such
+    force_sharded = os.environ.get("SDFS_BENCH_SHARDED", "0") == "1" and world == 1
+    if force_sharded:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29541")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+    if world > 1 or force_sharded:
         import torch.distributed as dist
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
@@ -187,7 +195,7 @@ def main():
     params, arrays = build_model(S, model, shapes)
     N = int(np.prod(shapes))
 
-    if world > 1:
+    if world > 1 or force_sharded:
         from sdfs_via_autodiff_amd.distributed import bench_sharded
         line = bench_sharded(S, model, shapes, params, arrays, args, rank, local_rank, world)
         if rank == 0:

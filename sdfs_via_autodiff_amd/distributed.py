@@ -878,7 +878,7 @@ def bench_sharded(S, model, shapes, params, arrays, args, rank, local_rank, worl
                                                     f"{n_exch / max(args.steps, 1):.2f} all-to-all re-shards + 1 all-reduce "
                                                     f"per iteration, backend {dist.get_backend()}",
                    "ranks": world, "ranks_seen": ranks_seen, "backend": dist.get_backend(), "devices_by_rank": devices,
-                   "measured_on": "RCCL over xGMI" if dist.get_backend() == "nccl" and len(set(devices)) == world
+                   "measured_on": "RCCL over xGMI" if dist.get_backend() == "nccl" and len(set(devices)) == world and world > 1
                                   else "REHEARSAL (not a multi-GPU measurement): ranks share a device or exchange through the host",
                    "shard_sizes": op.a_sizes,
                    "plan_rank0": op.backend.describe_plan().strip().split("\n")},

@@ -103,7 +103,14 @@ def main():
     shapes = tuple(int(x) for x in sys.argv[2].split(","))
     use_hip = sys.argv[3] == "hip"
     plain = len(sys.argv) > 4 and sys.argv[4] == "plain"      # unperturbed Rouwenhorst tensors: slice-merged plans, mirror schedule
-    dist.init_process_group("gloo")
+    # SHARDED_WORKER_PG=nccl: the RCCL code path (list-form all_to_all on views of the pack buffers, device-tensor
+    # all-reduces, ordering against the handle's stream) -- only with one rank per GPU, i.e. world size 1 on a 1-GPU box
+    pg = os.environ.get("SHARDED_WORKER_PG", "gloo")
+    if pg == "nccl":
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
+    else:
+        dist.init_process_group("gloo")
     rank = dist.get_rank()
     out = {}
     try:

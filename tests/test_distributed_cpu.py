@@ -25,12 +25,15 @@ def _free_port():
     return p
 
 
-def run_world2(model, shapes, backend, timeout=240, world=2, plain=False):
+def run_world2(model, shapes, backend, timeout=240, world=2, plain=False, pg=None):
+    env = dict(os.environ)
+    if pg:
+        env["SHARDED_WORKER_PG"] = pg
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
            os.path.join(REPO, "tests", "sharded_worker.py"), model, ",".join(map(str, shapes)), backend] + \
           (["plain"] if plain else [])
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, cwd=REPO)
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, cwd=REPO, env=env)
     lines = [l for l in r.stdout.splitlines() if l.startswith("RESULT ")]
     assert lines, f"no result (rc {r.returncode})\n{r.stdout[-2000:]}\n{r.stderr[-3000:]}"
     out = json.loads(lines[-1][7:])
@@ -135,6 +138,22 @@ def test_sharded_hip_stages_world4_uneven():
     assert out["T"] < 1e-12 and out["Tlin"] < 1e-12 and out["jvp"] < 1e-11, out
     assert out["sizes"] == [[2, 1, 1, 1], [2, 2, 1, 1]]
     assert out["newton_err"] < 1e-8, out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("model,shapes", [("gcy", (4, 3, 2, 5, 3, 6)), ("ssy", (5, 7, 6, 4))])
+def test_sharded_layer_on_rccl_world1(model, shapes):
+    """The "nccl" (= RCCL) branch of the multi-GPU layer has never had more than one GPU to run on.  With a
+    world of ONE rank it still executes on the real backend: init with device_id, the list-form all_to_all on views
+    of the pack / receive buffers, device-tensor all-reduces and their ordering against the handle's stream -- the
+    whole operator, Newton, the gated SA loop (mirror + exact phase) and Anderson.  What it cannot show is a link."""
+    out = run_world2(model, shapes, "hip", timeout=200, world=1, plain=True, pg="nccl")
+    assert out["T"] < 1e-12 and out["Tlin"] < 1e-12 and out["jvp"] < 1e-11, out
+    assert out["resid"] < 1e-8 and out["newton_err"] < 1e-8, out
+    assert out["mirror_ok"]
+    na, no = out["sa_iters"]
+    assert na == no and out["sa_err"] < 1e-8, out
+    check_sa_gating_and_anderson(out)
 
 
 @pytest.mark.gpu
