@@ -225,6 +225,7 @@ slice_kernel(const SliceDesc P, const SliceIO io) {
   constexpr bool MULP = MODE == S_JFIRST;
   constexpr bool JV32 = F32 && MULP;
   static_assert(!T32 || !F32, "S_TFIRST32 is its own storage form");
+  constexpr bool POWREG = MODE == S_TFIRST;                       // the power on the registers, before the tile is parked
   static_assert(!F32 || (MODE != S_TFIRST && MODE != S_MID), "plain T has no fp32 form");
   extern __shared__ double lds[];
   if (io.gate != nullptr) {
@@ -286,10 +287,21 @@ slice_kernel(const SliceDesc P, const SliceIO io) {
       }
     }
     // ---- park the tile in LDS (linear image of the global layout); J.v: x = c1 * v on the way ------------
+    // plain T: w^theta on the registers as they are parked -- one LDS write per unit instead of write + read + write
+    // (unrolled: EPT copies of the power routine; the LDS pipe is this pass's second bottleneck: 0.262 -> 0.254 ms at
+    // GCY 20^6, tools/probes/kernel_bench.hip).  The linearising and fp32-intermediate forms keep the rolled loop below.
+    PowLane PTr;
+    if (POWREG) PTr = pow_lane_init(lane);
 #pragma unroll
     for (int k = 0; k < Geo::EPT; ++k) {
       const int u = lane + 64 * k;
       if (MULP) { v[k].x *= c1v[MULP ? k : 0].x; v[k].y *= c1v[MULP ? k : 0].y; }
+      if (POWREG) {
+        const double xin[2] = {v[k].x, v[k].y};       // (masked lanes were loaded as 1)
+        double xw[2];
+        pow_fast_n<true, 2>(xin, P.theta, PTr, xw);
+        v[k] = make_double2(xw[0], xw[1]);
+      }
       if (Geo::UNITS % 64 == 0 || u < Geo::UNITS) *reinterpret_cast<double2*>(wl + 2 * u) = v[k];
     }
   }
@@ -297,7 +309,7 @@ slice_kernel(const SliceDesc P, const SliceIO io) {
   qf.load(P.Qf, lane);
   wave_lds_fence();
   // ---- prologue x = w^theta in place (rolled: one copy of the power routine; every lane stays active) --
-  if (POWP) {
+  if (POWP && !POWREG) {
     const PowLane PT = pow_lane_init(lane);
     double lin_scale = 1.0;
     if (LIN && F32) lin_scale = lin_scale_of(io.in[P.ref_off], P.theta, PT, false);
