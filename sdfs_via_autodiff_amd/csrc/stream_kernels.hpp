@@ -112,10 +112,10 @@ line_stream_kernel(const LineDesc P, const LineIO io) {
   constexpr bool MULE = MODE == L_JLAST;
   constexpr bool PARTIAL = Geo::UNITS % B != 0;
   static_assert(MODE != L_TFUSED, "the fused end + start form stays with line_kernel");
-  static_assert(!A3F || (CES && !PERSIST), "two-table a3: the last pass of T, one tile per workgroup");
+  static_assert(!A3F || CES, "two-table a3: the last pass of T");
   extern __shared__ double lds[];
   __shared__ double red[16];
-  __shared__ double sF1[A3F ? 32 : 1];
+  __shared__ double sF1[A3F ? 64 : 1];       // two halves: a persistent workgroup fills the next tile's while the last one is read
   if (io.gate != nullptr) {
     const unsigned long long g = *io.gate;
     if (g <= (unsigned long long)__double_as_longlong(io.gate_tol)) return;
@@ -168,7 +168,7 @@ line_stream_kernel(const LineDesc P, const LineIO io) {
       const long long tbase = line_tile_base(P, cur, N * N, o, chunk);
       v2d f2v = (v2d){1.0, 1.0};
       if constexpr (A3F) {
-        if (tid < N) sF1[tid] = P.f1[(long long)o * N + tid];      // (read behind this tile's barriers)
+        if (tid < N) sF1[32 * par + tid] = P.f1[(long long)o * N + tid];      // (read behind this tile's barriers)
         f2v = *reinterpret_cast<const v2d*>(P.f2 + (long long)o * P.lrest + (long long)chunk * LINE_R + 2 * c2);
       }
       if constexpr (OLDPF) { if (need_old) line_tile_load<EPT, B, Geo::UNITS>(wv, io.old + tbase, tid, b0, bstep); }
@@ -227,7 +227,7 @@ line_stream_kernel(const LineDesc P, const LineIO io) {
           if (!OLDPF && need_old) s1 = *reinterpret_cast<const double2*>(oldb + offc);
           if (CES && A3F) {
             const int row = rowok ? (u >> 3) : 0;
-            const double fx = sF1[row / N];
+            const double fx = sF1[32 * par + row / N];
             s2 = make_double2(fx * f2v.x, fx * f2v.y);
           } else if (CES) {
             const int row = rowok ? (u >> 3) : 0;

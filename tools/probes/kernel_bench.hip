@@ -119,8 +119,12 @@ int main(int argc, char** argv) {
   for (int i = 0; i < 4; ++i) { auto q = mkQ(); CK(hipMalloc(&Q[i], q.size() * 8)); CK(hipMemcpy(Q[i], q.data(), q.size() * 8, hipMemcpyHostToDevice)); }
   const long long n2 = (long long)n * n, n4 = n2 * n2;
   // a3[b, c, e, a] as in GCY: strides a:1, e:n, c:n^2, b:n^3
-  std::vector<double> ha3((size_t)n4);
-  for (auto& x : ha3) x = 0.5 + U(rng);
+  // ... as a product F1[c, a] * F2[e, b], the form the GCY tables have (the last pass's two-table variants read F1 / F2)
+  std::vector<double> hF1((size_t)n2), hF2((size_t)n2), ha3((size_t)n4);
+  for (auto& x : hF1) x = 0.7 + 0.5 * U(rng);
+  for (auto& x : hF2) x = 0.7 + 0.5 * U(rng);
+  for (int b = 0; b < n; ++b) for (int c = 0; c < n; ++c) for (int e = 0; e < n; ++e) for (int a = 0; a < n; ++a)
+    ha3[(size_t)(((b * n + c) * n + e) * n + a)] = hF1[(size_t)(c * n + a)] * hF2[(size_t)(e * n + b)];
   CK(hipMalloc(&a3, n4 * 8)); CK(hipMemcpy(a3, ha3.data(), n4 * 8, hipMemcpyHostToDevice));
   const double theta = -36.03, beta = 0.998;
   unsigned long long* resid; CK(hipMalloc(&resid, 8));
@@ -158,6 +162,17 @@ int main(int argc, char** argv) {
     int *od, *rd; CK(hipMalloc(&od, outv.size() * 4)); CK(hipMalloc(&rd, restv.size() * 4));
     CK(hipMemcpy(od, outv.data(), outv.size() * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(rd, restv.data(), restv.size() * 4, hipMemcpyHostToDevice));
     L.a3 = a3; L.out_idx = od; L.rest_idx = rd;
+    if (ax0 == 2) {                    // pair (c, d): outer o = a * n + b, x = c, position = e * n + f
+      std::vector<double> f1((size_t)(L.nouter * n)), f2((size_t)(L.nouter * L.lrest));
+      for (long long o = 0; o < L.nouter; ++o) {
+        const int a_ = (int)(o / n), b_ = (int)(o % n);
+        for (int x = 0; x < n; ++x) f1[(size_t)(o * n + x)] = hF1[(size_t)(x * n + a_)];
+        for (long long q = 0; q < L.lrest; ++q) f2[(size_t)(o * L.lrest + q)] = hF2[(size_t)((q / n) * n + b_)];
+      }
+      double *d1, *d2; CK(hipMalloc(&d1, f1.size() * 8)); CK(hipMalloc(&d2, f2.size() * 8));
+      CK(hipMemcpy(d1, f1.data(), f1.size() * 8, hipMemcpyHostToDevice)); CK(hipMemcpy(d2, f2.data(), f2.size() * 8, hipMemcpyHostToDevice));
+      L.f1 = d1; L.f2 = d2;
+    }
     return L;
   };
   const size_t llds = line_lds_bytes(n);
@@ -207,6 +222,9 @@ int main(int argc, char** argv) {
     Launch base = line_launch((line_fn)line_kernel<20, L_TLAST, false, true, false>, L3, (unsigned)L3.ntiles, tmpA, outA, w, true);
     add("line_kernel<20,TLAST> pair (c,d) baseline", base, b3, nullptr, nullptr, nullptr);
     add("line_stream<20,TLAST,2> pair (c,d) wgs " + std::to_string(2 * C), line_launch((line_fn)line_stream_kernel<20, L_TLAST, 2>, L3, 2 * C, tmpA, outB, w, true), b3, outB, base, outA);
+    add("line_stream<20,TLAST,3,OLDPF,A3F,nonpersist> pair (c,d)", line_launch((line_fn)line_stream_kernel<20, L_TLAST, 3, true, 256, false, true>, L3, (unsigned)L3.ntiles, tmpA, outB, w, true), b3, outB, base, outA);
+    add("line_stream<20,TLAST,2,OLDPF,A3F,persistent> pair (c,d) wgs " + std::to_string(2 * C), line_launch((line_fn)line_stream_kernel<20, L_TLAST, 2, true, 256, true, true>, L3, 2 * C, tmpA, outB, w, true), b3, outB, base, outA);
+    add("line_stream<20,TLAST,2,A3F,persistent (window)> pair (c,d) wgs " + std::to_string(2 * C), line_launch((line_fn)line_stream_kernel<20, L_TLAST, 2, false, 256, true, true>, L3, 2 * C, tmpA, outB, w, true), b3, outB, base, outA);
     add("line_stream<20,TLAST,3,OLDPF,256,nonpersist> pair (c,d)", line_launch((line_fn)line_stream_kernel<20, L_TLAST, 3, true, 256, false>, L3, (unsigned)L3.ntiles, tmpA, outB, w, true), b3, outB, base, outA);
     add("line_stream<20,TLAST,2,OLDPF,256,nonpersist> pair (c,d)", line_launch((line_fn)line_stream_kernel<20, L_TLAST, 2, true, 256, false>, L3, (unsigned)L3.ntiles, tmpA, outB, w, true), b3, outB, base, outA);
     add("line_stream<20,TLAST,1,OLDPF,512,nonpersist> pair (c,d)", line_launch((line_fn)line_stream_kernel<20, L_TLAST, 1, true, 512, false>, L3, (unsigned)L3.ntiles, tmpA, outB, w, true, 512), b3, outB, base, outA);
