@@ -203,6 +203,12 @@ struct SliceIO {
 
 template <int N> struct SliceGeo {
   static constexpr int G = N == 32 ? 2 : (N == 24 ? 2 : 4);     // slices per wave tile
+  // LDS row stride in doubles.  The contraction over the fastest axis reads 16 rows at this stride at once: at a
+  // stride of N doubles = 2N banks that is a 2-way bank conflict for N = 20 but 8-way for 16, 4-way for 24, 16-way for
+  // 32 (64 banks of 4 bytes) -- the first pass ran at 0.35 of the HBM peak at GCY 16^6 against 0.52 at 20^6.  N + 2
+  // makes the 16 rows conflict-free for every N; 20 keeps its linear image (padding it was measured: no gain).
+  static constexpr int RS = N == 20 ? N : N + 2;
+  static constexpr int LTILE = G * N * RS;                        // doubles of LDS per wave tile
   static constexpr int TILE = G * N * N;                          // doubles
   static constexpr int UNITS = TILE / 2;                          // double2 units
   static constexpr int EPT = (UNITS + 63) / 64;
@@ -240,7 +246,9 @@ slice_kernel(const SliceDesc P, const SliceIO io) {
   if (s0 >= P.nslices) return;                                   // no workgroup barrier below
   const long long rem = (P.nslices - s0) * (N * N / 2);          // valid double2 units of a trailing partial tile
   const int nvalid = rem < Geo::UNITS ? (int)rem : Geo::UNITS;
-  double* const wl = lds + wave * Geo::TILE;
+  double* const wl = lds + wave * Geo::LTILE;
+  // element e of the tile (linear image of the global layout) -> LDS offset: row e / N at stride RS
+  auto lofs = [](const int e) -> int { return Geo::RS == N ? e : (e / N) * Geo::RS + (e % N); };
   const long long gbase = s0 * (N * N);
   const unsigned lb = (unsigned)lane * 16u;
 
@@ -264,8 +272,8 @@ slice_kernel(const SliceDesc P, const SliceIO io) {
     for (int k = 0; k < Geo::EPT4; ++k) {
       const int u = lane + 64 * k;
       if (Geo::UNITS4 % 64 == 0 || u < Geo::UNITS4) {
-        *reinterpret_cast<double2*>(wl + 4 * u) = make_double2((double)v[k].x * (double)c1v[k].x, (double)v[k].y * (double)c1v[k].y);
-        *reinterpret_cast<double2*>(wl + 4 * u + 2) = make_double2((double)v[k].z * (double)c1v[k].z, (double)v[k].w * (double)c1v[k].w);
+        *reinterpret_cast<double2*>(wl + lofs(4 * u)) = make_double2((double)v[k].x * (double)c1v[k].x, (double)v[k].y * (double)c1v[k].y);
+        *reinterpret_cast<double2*>(wl + lofs(4 * u + 2)) = make_double2((double)v[k].z * (double)c1v[k].z, (double)v[k].w * (double)c1v[k].w);
       }
     }
   } else {
@@ -302,7 +310,7 @@ slice_kernel(const SliceDesc P, const SliceIO io) {
         pow_fast_n<true, 2>(xin, P.theta, PTr, xw);
         v[k] = make_double2(xw[0], xw[1]);
       }
-      if (Geo::UNITS % 64 == 0 || u < Geo::UNITS) *reinterpret_cast<double2*>(wl + 2 * u) = v[k];
+      if (Geo::UNITS % 64 == 0 || u < Geo::UNITS) *reinterpret_cast<double2*>(wl + lofs(2 * u)) = v[k];
     }
   }
   QFrag<N> qf;
@@ -320,7 +328,7 @@ slice_kernel(const SliceDesc P, const SliceIO io) {
     for (int k = 0; k < Geo::EPT; ++k) {
       const int u = lane + 64 * k;
       const bool in_tile = Geo::UNITS % 64 == 0 || u < Geo::UNITS;
-      const int lo = in_tile ? 2 * u : 0;
+      const int lo = in_tile ? lofs(2 * u) : 0;
       const double2 x2 = *reinterpret_cast<const double2*>(wl + lo);
       const double xin[2] = {in_tile ? x2.x : 1.0, in_tile ? x2.y : 1.0};
       double xw[2];
@@ -338,14 +346,14 @@ slice_kernel(const SliceDesc P, const SliceIO io) {
   }
 
   const int li = lane & 15, lk = lane >> 4;
-  // ---- contraction over the fastest axis: column c = (slice, e) at wl + c * N, rows contiguous --------
+  // ---- contraction over the fastest axis: column c = (slice, e) at wl + c * RS, rows contiguous -------
   {
-    double* const p0 = wl + li * N + lk;
+    double* const p0 = wl + li * Geo::RS + lk;
 #pragma unroll
-    for (int ct = 0; ct < Geo::NCT; ++ct) ctile<N, 1>(p0 + ct * 16 * N, qf);
+    for (int ct = 0; ct < Geo::NCT; ++ct) ctile<N, 1>(p0 + ct * 16 * Geo::RS, qf);
   }
   wave_lds_fence();
-  // ---- contraction over the second axis: column c = (slice g, f) at wl + g N^2 + f, row stride N -----
+  // ---- contraction over the second axis: column c = (slice g, f) at wl + g N RS + f, row stride RS ---
   {
     QFrag<N> qe;
     qe.load(P.Qe, lane);
@@ -353,7 +361,7 @@ slice_kernel(const SliceDesc P, const SliceIO io) {
     for (int ct = 0; ct < Geo::NCT; ++ct) {
       const int c = 16 * ct + li;
       const int g = c / N, f = c - g * N;
-      ctile<N, N>(wl + g * (N * N) + f + lk * N, qe);
+      ctile<N, Geo::RS>(wl + g * (N * Geo::RS) + f + lk * Geo::RS, qe);
     }
   }
   wave_lds_fence();
@@ -365,7 +373,7 @@ slice_kernel(const SliceDesc P, const SliceIO io) {
     for (int k = 0; k < Geo::EPT4; ++k) {
       const int u = lane + 64 * k;
       if (u < nvalid4) {
-        const double2 a = *reinterpret_cast<const double2*>(wl + 4 * u), b = *reinterpret_cast<const double2*>(wl + 4 * u + 2);
+        const double2 a = *reinterpret_cast<const double2*>(wl + lofs(4 * u)), b = *reinterpret_cast<const double2*>(wl + lofs(4 * u + 2));
         *reinterpret_cast<float4*>(outb + (lb + 1024u * k)) = make_float4((float)a.x, (float)a.y, (float)b.x, (float)b.y);
       }
     }
@@ -374,7 +382,7 @@ slice_kernel(const SliceDesc P, const SliceIO io) {
 #pragma unroll
     for (int k = 0; k < Geo::EPT; ++k) {
       const int u = lane + 64 * k;
-      if (u < nvalid) *reinterpret_cast<double2*>(outb + (lb + 1024u * k)) = *reinterpret_cast<const double2*>(wl + 2 * u);
+      if (u < nvalid) *reinterpret_cast<double2*>(outb + (lb + 1024u * k)) = *reinterpret_cast<const double2*>(wl + lofs(2 * u));
     }
   }
 }
@@ -1278,7 +1286,7 @@ inline line_fn line_variant(int n, int mode, bool persist, bool fullc, bool f32 
 }
 #endif
 inline int slice_tile_slices(int n) { return n == 16 ? SliceGeo<16>::G : n == 20 ? SliceGeo<20>::G : n == 24 ? SliceGeo<24>::G : SliceGeo<32>::G; }
-inline size_t slice_lds_bytes(int n) { return (size_t)slice_tile_slices(n) * n * n * 8 * 4; }
+inline size_t slice_lds_bytes(int n) { return (size_t)slice_tile_slices(n) * n * (n == 20 ? n : n + 2) * 8 * 4; }
 inline int line_block(int n) { return n <= 24 ? 256 : 512; }
 inline size_t line_lds_bytes(int n) { return (size_t)n * n * LINE_R * 8; }
 inline int line_blocks_per_cu(int n) { return n <= 16 ? LineGeo<16>::BPC : n == 20 ? LineGeo<20>::BPC : n == 24 ? LineGeo<24>::BPC : LineGeo<32>::BPC; }
