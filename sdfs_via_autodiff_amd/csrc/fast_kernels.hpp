@@ -913,6 +913,11 @@ struct SmallIO {
   unsigned long long* slot_out;
 };
 
+// LDS stride of X in the padded tile.  The contraction over Y reads 16 columns at once, one per x (R = 1) or four
+// x times four positions (R = 4): at a stride of 16 (64) doubles that is an 8-way (4-way) bank conflict; 18 (72)
+// doubles put the 16 columns on 16 different bank pairs.
+template <int R> struct SmallLds { static constexpr int SX = R == 1 ? 18 : 72; static constexpr int TILE = 16 * SX; };
+
 // element e of a tile -> LDS offset, global element offset against the tile base, a3 index part, position
 template <int R>
 __device__ __forceinline__ void small_decode(const SmallDesc& P, int e, int& l, unsigned& g, unsigned& ixy, int& r) {
@@ -920,7 +925,7 @@ __device__ __forceinline__ void small_decode(const SmallDesc& P, int e, int& l, 
   r = R == 1 ? 0 : (e & 3);
   const int x = (int)(__umul24((unsigned)row, P.my) >> 16);
   const int y = row - x * P.ny;
-  l = R == 1 ? x * 16 + y : x * 64 + y * 4 + r;
+  l = R == 1 ? x * SmallLds<1>::SX + y : x * SmallLds<4>::SX + y * 4 + r;
   g = (unsigned)x * P.sx + (unsigned)y * P.sy + (unsigned)r;
   ixy = __umul24((unsigned)x, (unsigned)P.a3x) + __umul24((unsigned)y, (unsigned)P.a3y);
 }
@@ -948,7 +953,9 @@ small_tile_kernel(const SmallDesc P, const SmallIO io) {
   constexpr int PG = EPL < 4 ? EPL : 4;        // points per call of the power routine
   static_assert(R == 1 || R == 4, "run lengths");
   static_assert(WPT == 1 || WPT == 4, "waves per tile");
-  __shared__ __attribute__((aligned(16))) double lds[(4 / WPT) * TILE];
+  constexpr int SX = SmallLds<R>::SX;           // LDS stride of X (conflict-free columns, see SmallLds)
+  constexpr int LT = SmallLds<R>::TILE;         // doubles of LDS per tile
+  __shared__ __attribute__((aligned(16))) double lds[(4 / WPT) * LT];
   __shared__ double red[12];
   // the gate word is fetched first and tested behind the tile loads (nothing is written before the test)
   const unsigned long long gate_word = io.gate != nullptr ? *io.gate : ~0ULL;
@@ -975,7 +982,7 @@ small_tile_kernel(const SmallDesc P, const SmallIO io) {
     const long long base = (long long)o * P.ostride + (long long)chunk * R;
     const int total = P.nx * P.ny * R;
     const unsigned pos0 = chunk * R;
-    double* const wl = WPT == 4 ? lds : lds + wave * TILE;
+    double* const wl = WPT == 4 ? lds : lds + wave * LT;
     const bool need_old = CES ? (io.resid != nullptr || io.part_out != nullptr) : (MULE && P.minus_identity);
     // ---- decode this thread's elements once ------------------------------------------------------------------
     int l[EPL], rr[EPL]; unsigned g[EPL], ia3[EPL]; bool ok[EPL];
@@ -1015,12 +1022,9 @@ small_tile_kernel(const SmallDesc P, const SmallIO io) {
     SDFS_SMALL_STAMP(2);
     if (io.zero != nullptr && blockIdx.x == 0 && tid == 0) *io.zero = 0ULL;
     // ---- zero the padded tile, then park the data ------------------------------------------------------------
-    if (EPL >= 2) {
 #pragma unroll
-      for (int k = 0; k < EPL / 2; ++k) *reinterpret_cast<double2*>(wl + 2 * (tl + TPT * k)) = make_double2(0.0, 0.0);
-    } else {
-      wl[tl] = 0.0;
-    }
+    for (int k = 0; k < (LT / 2 + TPT - 1) / TPT; ++k)
+      if (LT / 2 % TPT == 0 || tl + TPT * k < LT / 2) *reinterpret_cast<double2*>(wl + 2 * (tl + TPT * k)) = make_double2(0.0, 0.0);
     tile_sync();
     PowLane PT;
     if (POWP || CES) PT = pow_lane_init(lane);
@@ -1054,22 +1058,22 @@ small_tile_kernel(const SmallDesc P, const SmallIO io) {
     auto contract_pair = [&]() {
       if (R == 1) {
         if (mfma_wave) {
-          ctile<16, 16>(wl + li + lk * 16, q);
+          ctile<16, SX>(wl + li + lk * SX, q);
           wave_lds_fence();
-          ctile<16, 1>(wl + li * 16 + lk, q2);
+          ctile<16, 1>(wl + li * SX + lk, q2);
         }
       } else if (WPT == 1) {
 #pragma unroll
         for (int ct = 0; ct < 4; ++ct)
-          if (4 * ct < P.ny) ctile<16, 64>(wl + 16 * ct + li + lk * 64, q);
+          if (4 * ct < P.ny) ctile<16, SX>(wl + 16 * ct + li + lk * SX, q);
         wave_lds_fence();
 #pragma unroll
         for (int ct = 0; ct < 4; ++ct)
-          if (4 * ct < P.nx) ctile<16, 4>(wl + (4 * ct + (li >> 2)) * 64 + (li & 3) + lk * 4, q2);
+          if (4 * ct < P.nx) ctile<16, 4>(wl + (4 * ct + (li >> 2)) * SX + (li & 3) + lk * 4, q2);
       } else {
-        if (4 * wave < P.ny) ctile<16, 64>(wl + 16 * wave + li + lk * 64, q);
+        if (4 * wave < P.ny) ctile<16, SX>(wl + 16 * wave + li + lk * SX, q);
         __syncthreads();
-        if (4 * wave < P.nx) ctile<16, 4>(wl + (4 * wave + (li >> 2)) * 64 + (li & 3) + lk * 4, q2);
+        if (4 * wave < P.nx) ctile<16, 4>(wl + (4 * wave + (li >> 2)) * SX + (li & 3) + lk * 4, q2);
       }
       tile_sync();
     };
