@@ -30,6 +30,7 @@
 
 #include <type_traits>
 
+#include "anderson_step.hpp"
 #include "pass_kernel.hpp"
 #include "wave_reduce.hpp"
 
@@ -870,7 +871,11 @@ line_kernel(const LineDesc P, const LineIO io) {
 #ifndef SDFS_SMALL_STAMP
 #define SDFS_SMALL_STAMP(i)       // tools/probes/small_fused_probe.hip defines it: phase time stamps of workgroup 0
 #endif
-enum SmallMode { SM_FIRST_T = 0, SM_FIRST_TLIN = 1, SM_FIRST_J = 2, SM_MID = 3, SM_LAST_T = 4, SM_LAST_TLIN = 5, SM_LAST_J = 6, SM_FUSED_T = 7, SM_NMODES = 8 };
+#ifndef SDFS_AND_STAMP
+#define SDFS_AND_STAMP(i)         // tools/probes/anderson_fused_probe.hip: phase time stamps of the control workgroup
+#endif
+enum SmallMode { SM_FIRST_T = 0, SM_FIRST_TLIN = 1, SM_FIRST_J = 2, SM_MID = 3, SM_LAST_T = 4, SM_LAST_TLIN = 5, SM_LAST_J = 6, SM_FUSED_T = 7,
+                 SM_AND_FIRST = 8, SM_AND_LAST = 9 };   // Anderson: first pass with the previous pass's control step and the update of x; last pass with the push
 
 struct SmallDesc {
   int nx, ny;               // extents of the contracted pair (X slower)
@@ -880,6 +885,9 @@ struct SmallDesc {
   unsigned lrest;           // positions behind Y
   unsigned nchunks;         // ceil(lrest / R)
   long long ntiles;         // nouter * nchunks
+  unsigned cpx;             // XCD-aware launch of a strided pass (0: workgroup b works tile group b): workgroups per XCD;
+                            // workgroup b -- dispatched to XCD b mod 8 -- takes group (b mod 8) * cpx + b / 8, so that the
+                            // tiles of neighbouring positions, which share their 128-byte lines, meet in one L2
   const double* Qxp;        // 16 x 16 zero-padded matrices
   const double* Qyp;
   double theta, inv_theta, beta;
@@ -938,13 +946,14 @@ __device__ __forceinline__ void small_decode(const SmallDesc& P, int e, int& l, 
 constexpr int SMALL_RING = 512;      // most workgroups of an end pass for which successive approximation runs without atomics
 
 template <int MODE, int R, int WPT>
-__global__ void __launch_bounds__(256)
-small_tile_kernel(const SmallDesc P, const SmallIO io) {
-  constexpr bool POWP = MODE == SM_FIRST_T || MODE == SM_FIRST_TLIN;
+__device__ __forceinline__ void small_tile_body(const SmallDesc& P, const SmallIO& io, const AndArgs* an) {
+  constexpr bool ANDF = MODE == SM_AND_FIRST;  // Anderson: control step of the previous pass + update of x, then the first pass of T
+  constexpr bool ANDL = MODE == SM_AND_LAST;   // Anderson: last pass of T, then r = Tx - x into the history and its Gram row
+  constexpr bool POWP = MODE == SM_FIRST_T || MODE == SM_FIRST_TLIN || ANDF;
   constexpr bool LINP = MODE == SM_FIRST_TLIN;
   constexpr bool MULP = MODE == SM_FIRST_J;
   constexpr bool FUSED = MODE == SM_FUSED_T;
-  constexpr bool CES = MODE == SM_LAST_T || MODE == SM_LAST_TLIN || FUSED;
+  constexpr bool CES = MODE == SM_LAST_T || MODE == SM_LAST_TLIN || FUSED || ANDL;
   constexpr bool LINE = MODE == SM_LAST_TLIN;
   constexpr bool MULE = MODE == SM_LAST_J;
   constexpr int TILE = 256 * R;                // doubles per tile
@@ -957,6 +966,9 @@ small_tile_kernel(const SmallDesc P, const SmallIO io) {
   constexpr int LT = SmallLds<R>::TILE;         // doubles of LDS per tile
   __shared__ __attribute__((aligned(16))) double lds[(4 / WPT) * LT];
   __shared__ double red[12];
+  constexpr int AND_LDS = (int)(sizeof(AndStepLds) / 8);
+  __shared__ __attribute__((aligned(16))) double and_raw[ANDF ? AND_LDS : 1];         // the control step of wave 0
+  __shared__ double redj[ANDL ? AND_FUSE_M * 16 : 1];
   // the gate word is fetched first and tested behind the tile loads (nothing is written before the test)
   const unsigned long long gate_word = io.gate != nullptr ? *io.gate : ~0ULL;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -970,10 +982,57 @@ small_tile_kernel(const SmallDesc P, const SmallIO io) {
 #pragma unroll
     for (int k = 0; k < SMALL_RING / 64; ++k) gate_err = fmax(gate_err, gp[k]);
   }
+  // Anderson, first pass.  The step of the previous pass is due; what the tiles need of it is known when the chunk is
+  // captured (AndArgs::step_kind): nothing (0: the step can neither mix nor reject, x = fx; should it end the loop, the
+  // launches behind this one are gated and x = fx is the final update anyway), whether the pass is rejected (1: the
+  // diagonal entry of the Gram row), everything (2: a mixing step: wave 0 of every workgroup works it out, the same
+  // operations everywhere).  The state is written by an extra workgroup that has no tile (the last one), off every
+  // tile's path.  One copy of the code, in front of the tile's own work: unrolled twice it was 130 KB of instructions
+  // that every launch fetched cold (tools/probes/anderson_fused_probe.hip: 15 us for the row sums alone).
+  int and_mode = 0, and_open = 1, and_prev = 0;
+  if (ANDF) {
+    const bool ctrl = blockIdx.x == gridDim.x - 1;
+    if (an->Sin->gate == 0ULL) {                // the loop has ended: carry its final state along
+      if (ctrl && wave == 0) and_state_carry(lane, an->Sin, an->Sout);
+      return;
+    }
+    const int nonfinite = (int)(*an->flag != 0u);
+    if (!ctrl && an->step_kind == 1) {
+      // the pass behind a mixing step: is it rejected?  (its push has recorded whether it met a non-finite residual)
+      if (nonfinite) {
+        const AndState* const Sp = an->Sin;
+        const int pp = (int)Sp->prev_pos;
+        if (Sp->last_mixed != 0.0 && pp >= 0 && Sp->rejected < 1000.0) {
+          and_mode = 2; and_prev = pp;
+          and_open = (sqrt(Sp->G[pp * an->m + pp]) > an->par.tol && Sp->it + 1.0 < an->par.max_iter) ? 1 : 0;
+        }
+      }
+    } else if (ctrl || an->step_kind == 2) {
+      AndStepLds& sh = *reinterpret_cast<AndStepLds*>(and_raw);
+      const bool full = ctrl || an->step_kind == 2;
+      SDFS_AND_STAMP(0);
+      and_row_sums16(an->partial, an->nb, an->m, full ? -1 : an->pos, sh.row);
+      __syncthreads();
+      SDFS_AND_STAMP(1);
+      if (wave == 0)
+        and_step_wave<AND_FUSE_M + 1, true>(sh, lane, an->m, an->pos, an->rel, an->Sin, an->Sout, ctrl, an->err_slot, an->kind_slot, an->par, nonfinite);
+      __syncthreads();
+      SDFS_AND_STAMP(2);
+      and_mode = __builtin_amdgcn_readfirstlane(sh.mix_mode);
+      and_open = __builtin_amdgcn_readfirstlane(sh.open);
+      and_prev = __builtin_amdgcn_readfirstlane(sh.prev_pos);
+    }
+    if (ctrl) return;
+  }
+  double acc[ANDL ? AND_FUSE_M : 1];            // Anderson, last pass: <r, R_j> over this thread's elements
+#pragma unroll
+  for (int j = 0; j < (ANDL ? AND_FUSE_M : 1); ++j) acc[j] = 0.0;
   const int tl = WPT == 4 ? tid : lane;        // this thread's index inside its tile
-  const long long t = WPT == 4 ? (long long)blockIdx.x : (long long)blockIdx.x * 4 + wave;
+  const unsigned wgi = P.cpx != 0u ? (blockIdx.x & 7u) * P.cpx + (blockIdx.x >> 3) : blockIdx.x;
+  const long long t = WPT == 4 ? (long long)wgi : (long long)wgi * 4 + wave;
   SDFS_SMALL_STAMP(0);
   const bool active = t < P.ntiles;            // uniform per tile; idle waves (WPT = 1) fall through to the reductions
+  if (ANDF && !active) return;                 // (no reductions in that form, and its workgroup barrier is for live waves)
   auto tile_sync = [&]() { if (WPT == 4) __syncthreads(); else wave_lds_fence(); };
   double rmax = 0.0, dot_yv = 0.0, dot_yy = 0.0;
   bool rnan = false;
@@ -983,7 +1042,7 @@ small_tile_kernel(const SmallDesc P, const SmallIO io) {
     const int total = P.nx * P.ny * R;
     const unsigned pos0 = chunk * R;
     double* const wl = WPT == 4 ? lds : lds + wave * LT;
-    const bool need_old = CES ? (io.resid != nullptr || io.part_out != nullptr) : (MULE && P.minus_identity);
+    const bool need_old = CES ? (ANDL || io.resid != nullptr || io.part_out != nullptr) : (MULE && P.minus_identity);
     // ---- decode this thread's elements once ------------------------------------------------------------------
     int l[EPL], rr[EPL]; unsigned g[EPL], ia3[EPL]; bool ok[EPL];
 #pragma unroll
@@ -1017,10 +1076,73 @@ small_tile_kernel(const SmallDesc P, const SmallIO io) {
       for (int k = 0; k < EPL; ++k)
         if (TPT * k < total) s2[k] = P.a3[ok[k] ? io0 + (unsigned)P.rest_idx[pos0 + (unsigned)rr[k]] + ia3[k] : 0u];
     }
+    // Anderson, last pass: the residual history of this thread's points travels with the tile (few elements per thread),
+    // else it is requested group by group in front of the power.  Behind the a3 gather: loads return in order, and its
+    // index tables would otherwise wait for these -- strided, slow -- streams before the gather could even be issued
+    // (tools/probes/anderson_fused_probe.hip: 9100 cycles to that point against 2500).
+    constexpr bool HIST_EARLY = ANDL && EPL <= 4;
+    double hoe[HIST_EARLY ? AND_FUSE_M : 1][HIST_EARLY ? EPL : 1];
+    if (HIST_EARLY) {
+      // (a fixed number of requests from valid addresses, whatever m: the waits behind them stay counted ones)
+#pragma unroll
+      for (int jh = 0; jh < AND_FUSE_M; ++jh) {
+        const double* const pr = an->h.R[jh < an->m ? jh : 0];
+#pragma unroll
+        for (int k = 0; k < EPL; ++k)
+          if (k == 0 || TPT * k < total) hoe[HIST_EARLY ? jh : 0][HIST_EARLY ? k : 0] = pr[base + g[k]];
+      }
+    }
     SDFS_SMALL_STAMP(1);
     if (gate_word <= (unsigned long long)__double_as_longlong(io.gate_tol)) return;      // uniform over the grid
     SDFS_SMALL_STAMP(2);
     if (io.zero != nullptr && blockIdx.x == 0 && tid == 0) *io.zero = 0ULL;
+    if (ANDF) {
+      // ---- Anderson: this tile of the new iterate ------------------------------------------------------------------
+      AndStepLds& sh = *reinterpret_cast<AndStepLds*>(and_raw);
+      // the history is requested before the solve (only a pass whose step can mix needs it)
+      double hx[ANDF ? AND_FUSE_M : 1][EPL];                     // Y_j = x_j + beta r_j (see AndArgs)
+      const bool full = an->step_kind == 2;
+      if (full) {
+#pragma unroll
+        for (int j = 0; j < AND_FUSE_M; ++j) {
+          const double* const px = an->h.X[j < an->m ? j : 0];
+#pragma unroll
+          for (int k = 0; k < EPL; ++k)
+            if (k == 0 || TPT * k < total) hx[ANDF ? j : 0][k] = px[base + g[k]];
+        }
+      }
+      const int mix_mode = and_mode;
+      if (mix_mode == 1 && full) {
+        // x = sum_j coef_j Y_j
+#pragma unroll
+        for (int k = 0; k < EPL; ++k) {
+          double xa = 0.0;
+#pragma unroll
+          for (int j = 0; j < AND_FUSE_M; ++j)
+            if (j < an->m) xa = fma(sh.coef[j], hx[ANDF ? j : 0][k], xa);
+          v[k] = xa;
+        }
+      } else if (mix_mode == 2) {
+        // rejected step: x = x_prev + r_prev = Y_prev + (1 - beta) R_prev, the plain step from the last good iterate;
+        // the poisoned slot is cleared (residual zero, Y the new iterate: finite, and out of every sum until it is refilled)
+        const double* px = an->h.X[0];
+        const double* pr = an->h.R[0];
+#pragma unroll
+        for (int j = 1; j < AND_FUSE_M; ++j)
+          if (j == and_prev) { px = an->h.X[j]; pr = an->h.R[j]; }
+#pragma unroll
+        for (int k = 0; k < EPL; ++k) {
+          if (TPT * k < total) {
+            v[k] = fma(1.0 - an->beta, pr[base + g[k]], px[base + g[k]]);
+            if (ok[k]) { an->r_pos[base + g[k]] = 0.0; an->x_pos[base + g[k]] = v[k]; }
+          }
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < EPL; ++k)
+        if (TPT * k < total && ok[k]) an->x[base + g[k]] = v[k];
+      if (and_open == 0) return;      // uniform over the grid: the loop ended with that update
+    }
     // ---- zero the padded tile, then park the data ------------------------------------------------------------
 #pragma unroll
     for (int k = 0; k < (LT / 2 + TPT - 1) / TPT; ++k)
@@ -1097,6 +1219,16 @@ small_tile_kernel(const SmallDesc P, const SmallIO io) {
       for (int k = 0; k < EPL; k += PG) {
         if (TPT * k < total) {
           double sv[PG], ks[PG], uu[PG];
+          // Anderson: the residual history of these points is requested in front of the power
+          double ho[ANDL ? AND_FUSE_M : 1][PG];
+          if (ANDL) {
+#pragma unroll
+            for (int jh = 0; jh < AND_FUSE_M; ++jh) {
+              const double* const pr = an->h.R[jh < an->m ? jh : 0];
+#pragma unroll
+              for (int j = 0; j < PG; ++j) ho[ANDL ? jh : 0][j] = HIST_EARLY ? hoe[HIST_EARLY ? jh : 0][HIST_EARLY ? k + j : 0] : pr[base + g[k + j]];
+            }
+          }
 #pragma unroll
           for (int j = 0; j < PG; ++j) { sv[j] = wl[l[k + j]]; ks[j] = ok[k + j] ? s2[k + j] * sv[j] : 1.0; }
           pow_fast_n<false, PG>(ks, P.inv_theta, PT, uu);
@@ -1113,6 +1245,15 @@ small_tile_kernel(const SmallDesc P, const SmallIO io) {
                 rmax = fmax(rmax, r0);
               }
               outb[g[k + j]] = y;
+              if (ANDL) {
+                // Y[pos] = x + beta r, R[pos] = r = Tx - x, and this point's share of row `pos` of the Gram matrix
+                const double xo = s1[k + j], r = y - xo;
+                rnan |= !isfinite(r);
+                an->x_pos[base + g[k + j]] = fma(an->beta, r, xo);
+                an->r_pos[base + g[k + j]] = r;
+#pragma unroll
+                for (int jh = 0; jh < AND_FUSE_M; ++jh) acc[ANDL ? jh : 0] += r * (jh == an->pos ? r : ho[ANDL ? jh : 0][j]);    // (slots >= m: unused sums)
+              }
             }
           }
           if (FUSED) {
@@ -1183,6 +1324,28 @@ small_tile_kernel(const SmallDesc P, const SmallIO io) {
       if (io.dot_with == nullptr) io.dotp[gridDim.x + blockIdx.x] = (red[4] + red[5]) + (red[6] + red[7]);
     }
   }
+  if (ANDL) {
+    if (__any(rnan) && lane == 0) atomicOr(an->flag, 1u);          // (rare: a mixing step left the domain)
+#pragma unroll
+    for (int j = 0; j < AND_FUSE_M; ++j)
+      if (j < an->m) {
+        // the 16 lanes of a DPP row, then 4 rows x 4 waves through LDS (the v_readlane tail of wave_sum_f64, ten times
+        // over, was 2500 of the kernel's 9000 cycles)
+        double sj = acc[ANDL ? j : 0];
+        sj += dpp_mov_f64<0xB1>(sj);
+        sj += dpp_mov_f64<0x4E>(sj);
+        sj += dpp_mov_f64<0x141>(sj);
+        sj += dpp_mov_f64<0x140>(sj);
+        if ((lane & 15) == 0) redj[ANDL ? j * 16 + wave * 4 + (lane >> 4) : 0] = sj;
+      }
+    __syncthreads();
+    if (tid < an->m) {
+      double sj = 0.0;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) sj += redj[ANDL ? tid * 16 + q : 0];
+      an->partial_out[blockIdx.x + tid * gridDim.x] = sj;
+    }
+  }
   if (CES && (io.resid != nullptr || io.part_out != nullptr)) {
     if (rnan) rmax = __longlong_as_double(0x7ff0000000000000LL);                // NaN -> +inf
     rmax = wave_max_f64(rmax);
@@ -1195,6 +1358,55 @@ small_tile_kernel(const SmallDesc P, const SmallIO io) {
     }
   }
   SDFS_SMALL_STAMP(9);
+}
+
+template <int MODE, int R, int WPT>
+__global__ void __launch_bounds__(256)
+small_tile_kernel(const SmallDesc P, const SmallIO io) { small_tile_body<MODE, R, WPT>(P, io, nullptr); }
+
+// the Anderson forms: SM_AND_FIRST / SM_AND_LAST
+template <int MODE, int R, int WPT>
+__global__ void __launch_bounds__(256)
+small_and_kernel(const SmallDesc P, const SmallIO io, const AndArgs an) { small_tile_body<MODE, R, WPT>(P, io, &an); }
+
+// End of a chunk of the fused Anderson loop: the control step of the chunk's last pass and the update of x it decides on,
+// with the row sums, the solve and the mixing expression of SM_AND_FIRST (the passes must not depend on where the chunks
+// end).  Every workgroup works the step out, workgroup 0 writes the state; elements in their memory order.
+__global__ void __launch_bounds__(256)
+small_and_finish(const AndArgs an, const double* __restrict__ fx, long long n) {
+  __shared__ __attribute__((aligned(16))) double and_raw[sizeof(AndStepLds) / 8];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (an.Sin->gate == 0ULL) {
+    if (blockIdx.x == 0 && wave == 0) and_state_carry(lane, an.Sin, an.Sout);
+    return;
+  }
+  AndStepLds& sh = *reinterpret_cast<AndStepLds*>(and_raw);
+  const int nonfinite = (int)(*an.flag != 0u);
+  and_row_sums16(an.partial, an.nb, an.m, -1, sh.row);
+  __syncthreads();
+  if (wave == 0)
+    and_step_wave<AND_FUSE_M + 1, true>(sh, lane, an.m, an.pos, an.rel, an.Sin, an.Sout, blockIdx.x == 0, an.err_slot, an.kind_slot, an.par, nonfinite);
+  __syncthreads();
+  const int mode = sh.mix_mode, prev = sh.prev_pos;
+  const double* px = an.h.X[0];
+  const double* pr = an.h.R[0];
+#pragma unroll
+  for (int j = 1; j < AND_FUSE_M; ++j)
+    if (j == prev) { px = an.h.X[j]; pr = an.h.R[j]; }
+  for (long long e = (long long)blockIdx.x * 256 + tid; e < n; e += (long long)gridDim.x * 256) {
+    double v;
+    if (mode == 0) v = fx[e];
+    else if (mode == 1) {
+      v = 0.0;
+#pragma unroll
+      for (int j = 0; j < AND_FUSE_M; ++j)
+        if (j < an.m) v = fma(sh.coef[j], an.h.X[j][e], v);
+    } else {
+      v = fma(1.0 - an.beta, pr[e], px[e]);
+      an.r_pos[e] = 0.0; an.x_pos[e] = v;
+    }
+    an.x[e] = v;
+  }
 }
 
 // end of a chunk of iterations: the last iteration's error for the host
@@ -1210,13 +1422,14 @@ __global__ void __launch_bounds__(64) small_sa_finish(const double* part, int n,
 }
 
 typedef void (*small_fn)(const SmallDesc, const SmallIO);
+typedef void (*small_and_fn)(const SmallDesc, const SmallIO, const AndArgs);
 typedef void (*slice_fn)(const SliceDesc, const SliceIO);
 typedef void (*line_fn)(const LineDesc, const LineIO);
 
 #ifndef SDFS_NO_VARIANT_TABLES
 template <int R, int WPT> inline small_fn small_variant_rw(int mode) {
   switch (mode) {
-    case SM_FIRST_T: return R == 1 ? (small_fn)small_tile_kernel<SM_FIRST_T, 1, WPT> : nullptr;
+    case SM_FIRST_T: return (small_fn)small_tile_kernel<SM_FIRST_T, R, WPT>;      // (R = 4: the fused Anderson loop opens on the slowest pair)
     case SM_FIRST_TLIN: return R == 1 ? (small_fn)small_tile_kernel<SM_FIRST_TLIN, 1, WPT> : nullptr;
     case SM_FIRST_J: return R == 1 ? (small_fn)small_tile_kernel<SM_FIRST_J, 1, WPT> : nullptr;
     case SM_MID: return (small_fn)small_tile_kernel<SM_MID, R, WPT>;
@@ -1232,7 +1445,18 @@ inline small_fn small_variant(int mode, int r, int wpt) {
   if (wpt == 4) return r == 1 ? small_variant_rw<1, 4>(mode) : (r == 4 ? small_variant_rw<4, 4>(mode) : nullptr);
   return r == 1 ? small_variant_rw<1, 1>(mode) : (r == 4 ? small_variant_rw<4, 1>(mode) : nullptr);
 }
+inline small_and_fn small_and_variant(int mode, int r, int wpt) {
+  if (mode == SM_AND_FIRST) {
+    if (wpt == 4) return r == 1 ? (small_and_fn)small_and_kernel<SM_AND_FIRST, 1, 4> : (r == 4 ? (small_and_fn)small_and_kernel<SM_AND_FIRST, 4, 4> : nullptr);
+    return r == 1 ? (small_and_fn)small_and_kernel<SM_AND_FIRST, 1, 1> : (r == 4 ? (small_and_fn)small_and_kernel<SM_AND_FIRST, 4, 1> : nullptr);
+  }
+  if (mode != SM_AND_LAST) return nullptr;
+  if (wpt == 4) return r == 1 ? (small_and_fn)small_and_kernel<SM_AND_LAST, 1, 4> : (r == 4 ? (small_and_fn)small_and_kernel<SM_AND_LAST, 4, 4> : nullptr);
+  return r == 1 ? (small_and_fn)small_and_kernel<SM_AND_LAST, 1, 1> : (r == 4 ? (small_and_fn)small_and_kernel<SM_AND_LAST, 4, 1> : nullptr);
+}
 inline unsigned small_grid(long long ntiles, int wpt) { return (unsigned)(wpt == 4 ? ntiles : (ntiles + 3) / 4); }
+inline unsigned small_grid(const SmallDesc& d, int wpt) { return d.cpx != 0u ? 8u * d.cpx : small_grid(d.ntiles, wpt); }
+inline unsigned small_cpx(long long ntiles, int wpt) { return (small_grid(ntiles, wpt) + 7u) / 8u; }
 
 
 template <int N> inline slice_fn slice_variant_n(int mode, bool f32) {

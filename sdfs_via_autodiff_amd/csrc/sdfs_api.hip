@@ -109,8 +109,10 @@ struct Knobs {
   int small_plan = 1;          // SDFS_SMALL_PLAN: 0 = never use the small-grid pair plan
   int small_r = 0;             // SDFS_SMALL_R: force the run length of its line passes (1 or 4)
   int small_wpt = 0;           // SDFS_SMALL_WPT: force its waves per tile (1 or 4)
+  int small_xcd = 1;           // SDFS_SMALL_XCD: 0 = its strided passes launch tile b on workgroup b (no XCD-aware order)
   int no_bicg_merge = 0;       // SDFS_NO_BICG_MERGE: 1 = BiCGSTAB keeps its finishing kernels as launches of their own on small grids too
   int and_host = 0;            // SDFS_AND_HOST: 1 = Anderson with the Gram solve on the host (one synchronisation per iteration)
+  int and_fused = 1;           // SDFS_AND_FUSED: 0 = Anderson on the small-grid plan keeps push / step / update as launches of their own
   int a3_tables = 1;           // SDFS_A3_TABLES: 0 = the streamed last pass gathers a3 even where it factorises into two small tables
   int sa_fused = -1;           // SDFS_SA_FUSED: 0 = successive approximation keeps one launch per pass; 1 = fused end + start kernels;
                                // default (-1): fused, except on the 6-D pair plan when its line passes run the streamed forms
@@ -141,8 +143,9 @@ struct sdfs_handle {
   Plan plan[2];
   FastPlan fast;                      // pair plan of the full grid, when the model admits it
   unsigned* sched = nullptr;          // tile tickets of the persistent line passes (SCHED_WORDS per pass, zero between launches)
-  AndState* and_state = nullptr;      // device-resident Anderson loop: state, per-chunk record of its passes
+  AndState* and_state = nullptr;      // device-resident Anderson loop: state (two buffers: the fused small-grid form alternates), per-chunk record of its passes
   AndState* and_state_host = nullptr;
+  unsigned* and_flag = nullptr;       // fused form: per pass of a chunk, set by a push that met a non-finite residual
   double* and_err = nullptr; int* and_kind = nullptr; int and_slots = 0;
   double* and_err_host = nullptr; int* and_kind_host = nullptr;
   hipGraphExec_t and_graph = nullptr;
@@ -271,7 +274,9 @@ Knobs read_knobs() {
   k.small_r = env_int("SDFS_SMALL_R", 0);
   k.sa_fused = env_int("SDFS_SA_FUSED", -1);
   k.small_wpt = env_int("SDFS_SMALL_WPT", 0);
+  k.small_xcd = env_int("SDFS_SMALL_XCD", 1);
   k.and_host = env_int("SDFS_AND_HOST", 0);
+  k.and_fused = env_int("SDFS_AND_FUSED", 1);
   const char* pl = getenv("SDFS_PLAN");
   if (pl && !strcmp(pl, "classic")) k.plan = 1;
   else if (pl && !strcmp(pl, "pair")) k.plan = 2;
@@ -938,6 +943,10 @@ int build_small_plan(sdfs_handle* h) {
     P.wpt = S.ntiles <= 2LL * h->num_cus ? 4 : 1;
     if (h->knobs.small_wpt == 1 || h->knobs.small_wpt == 4) P.wpt = h->knobs.small_wpt;
     if (S.ntiles >= (1LL << 31)) return 0;
+    // strided pass with as many workgroups as fit the GPU at once: neighbouring tiles (they share their 128-byte
+    // lines) to the same XCD (tools/probes/anderson_fused_probe.hip: 15^4 pair of passes 7.8 -> 7.0 us)
+    S.cpx = 0;
+    if (lrest > 1 && h->knobs.small_xcd && small_grid(S.ntiles, P.wpt) <= 2u * (unsigned)h->num_cus) S.cpx = small_cpx(S.ntiles, P.wpt);
     S.Qxp = h->ax[a].Qp; S.Qyp = h->ax[a + 1].Qp;
     S.theta = h->theta; S.inv_theta = 1.0 / h->theta; S.beta = h->beta;
     S.cbt = (double)powl((long double)h->beta, (long double)h->theta);
@@ -1043,7 +1052,7 @@ int run_fast_plan(sdfs_handle* h, int mode, const double* in, double* out, const
       int cid = -1;
       if (h->profiling) { char nm[48]; snprintf(nm, sizeof nm, "%s:%s", tag, P.label.c_str()); cid = counter_id(h, nm, bytes, P.flops); }
       ProfScope ps(h, cid);
-      hipLaunchKernelGGL(fn, dim3(small_grid(d.ntiles, P.wpt)), dim3(256), 0, h->stream, d, io);
+      hipLaunchKernelGGL(fn, dim3(small_grid(d, P.wpt)), dim3(256), 0, h->stream, d, io);
     } else if (!P.line) {
       SliceIO io;
       memset(&io, 0, sizeof io);
@@ -1112,7 +1121,7 @@ int run_fast_plan(sdfs_handle* h, int mode, const double* in, double* out, const
 // tiles of the last pass of a J.v application (per-block partial sums of the fused dots)
 long long jvp_last_tiles(sdfs_handle* h) {
   if (h->cont || h->dense) return 0;
-  if (h->fast.ok && h->fast.small) return h->krylov_f32 ? h->plan[0].passes.back().d.ntiles : (long long)small_grid(h->fast.passes.back().sm.ntiles, h->fast.passes.back().wpt);
+  if (h->fast.ok && h->fast.small) return h->krylov_f32 ? h->plan[0].passes.back().d.ntiles : (long long)small_grid(h->fast.passes.back().sm, h->fast.passes.back().wpt);
   if (h->fast.ok && h->krylov_f32 && h->fast.f32_ok) return h->fast.passes.back().ld.ntiles;
   if (h->fast.ok && !h->krylov_f32) return line_grid(h, h->fast.passes.back());
   return h->plan[0].passes.empty() ? 0 : h->plan[0].passes.back().d.ntiles;
@@ -1273,7 +1282,7 @@ int small_sa_prologue(sdfs_handle* h, const double* w) {
   int cid = -1;
   if (h->profiling) cid = counter_id(h, ("sa:first " + P.label).c_str(), 16.0 * (double)h->N, P.flops);
   ProfScope ps(h, cid);
-  hipLaunchKernelGGL(fn, dim3(small_grid(P.sm.ntiles, P.wpt)), dim3(256), 0, h->stream, P.sm, io);
+  hipLaunchKernelGGL(fn, dim3(small_grid(P.sm, P.wpt)), dim3(256), 0, h->stream, P.sm, io);
   HIPCHK(h, hipGetLastError());
   return 0;
 }
@@ -1288,7 +1297,7 @@ int small_sa_iteration(sdfs_handle* h, long long it, const double* w_old, double
   const bool forward = (it & 1) == 0;
   const double n8 = 8.0 * (double)h->N;
   // writer of ring[p]: the end pass of the iterations of parity p (forward iterations end on the last pair)
-  auto ring_n = [&](int parity) { const FastPass& E = h->fast.passes[parity == 0 ? np - 1 : 0]; return (int)small_grid(E.sm.ntiles, E.wpt); };
+  auto ring_n = [&](int parity) { const FastPass& E = h->fast.passes[parity == 0 ? np - 1 : 0]; return (int)small_grid(E.sm, E.wpt); };
   for (int j = 1; j < np; ++j) {
     const FastPass& P = h->fast.passes[forward ? j : np - 1 - j];
     const bool last = j == np - 1;
@@ -1307,7 +1316,7 @@ int small_sa_iteration(sdfs_handle* h, long long it, const double* w_old, double
     int cid = -1;
     if (h->profiling) cid = counter_id(h, ((last ? "sa:fused " : "sa:") + P.label).c_str(), (last ? 4 : 2) * n8, (last ? 2 : 1) * P.flops);
     ProfScope ps(h, cid);
-    hipLaunchKernelGGL(fn, dim3(small_grid(P.sm.ntiles, P.wpt)), dim3(256), 0, h->stream, P.sm, io);
+    hipLaunchKernelGGL(fn, dim3(small_grid(P.sm, P.wpt)), dim3(256), 0, h->stream, P.sm, io);
     HIPCHK(h, hipGetLastError());
   }
   return 0;
@@ -1379,7 +1388,7 @@ int solve_sa(sdfs_handle* h, const sdfs_opts& o, double* w, int64_t* n_iter, int
   if (fused && h->knobs.sa_fused != 2) {
     const FastPass& E0 = h->fast.passes.back();
     const FastPass& E1 = h->fast.passes.front();
-    ring_n[0] = (int)small_grid(E0.sm.ntiles, E0.wpt); ring_n[1] = (int)small_grid(E1.sm.ntiles, E1.wpt);
+    ring_n[0] = (int)small_grid(E0.sm, E0.wpt); ring_n[1] = (int)small_grid(E1.sm, E1.wpt);
     ring = ring_n[0] <= SA_RING && ring_n[1] <= SA_RING;
   }
   if (ring) {
@@ -1784,6 +1793,15 @@ int solve_anderson_host(sdfs_handle* h, const sdfs_opts& o, double* w, int64_t* 
   return 0;
 }
 
+// Small-grid plan: can the Anderson loop run its fused form (fast_kernels.hpp, SM_AND_FIRST / SM_AND_LAST) with history m?
+bool anderson_fused_ok(const sdfs_handle* h, int m) {
+  if (!(h->knobs.and_fused && h->fast.ok && h->fast.small && h->fast.passes.size() >= 2 && m <= AND_FUSE_M)) return false;
+  // (pair order reversed: the application ends on the fastest pair, whose tiles are contiguous -- the push's history
+  // streams then cost 4 lines per wave request instead of 64)
+  const FastPass& L = h->fast.passes.front();
+  return (int)small_grid(L.sm, L.wpt) <= AND_FUSE_RING && L.sm.a3 != nullptr && h->fast.passes.back().sm.a3 != nullptr;
+}
+
 // The same loop with its control on the device (vec_kernels.hpp, AndState / k_and_step / k_and_mix_dev): per pass
 // T, push, one single-workgroup step kernel (Gram row, solve, safeguard, stopping test) and the update of x, every
 // launch gated on the loop's own flag; `chunk` passes per host synchronisation, replayed from a hipGraph.
@@ -1802,8 +1820,22 @@ int solve_anderson(sdfs_handle* h, const sdfs_opts& o, double* w, int64_t* n_ite
   // passes per synchronisation: a multiple of the history length, so that the slot of pass i of a chunk is fixed
   int chunk = std::max(1, o.check_every);
   chunk = ((chunk + m - 1) / m) * m;
+  // Small-grid plan: the push rides on T's last pass, the control step and the update of x on the first pass of the next
+  // application (fast_kernels.hpp, SM_AND_LAST / SM_AND_FIRST): D/2 launches per pass instead of D/2 + 3.  The state
+  // alternates between two buffers (even chunks end where they began) and the passes whose step can mix are fixed at
+  // capture time (chunks are multiples of the mixing frequency).
+  bool fusedp = !h->profiling && anderson_fused_ok(h, m);
+  if (fusedp) {
+    auto lcm = [](long long a, long long b) { long long x = a, y = b; while (y) { const long long t = x % y; x = y; y = t; } return a / x * b; };
+    const long long unit = lcm(lcm(m, 2), o.mixing_freq);
+    // (a chunk of this form ends with a launch of its own and the passes do not depend on the chunking: the default
+    // polling interval is stretched, an explicit one is honoured)
+    if (o.check_every == 32) chunk = 120;
+    if (unit > 4096) fusedp = false;
+    else chunk = (int)(((chunk + unit - 1) / unit) * unit);      // (a chunk ends with one launch of its own: the longer the better)
+  }
   if (!h->and_state) {
-    HIPCHK(h, hipMalloc((void**)&h->and_state, sizeof(AndState)));
+    HIPCHK(h, hipMalloc((void**)&h->and_state, 2 * sizeof(AndState)));
     h->misc_allocs.push_back(h->and_state);
     HIPCHK(h, hipHostMalloc((void**)&h->and_state_host, sizeof(AndState)));
   }
@@ -1814,6 +1846,8 @@ int solve_anderson(sdfs_handle* h, const sdfs_opts& o, double* w, int64_t* n_ite
     h->misc_allocs.push_back(h->and_err);
     HIPCHK(h, hipMalloc((void**)&h->and_kind, sizeof(int) * chunk));
     h->misc_allocs.push_back(h->and_kind);
+    HIPCHK(h, hipMalloc((void**)&h->and_flag, sizeof(unsigned) * chunk));
+    h->misc_allocs.push_back(h->and_flag);
     HIPCHK(h, hipHostMalloc((void**)&h->and_err_host, sizeof(double) * chunk));
     HIPCHK(h, hipHostMalloc((void**)&h->and_kind_host, sizeof(int) * chunk));
     h->and_slots = chunk;
@@ -1837,6 +1871,7 @@ int solve_anderson(sdfs_handle* h, const sdfs_opts& o, double* w, int64_t* n_ite
     I.prev_pos = -1.0; I.mix_rel = -1;
     I.gate = (o.max_iter > 0 && I.err > o.tol) ? ~0ULL : 0ULL;
     HIPCHK(h, hipMemcpyAsync(S, &I, sizeof I, hipMemcpyHostToDevice, st));
+    HIPCHK(h, hipMemcpyAsync(S + 1, &I, sizeof I, hipMemcpyHostToDevice, st));
     HIPCHK(h, hipStreamSynchronize(st));
   }
   h->trace.clear();
@@ -1849,7 +1884,7 @@ int solve_anderson(sdfs_handle* h, const sdfs_opts& o, double* w, int64_t* n_ite
       if (r2) return r2;
       ProfScope ps(h, cvec);
       hipLaunchKernelGGL(k_and_push, dim3(g), dim3(VEC_BLOCK), 0, st, (const double*)x, (const double*)fx, hp, m, pos, n, h->partial, (const unsigned long long*)&S->gate);
-      hipLaunchKernelGGL(k_and_step, dim3(1), dim3(VEC_BLOCK), 0, st, (const double*)h->partial, g, m, pos, i, S, h->and_err + i, h->and_kind + i,
+      hipLaunchKernelGGL(k_and_step, dim3(1), dim3(VEC_BLOCK), 0, st, (const double*)h->partial, g, m, pos, i, (const AndState*)S, S, h->and_err + i, h->and_kind + i,
                          o.tol, (double)o.max_iter, (int)o.mixing_freq, o.ridge);
       hipLaunchKernelGGL(k_and_mix_dev, dim3(g), dim3(VEC_BLOCK), 0, st, hp, (const AndState*)S, m, o.beta, x, (const double*)fx, pos, i, n);
     }
@@ -1859,6 +1894,70 @@ int solve_anderson(sdfs_handle* h, const sdfs_opts& o, double* w, int64_t* n_ite
     HIPCHK(h, hipMemcpyAsync(h->and_state_host, S, sizeof(AndState), hipMemcpyDeviceToHost, st));
     return 0;
   };
+  // the fused form of a chunk: pass 0 starts from x as it stands, pass i > 0 opens with the step of pass i - 1; the step
+  // and the update of the chunk's last pass are the two launches of the unfused form.  State of pass i: S[i & 1].
+  auto enqueue_fused = [&](int count) -> int {
+    HIPCHK(h, hipMemsetAsync(h->and_kind, 0, sizeof(int) * (size_t)chunk, st));
+    HIPCHK(h, hipMemsetAsync(h->and_flag, 0, sizeof(unsigned) * (size_t)chunk, st));
+    const int np = (int)h->fast.passes.size();
+    const FastPass& PF = h->fast.passes[np - 1];
+    const FastPass& PL = h->fast.passes[0];
+    const int nbl = (int)small_grid(PL.sm, PL.wpt);
+    AndStepPar par;
+    par.tol = o.tol; par.max_iter = (double)o.max_iter; par.ridge = o.ridge; par.mixing_freq = (int)o.mixing_freq;
+    for (int i = 0; i < count; ++i) {
+      const int pos = i % m;
+      AndState* Si = S + (i & 1);
+      SmallIO io;
+      AndArgs an;
+      memset(&an, 0, sizeof an);
+      an.h = hp; an.par = par; an.beta = o.beta; an.m = m; an.nb = nbl;
+      // first pass
+      memset(&io, 0, sizeof io);
+      io.out = h->tmp;
+      if (i == 0) {
+        io.in = x; io.gate = &Si->gate;
+        hipLaunchKernelGGL(small_variant(SM_FIRST_T, PF.r, PF.wpt), dim3(small_grid(PF.sm, PF.wpt)), dim3(256), 0, st, PF.sm, io);
+      } else {
+        const int ppos = (i - 1) % m;
+        io.in = fx;
+        an.Sin = S + ((i - 1) & 1); an.Sout = Si; an.partial = h->partial; an.x = x; an.x_pos = hp.X[ppos]; an.r_pos = hp.R[ppos];
+        an.err_slot = h->and_err + (i - 1); an.kind_slot = h->and_kind + (i - 1); an.flag = h->and_flag + (i - 1);
+        an.pos = ppos; an.rel = i - 1;
+        an.step_kind = (i % (int)o.mixing_freq) == 0 ? 2 : (((i - 1) % (int)o.mixing_freq) == 0 ? 1 : 0);
+        // (+ 1: the workgroup that writes the state)
+        hipLaunchKernelGGL(small_and_variant(SM_AND_FIRST, PF.r, PF.wpt), dim3(small_grid(PF.sm, PF.wpt) + 1), dim3(256), 0, st, PF.sm, io, an);
+      }
+      for (int q = np - 2; q >= 1; --q) {
+        const FastPass& PM = h->fast.passes[q];
+        memset(&io, 0, sizeof io);
+        io.in = h->tmp; io.out = h->tmp; io.gate = &Si->gate;
+        hipLaunchKernelGGL(small_variant(SM_MID, PM.r, PM.wpt), dim3(small_grid(PM.sm, PM.wpt)), dim3(256), 0, st, PM.sm, io);
+      }
+      memset(&io, 0, sizeof io);
+      io.in = h->tmp; io.out = fx; io.old = x; io.gate = &Si->gate;
+      an.Sin = nullptr; an.Sout = nullptr; an.partial = nullptr; an.partial_out = h->partial;
+      an.x_pos = hp.X[pos]; an.r_pos = hp.R[pos]; an.pos = pos; an.rel = i; an.step_kind = 0; an.flag = h->and_flag + i;
+      hipLaunchKernelGGL(small_and_variant(SM_AND_LAST, PL.r, PL.wpt), dim3(nbl), dim3(256), 0, st, PL.sm, io, an);
+    }
+    const int lastp = count - 1;
+    {
+      AndArgs an;
+      memset(&an, 0, sizeof an);
+      an.h = hp; an.par = par; an.beta = o.beta; an.m = m; an.nb = nbl;
+      an.Sin = S + (lastp & 1); an.Sout = S + (count & 1); an.partial = h->partial; an.x = x;
+      an.x_pos = hp.X[lastp % m]; an.r_pos = hp.R[lastp % m];
+      an.err_slot = h->and_err + lastp; an.kind_slot = h->and_kind + lastp; an.flag = h->and_flag + lastp;
+      an.pos = lastp % m; an.rel = lastp; an.step_kind = 2;
+      hipLaunchKernelGGL(small_and_finish, dim3((unsigned)std::min<long long>((n + 255) / 256, 512)), dim3(256), 0, st, an, (const double*)fx, n);
+    }
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipMemcpyAsync(h->and_err_host, h->and_err, sizeof(double) * (size_t)count, hipMemcpyDeviceToHost, st));
+    HIPCHK(h, hipMemcpyAsync(h->and_kind_host, h->and_kind, sizeof(int) * (size_t)count, hipMemcpyDeviceToHost, st));
+    HIPCHK(h, hipMemcpyAsync(h->and_state_host, S + (count & 1), sizeof(AndState), hipMemcpyDeviceToHost, st));
+    return 0;
+  };
+  auto enqueue_any = [&](int count) -> int { return fusedp ? enqueue_fused(count) : enqueue(count); };
   const bool graph = o.use_graph && !h->profiling && st != nullptr && chunk > 1;
   const double key[4] = {o.tol, (double)o.max_iter, o.beta, o.ridge};
   if (graph && (h->and_graph == nullptr || h->and_graph_chunk != chunk || h->and_graph_m != m || h->and_graph_freq != (int)o.mixing_freq ||
@@ -1866,7 +1965,7 @@ int solve_anderson(sdfs_handle* h, const sdfs_opts& o, double* w, int64_t* n_ite
     if (h->and_graph) { hipGraphExecDestroy(h->and_graph); h->and_graph = nullptr; }
     hipGraph_t gr = nullptr;
     HIPCHK(h, hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
-    rc = enqueue(chunk);
+    rc = enqueue_any(chunk);
     hipError_t e = hipStreamEndCapture(st, &gr);
     if (rc || e != hipSuccess) {
       if (gr) hipGraphDestroy(gr);
@@ -1884,7 +1983,7 @@ int solve_anderson(sdfs_handle* h, const sdfs_opts& o, double* w, int64_t* n_ite
   while (running && enq < o.max_iter) {
     const int count = (int)std::min<long long>(chunk, o.max_iter - enq);
     if (graph && count == chunk) { HIPCHK(h, hipGraphLaunch(h->and_graph, st)); }
-    else if ((rc = enqueue(count))) return rc;
+    else if ((rc = enqueue_any(count))) return rc;
     HIPCHK(h, hipStreamSynchronize(st));
     enq += count;
     if (o.record_errors)
@@ -2745,7 +2844,7 @@ int sdfs_describe_plan(const sdfs_handle* h, char* buf, int64_t cap) {
       int occ = -1;
       if (P.small) {
         snprintf(line, sizeof line, "small-grid plan pass %zu: %s %d wave%s per tile, run %d, tiles %lld, workgroups %u\n", i,
-                 P.label.c_str(), P.wpt, P.wpt == 1 ? "" : "s", P.r, P.sm.ntiles, small_grid(P.sm.ntiles, P.wpt));
+                 P.label.c_str(), P.wpt, P.wpt == 1 ? "" : "s", P.r, P.sm.ntiles, small_grid(P.sm, P.wpt));
       } else if (!P.line) {
         hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)slice_variant(P.n, S_TFIRST), 256, slice_lds_bytes(P.n));
         const long long nt = (P.sd.nslices + slice_tile_slices(P.n) - 1) / slice_tile_slices(P.n);
@@ -2760,6 +2859,8 @@ int sdfs_describe_plan(const sdfs_handle* h, char* buf, int64_t cap) {
       }
       s += line;
     }
+    if (h->fast.small && anderson_fused_ok(h, 10))
+      s += "small-grid plan, Anderson: passes in reverse order, push on the last pass, control step + update of x on the first\n";
     s += "generic plan (fp32 Krylov storage, sharded stages):\n";
   }
   for (int st = 0; st < 2; ++st) {

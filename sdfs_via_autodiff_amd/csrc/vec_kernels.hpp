@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "anderson_step.hpp"
 #include "wave_reduce.hpp"
 
 namespace sdfs {
@@ -446,8 +447,7 @@ k_newton_update(const double* __restrict__ x, const T* __restrict__ step,
 // ---- Anderson ---------------------------------------------------------------
 // r = fx - x stored into R[pos]; X[pos] = x; partial sums of <r, R[j]> for j < m
 // (row `pos` of the Gram matrix; R[pos] itself is the fresh r).
-constexpr int AND_MAX_M = 16;
-struct AndPtrs { double* X[AND_MAX_M]; double* R[AND_MAX_M]; };
+// (AND_MAX_M, AndPtrs: anderson_step.hpp)
 
 __global__ void __launch_bounds__(VEC_BLOCK)
 k_and_push(const double* __restrict__ x, const double* __restrict__ fx, AndPtrs h, int m, int pos,
@@ -505,116 +505,25 @@ k_and_mix(AndPtrs h, AndCoef c, int m, double beta, double* __restrict__ xnext, 
 
 // ---- Anderson, device-resident control -------------------------------------------------------------------------
 // The loop of solve_anderson (sdfs_api.hip) -- Gram matrix, the (m+1) x (m+1) solve of jaxopt's parametrisation
-// (code/solvers.py:98-124), the rejection safeguard and the stopping test -- as state in device memory, advanced by
-// one single-workgroup kernel per iteration, so that the host enqueues (or replays from a hipGraph) whole chunks of
-// iterations and synchronises once per chunk.
-struct AndState {
-  double G[AND_MAX_M * AND_MAX_M];
-  double coef[AND_MAX_M];
-  double mix_beta;
-  double err;
-  double it;                 // loop passes executed
-  double rejected, no_mix_until, last_mixed, prev_pos;
-  double status;             // 1: non-finite residual ended the loop
-  unsigned long long gate;   // ~0 while the loop runs, 0 once it has ended
-  int mix_rel;               // index (within the chunk) of the pass whose update of x is due
-  int mix_mode;              // 0: x = fx;  1: x = sum_j coef_j (X_j + mix_beta R_j);  2: the same and R[pos] = 0 (rejected step)
-};
-
-// (mode 2 leaves the poisoned history slot `pos` out of the sum: its residual is NaN until the same kernel has zeroed it)
-// kinds of a pass in the per-chunk record: 0 = not executed (loop had ended), 1 = regular (its error joins the trace), 2 = rejected
+// (code/solvers.py:98-124), the rejection safeguard and the stopping test -- as state in device memory (AndState,
+// and_step_wave: anderson_step.hpp), advanced by one single-workgroup kernel per iteration, so that the host enqueues
+// (or replays from a hipGraph) whole chunks of iterations and synchronises once per chunk.  Sout = Sin: in place
+// (every read of the state precedes the first write).
 __global__ void __launch_bounds__(VEC_BLOCK)
-k_and_step(const double* __restrict__ partial, int nb, int m, int pos, int rel, AndState* __restrict__ S,
-           double* __restrict__ err_slot, int* __restrict__ kind_slot, double tol, double max_iter, int mixing_freq, double ridge) {
-#pragma clang fp contract(off)
-  SDFS_GATED(&S->gate);
-  __shared__ double row[AND_MAX_M];
-  __shared__ double Gs[AND_MAX_M * AND_MAX_M];
-  __shared__ double A[(AND_MAX_M + 1) * (AND_MAX_M + 1)];
-  __shared__ double b[AND_MAX_M + 1];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  // the Gram matrix and the loop's scalars come in with one parallel round of loads
-  if (tid < m * m) Gs[tid] = S->G[tid];
-  const double it = S->it, prev_pos_d = S->prev_pos, last_mixed = S->last_mixed, rejected = S->rejected, no_mix_until = S->no_mix_until;
-  gram_row_sums(partial, nb, m, row);
-  __syncthreads();
-  if (wave != 0) return;                 // the rest is one wave's work: LDS operations of a wave execute in order
-  if (lane < m) { Gs[pos * m + lane] = row[lane]; Gs[lane * m + pos] = row[lane]; }
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
-  const int d = m + 1;
-  const int prev_pos = (int)prev_pos_d;
-  double err = sqrt(Gs[pos * m + pos]);
-  const bool reject = !isfinite(err) && last_mixed != 0.0 && prev_pos >= 0 && rejected < 1000.0;   // uniform
-  if (reject) {
-    // a mixing step left the domain: plain step from the last good iterate, drop the poisoned slot, pause mixing
-    err = sqrt(Gs[prev_pos * m + prev_pos]);
-    if (lane < m) { S->G[pos * m + lane] = 0.0; S->G[lane * m + pos] = 0.0; S->coef[lane] = (lane == prev_pos) ? 1.0 : 0.0; }
-    if (lane == 0) {
-      S->mix_beta = 1.0; S->mix_mode = 2; S->mix_rel = rel;
-      S->last_mixed = 0.0; S->rejected = rejected + 1.0; S->it = it + 1.0; S->no_mix_until = it + 1.0 + m;
-      S->err = err;
-      *kind_slot = 2;
-      if (!(err > tol && it + 1.0 < max_iter)) S->gate = 0ULL;
-    }
+k_and_step(const double* __restrict__ partial, int nb, int m, int pos, int rel, const AndState* Sin, AndState* Sout,
+           double* __restrict__ err_slot, int* __restrict__ kind_slot, double tol, double max_iter, int mixing_freq, double ridge,
+           const unsigned* __restrict__ flag = nullptr) {
+  __shared__ AndStepLds sh;
+  if (Sin->gate == 0ULL) {
+    if (threadIdx.x < 64) and_state_carry((int)threadIdx.x, Sin, Sout);
     return;
   }
-  if (lane < m) { S->G[pos * m + lane] = row[lane]; S->G[lane * m + pos] = row[lane]; }
-  const bool want_mix = it + 1.0 >= m && it + 1.0 >= no_mix_until && ((long long)(it + 1.0)) % mixing_freq == 0 && isfinite(err);   // uniform
-  bool mixed = false;
-  if (want_mix) {
-    auto wsync = [&]() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); };
-    for (int i = lane; i < d * d; i += 64) {
-      const int r = i / d, c = i - r * d;
-      A[i] = (r == 0) ? (c == 0 ? 0.0 : 1.0) : (c == 0 ? 1.0 : Gs[(r - 1) * m + c - 1] + (r == c ? ridge : 0.0));
-    }
-    if (lane < d) b[lane] = lane == 0 ? 1.0 : 0.0;
-    wsync();
-    // Gaussian elimination with partial pivoting, the operations of the host's solve_dense in the same order (no
-    // fused multiply-adds); lane r owns row r.  Pivot = first row of the largest |entry|, as the host's scan finds it
-    mixed = true;
-    for (int c = 0; c < d; ++c) {
-      const double mine = (lane >= c && lane < d) ? fabs(A[lane * d + c]) : -1.0;
-      const double big = wave_max(mine);
-      if (big == 0.0 || !(big == big)) { mixed = false; break; }     // (a NaN column: the host's scan keeps row c and divides by NaN; no mixing either way)
-      const int piv = __ffsll((long long)__ballot(mine == big)) - 1;
-      if (piv != c) {
-        double t0 = 0.0, t1 = 0.0;
-        if (lane < d) { t0 = A[c * d + lane]; t1 = A[piv * d + lane]; }
-        const double b0 = b[c], b1 = b[piv];
-        wsync();
-        if (lane < d) { A[c * d + lane] = t1; A[piv * d + lane] = t0; }
-        if (lane == 0) { b[c] = b1; b[piv] = b0; }
-        wsync();
-      }
-      if (lane > c && lane < d) {
-        const double f = A[lane * d + c] / A[c * d + c];
-        if (f != 0.0) {
-          for (int k = c; k < d; ++k) A[lane * d + k] -= f * A[c * d + k];
-          b[lane] -= f * b[c];
-        }
-      }
-      wsync();
-    }
-    if (mixed && lane == 0) {
-      for (int r = d - 1; r >= 0; --r) {
-        double s = b[r];
-        for (int k = r + 1; k < d; ++k) s -= A[r * d + k] * b[k];
-        b[r] = s / A[r * d + r];
-      }
-    }
-    wsync();
-    if (mixed && lane < m) S->coef[lane] = b[lane + 1];
-  }
-  if (lane == 0) {
-    *err_slot = err; *kind_slot = 1;
-    S->err = err;
-    S->mix_mode = mixed ? 1 : 0;
-    S->mix_rel = rel;
-    S->last_mixed = mixed ? 1.0 : 0.0; S->prev_pos = (double)pos;
-    S->it = it + 1.0;
-    if (!isfinite(err)) { S->status = 1.0; S->gate = 0ULL; }
-    else if (!(err > tol && it + 1.0 < max_iter)) S->gate = 0ULL;
-  }
+  gram_row_sums(partial, nb, m, sh.row);
+  __syncthreads();
+  if (threadIdx.x >= 64) return;         // the rest is one wave's work: LDS operations of a wave execute in order
+  AndStepPar par;
+  par.tol = tol; par.max_iter = max_iter; par.ridge = ridge; par.mixing_freq = mixing_freq;
+  and_step_wave<AND_MAX_M + 1>(sh, (int)threadIdx.x, m, pos, rel, Sin, Sout, true, err_slot, kind_slot, par, flag != nullptr ? (int)(*flag != 0u) : -1);
 }
 
 // the update of x that pass `rel` decided on (runs also for the pass that ended the loop)

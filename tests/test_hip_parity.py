@@ -585,26 +585,34 @@ def J_at(oJ, x, shapes):
     return np.stack([oJ(x, e.reshape(shapes)).ravel() for e in np.eye(n)], axis=1)
 
 
+def _anderson_builder(S):
+    import os
+
+    def build(model, shapes, host, fused=False):
+        m = S.SSY() if model == "ssy" else S.GCY()
+        arr = (S.discretize_ssy if model == "ssy" else S.discretize_gcy)(m, shapes)
+        old = {k: os.environ.get(k) for k in ("SDFS_AND_HOST", "SDFS_AND_FUSED")}
+        os.environ["SDFS_AND_HOST"] = "1" if host else "0"
+        os.environ["SDFS_AND_FUSED"] = "1" if fused else "0"
+        try:
+            return S.KoopmansOperator(model, shapes, m.params, arr)
+        finally:
+            for k, v in old.items():
+                if v is None:
+                    del os.environ[k]
+                else:
+                    os.environ[k] = v
+    return build
+
+
 def test_anderson_device_loop_matches_host_controlled_loop(S):
     """The Anderson loop keeps its control (Gram matrix, (m+1) x (m+1) solve, rejection safeguard, stopping test) on
     the device and synchronises once per chunk of passes.  Same passes, errors and iterate as the loop that solves
     on the host after every pass (SDFS_AND_HOST=1): with and without hipGraph replay, for chunk lengths that are
-    not multiples of the history, when max_iter ends the loop, and through the safeguard at GCY 12^6."""
-    import os
-
-    def build(model, shapes, host):
-        m = S.SSY() if model == "ssy" else S.GCY()
-        arr = (S.discretize_ssy if model == "ssy" else S.discretize_gcy)(m, shapes)
-        old = os.environ.get("SDFS_AND_HOST")
-        os.environ["SDFS_AND_HOST"] = "1" if host else "0"
-        try:
-            return S.KoopmansOperator(model, shapes, m.params, arr)
-        finally:
-            if old is None:
-                del os.environ["SDFS_AND_HOST"]
-            else:
-                os.environ["SDFS_AND_HOST"] = old
-
+    not multiples of the history, when max_iter ends the loop, and through the safeguard at GCY 12^6.  (The launches
+    of their own for push / step / update, SDFS_AND_FUSED=0: they add the Gram row in the host loop's order; the fused
+    small-grid form has its own test below.)"""
+    build = _anderson_builder(S)
     for model, shapes, tol in (("ssy", (3, 3, 3, 3), 1e-6), ("ssy", (15,) * 4, 1e-6), ("gcy", (3, 4, 2, 3, 2, 4), 1e-6)):
         Td, Th = build(model, shapes, False), build(model, shapes, True)
         w0 = np.full(shapes, 800.0)
@@ -633,6 +641,84 @@ def test_anderson_device_loop_matches_host_controlled_loop(S):
     assert idv["status"] == 0 and np.all(np.isfinite(xd))
     assert abs(nd - nh) <= max(8, nh // 10), (nd, nh)
     np.testing.assert_allclose(xd, xh, rtol=0, atol=1e-4)
+
+
+@pytest.mark.parametrize("model,shapes", [("ssy", (3, 3, 3, 3)), ("ssy", (15,) * 4), ("ssy", (7, 16, 5, 9)),
+                                          ("gcy", (3, 4, 2, 3, 2, 4)), ("gcy", (6,) * 6), ("gcy", (4, 5, 6, 7, 4, 5))])
+def test_anderson_fused_small_grid_loop(S, model, shapes):
+    """Small-grid plan, default: the push rides on T's last pass, the control step of a pass and the update of x on the
+    first pass of the next application (SM_AND_LAST / SM_AND_FIRST, D/2 launches per pass).  The Gram row is then added
+    tile by tile, so the iteration path -- which follows the last bits of that ill-conditioned matrix -- is not the host
+    loop's bit for bit.  Held here: before the first mixing step (pass 12) the iterates are the host loop's; the error
+    trace agrees while the paths have not parted (first mixing steps); the loop stops by the same rule at a point whose
+    residual is the tolerance's; chunking and graph replay do not change the passes; max_iter is honoured exactly."""
+    build = _anderson_builder(S)
+    Tf, Th = build(model, shapes, False, fused=True), build(model, shapes, True)
+    w0 = np.full(shapes, 800.0)
+    tol = 1e-6
+    # the reference's parameters: identical until the first mixing step (pass 12), then the paths part
+    for k in (1, 2, 5, 11, 12, 21, 40):
+        xf, nf, inf = Tf.solve(w0, "anderson", tol=0.0, max_iter=k, record_errors=True)
+        xh, nh, ih = Th.solve(w0, "anderson", tol=0.0, max_iter=k, record_errors=True)
+        assert nf == nh == k and inf["n_apply"] == k and len(inf["errors"]) == len(ih["errors"]), (k, nf, nh)
+        if k < 12:
+            np.testing.assert_allclose(inf["errors"], ih["errors"], rtol=1e-12)
+            np.testing.assert_allclose(xf, xh, rtol=1e-12)
+        else:
+            np.testing.assert_allclose(inf["errors"][:12], ih["errors"][:12], rtol=1e-12)
+    # a well-conditioned Gram system (large ridge, beta 1): rounding is not amplified, so the whole path -- every kind
+    # of step, chunk boundaries, mixing with a partly filled and a full history -- is the host loop's to rounding
+    kw = dict(ridge=1e9, beta=1.0, record_errors=True)
+    for k in (12, 13, 16, 20, 21, 40, 41, 57):
+        xf, nf, inf = Tf.solve(w0, "anderson", tol=0.0, max_iter=k, **kw)
+        xh, nh, ih = Th.solve(w0, "anderson", tol=0.0, max_iter=k, **kw)
+        assert nf == nh == k and len(inf["errors"]) == len(ih["errors"]) == k
+        np.testing.assert_allclose(inf["errors"], ih["errors"], rtol=1e-9)
+        np.testing.assert_allclose(xf, xh, rtol=1e-11)
+    xf, nf, inf = Tf.solve(w0, "anderson", tol=0.0, max_iter=30, history=3, mixing_freq=2, check_every=5, **kw)
+    xh, nh, ih = Th.solve(w0, "anderson", tol=0.0, max_iter=30, history=3, mixing_freq=2, **kw)
+    np.testing.assert_allclose(inf["errors"], ih["errors"], rtol=1e-9)
+    np.testing.assert_allclose(xf, xh, rtol=1e-11)
+    xh, nh, ih = Th.solve(w0, "anderson", tol=tol, record_errors=True)
+    ref = None
+    for kw in ({}, dict(check_every=7), dict(use_graph=0, check_every=3), dict(check_every=1), dict(check_every=100)):
+        xf, nf, inf = Tf.solve(w0, "anderson", tol=tol, record_errors=True, **kw)
+        assert inf["status"] == 0 and inf["final_err"] <= tol and len(inf["errors"]) <= nf
+        assert inf["errors"][-1] == inf["final_err"] and (nf < 2 or inf["errors"][-2] > tol)
+        if ref is None:
+            ref = (xf, nf, inf["errors"])
+        else:       # the passes do not depend on how they are chunked
+            assert nf == ref[1] and np.array_equal(xf, ref[0]) and np.array_equal(inf["errors"], ref[2]), kw
+        assert nf <= 2 * nh + 20, (nf, nh)
+        # |x - x*| <= |T x - x|_2 / (1 - modulus): both loops end within that of each other
+        np.testing.assert_allclose(xf, xh, rtol=0, atol=2e-3)
+        r = np.max(np.abs(Tf(xf) - xf))
+        assert r <= tol
+    xf, nf, inf = Tf.solve(w0, "anderson", tol=tol, history=3, mixing_freq=2, beta=1.0, ridge=1e-8, max_iter=60000)
+    xh3, nh3, ih3 = Th.solve(w0, "anderson", tol=tol, history=3, mixing_freq=2, beta=1.0, ridge=1e-8, max_iter=60000)
+    assert inf["final_err"] <= tol and ih3["final_err"] <= tol, (nf, nh3, inf["final_err"], ih3["final_err"])
+    assert nf <= 2 * nh3 + 20
+    np.testing.assert_allclose(xf, xh3, rtol=0, atol=2e-3)
+    assert "Anderson: passes in reverse order" in Tf.describe_plan() and "Anderson" not in Th.describe_plan()
+
+
+def test_anderson_fused_loop_through_the_safeguard(S):
+    """A mixing step that leaves the domain inside the fused loop (GCY 6^6 from a start close to zero with strong
+    mixing): rejected passes are recorded, the loop recovers and ends at the fixed point the host-controlled loop finds."""
+    build = _anderson_builder(S)
+    shapes = (6,) * 6
+    Tf, Th = build("gcy", shapes, False, fused=True), build("gcy", shapes, True)
+    assert "Anderson: passes in reverse order" in Tf.describe_plan()
+    hit = False
+    for level, beta in ((800.0, 8.0), (5.0, 8.0), (5.0, 30.0), (1.0, 60.0)):
+        w0 = np.full(shapes, level)
+        xf, nf, inf = Tf.solve(w0, "anderson", tol=1e-6, max_iter=8000, beta=beta, record_errors=True)
+        xh, nh, ih = Th.solve(w0, "anderson", tol=1e-6, max_iter=8000, beta=beta, record_errors=True)
+        assert inf["status"] == ih["status"] == 0 and np.all(np.isfinite(xf))
+        np.testing.assert_allclose(xf, xh, rtol=0, atol=2e-3)
+        assert nf <= 2 * nh + 20
+        hit = hit or len(inf["errors"]) < nf          # rejected passes run but stay out of the trace
+    assert hit, "no start / beta of this test reached the safeguard: pick harsher ones"
 
 
 @pytest.mark.parametrize("model,shapes,beta,gamma,psi,level", [
