@@ -49,16 +49,7 @@ __device__ __forceinline__ void and_wsync() { __builtin_amdgcn_fence(__ATOMIC_AC
 // fused multiply-adds -- with the matrix in REGISTERS: lane r owns row r, pivot rows travel by v_readlane.  (Round 2
 // kept the matrix in LDS: every multiply-subtract of the inner loops then waited for two LDS round trips, 17 us for
 // m = 10, most of a mixing pass.)  Returns false if a pivot column is all zeros (no mixing); alpha goes to coef[0..m).
-// FAST (the fused small-grid loop, whose Gram rows are added in an order of their own anyway): quotients as products
-// with a Newton-refined v_rcp_f64 -- one per pivot, and one for all diagonal entries of the back substitution -- and
-// the pivot search inside the one DPP row that holds the system (d <= 16): 1050 instead of 1900 instructions.
-__device__ __forceinline__ double and_rcp(double x) {
-  double r = __builtin_amdgcn_rcp(x);
-  r = fma(fma(-x, r, 1.0), r, r);
-  r = fma(fma(-x, r, 1.0), r, r);
-  return r;
-}
-template <int DMAX, bool FAST = false>
+template <int DMAX>
 __device__ __forceinline__ bool and_solve_regs(const double* __restrict__ Gs, int m, double ridge, int lane, double* __restrict__ coef) {
 #pragma clang fp contract(off)
   const int d = m + 1;
@@ -70,18 +61,11 @@ __device__ __forceinline__ bool and_solve_regs(const double* __restrict__ Gs, in
     a[k] = v;
   }
   bool ok = true;
-  double dg = 0.0;                                                       // FAST: reciprocal of this lane's pivot
 #pragma unroll
   for (int c = 0; c < DMAX; ++c) {
     if (c < d && ok) {                                                   // uniform
       const double mine = (lane >= c && lane < d) ? fabs(a[c]) : -1.0;
-      double big;
-      if (FAST && DMAX <= 16) {
-        double t = mine;                                                   // rows 0 .. d-1 sit in the first DPP row
-        t = fmax(t, dpp_mov_f64<0xB1>(t)); t = fmax(t, dpp_mov_f64<0x4E>(t));
-        t = fmax(t, dpp_mov_f64<0x141>(t)); t = fmax(t, dpp_mov_f64<0x140>(t));
-        big = readlane_f64(t, 0);
-      } else big = wave_max_f64(mine);
+      const double big = wave_max_f64(mine);
       if (big == 0.0 || !(big == big)) ok = false;                       // (a NaN column: the host's scan keeps row c and divides by NaN; no mixing either way)
       else {
         // pivot = first row of the largest |entry|, as the host's scan finds it
@@ -99,10 +83,8 @@ __device__ __forceinline__ bool and_solve_regs(const double* __restrict__ Gs, in
 #pragma unroll
         for (int k = c; k < DMAX; ++k) prow[k] = readlane_f64(a[k], c);
         const double pb = readlane_f64(bb, c);
-        const double pinv = FAST ? and_rcp(prow[c]) : 0.0;
-        if (FAST && lane == c) dg = pinv;
         if (lane > c && lane < d) {
-          const double f = FAST ? a[c] * pinv : a[c] / prow[c];
+          const double f = a[c] / prow[c];
           if (f != 0.0) {
 #pragma unroll
             for (int k = c; k < DMAX; ++k) a[k] -= f * prow[k];         // (columns >= d hold zeros)
@@ -124,9 +106,81 @@ __device__ __forceinline__ bool and_solve_regs(const double* __restrict__ Gs, in
 #pragma unroll
       for (int k = r + 1; k < DMAX; ++k)
         if (k < d) sacc -= a[k] * xs[k];
-      const double xr = FAST ? sacc * dg : sacc / a[r];
+      const double xr = sacc / a[r];
       xs[r] = readlane_f64(xr, r);
       if (lane == r && r >= 1) coef[r - 1] = xr;
+    }
+  }
+  return true;
+}
+
+// The same system for the fused small-grid loop, whose Gram rows are added in an order of their own anyway (no bitwise
+// twin on the host to follow): partial pivoting WITHOUT moving rows -- the pivot row stays in its lane and leaves the
+// set of candidates; the row swaps of the routine above were 2/3 of its 4800 instructions, 7 us of a mixing pass --,
+// the pivot search inside the one DPP row that holds the system (d <= 16), quotients as products with a
+// Newton-refined v_rcp_f64 (one per pivot).  About 1000 instructions.
+__device__ __forceinline__ double and_rcp(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  r = fma(fma(-x, r, 1.0), r, r);
+  r = fma(fma(-x, r, 1.0), r, r);
+  return r;
+}
+template <int DMAX>
+__device__ __forceinline__ bool and_solve_fast(const double* __restrict__ Gs, int m, double ridge, int lane, double* __restrict__ coef) {
+  static_assert(DMAX <= 16, "one DPP row");
+  const int d = m + 1;
+  double a[DMAX], bb = lane == 0 ? 1.0 : 0.0;
+#pragma unroll
+  for (int k = 0; k < DMAX; ++k) {
+    double v = 0.0;
+    if (lane < d && k < d) v = lane == 0 ? (k == 0 ? 0.0 : 1.0) : (k == 0 ? 1.0 : Gs[(lane - 1) * m + (k - 1)] + (lane == k ? ridge : 0.0));
+    a[k] = v;
+  }
+  bool ok = true, cand = lane < d;            // cand: this row has not been a pivot row yet
+  double dg = 0.0;                            // reciprocal of this row's pivot
+  int pl[DMAX];                               // lane of the pivot row of column c (uniform)
+#pragma unroll
+  for (int c = 0; c < DMAX; ++c) {
+    pl[c] = 0;
+    if (c < d && ok) {                                                   // uniform
+      const double mine = cand ? fabs(a[c]) : -1.0;
+      double t = mine;
+      t = fmax(t, dpp_mov_f64<0xB1>(t)); t = fmax(t, dpp_mov_f64<0x4E>(t));
+      t = fmax(t, dpp_mov_f64<0x141>(t)); t = fmax(t, dpp_mov_f64<0x140>(t));
+      const double big = readlane_f64(t, 0);
+      if (!(big > 0.0)) ok = false;                                       // all zeros (or NaN): no mixing
+      else {
+        const int piv = __builtin_amdgcn_readfirstlane(__ffsll((long long)__ballot(mine == big)) - 1);
+        pl[c] = piv;
+        double prow[DMAX];
+#pragma unroll
+        for (int k = c; k < DMAX; ++k) prow[k] = readlane_f64(a[k], piv);
+        const double pb = readlane_f64(bb, piv);
+        const double pinv = and_rcp(prow[c]);
+        if (lane == piv) { dg = pinv; cand = false; }
+        if (cand) {
+          const double f = a[c] * pinv;
+#pragma unroll
+          for (int k = c + 1; k < DMAX; ++k) a[k] = fma(-f, prow[k], a[k]);      // (columns >= d hold zeros)
+          bb = fma(-f, pb, bb);
+        }
+      }
+    }
+  }
+  if (!ok) return false;
+  // back substitution: the row of column r sits in lane pl[r]
+  double xs[DMAX];
+#pragma unroll
+  for (int k = 0; k < DMAX; ++k) xs[k] = 0.0;
+#pragma unroll
+  for (int r = DMAX - 1; r >= 0; --r) {
+    if (r < d) {                                                          // uniform
+      double sacc = bb;
+#pragma unroll
+      for (int k = r + 1; k < DMAX; ++k) sacc = fma(-a[k], xs[k], sacc);   // (xs[k] = 0 for k >= d)
+      const double xr = sacc * dg;
+      xs[r] = readlane_f64(xr, pl[r]);
+      if (lane == pl[r] && r >= 1) coef[r - 1] = xr;
     }
   }
   return true;
@@ -170,7 +224,7 @@ __device__ __forceinline__ void and_step_wave(AndStepLds& sh, int lane, int m, i
     const bool want_mix = it + 1.0 >= m && it + 1.0 >= no_mix_until && ((long long)(it + 1.0)) % par.mixing_freq == 0 && isfinite(err);   // uniform
     bool mixed = false;
     if (want_mix) {
-      mixed = and_solve_regs<DMAX, FAST>(Gs, m, par.ridge, lane, sh.coef);
+      mixed = FAST ? and_solve_fast<FAST ? DMAX : 1>(Gs, m, par.ridge, lane, sh.coef) : and_solve_regs<DMAX>(Gs, m, par.ridge, lane, sh.coef);
       and_wsync();
     }
     mode = mixed ? 1 : 0; kind = 1;

@@ -968,7 +968,7 @@ __device__ __forceinline__ void small_tile_body(const SmallDesc& P, const SmallI
   __shared__ double red[12];
   constexpr int AND_LDS = (int)(sizeof(AndStepLds) / 8);
   __shared__ __attribute__((aligned(16))) double and_raw[ANDF ? AND_LDS : 1];         // the control step of wave 0
-  __shared__ double redj[ANDL ? AND_FUSE_M * 16 : 1];
+  __shared__ double redj[ANDL ? AND_FUSE_M * 256 : 1];
   // the gate word is fetched first and tested behind the tile loads (nothing is written before the test)
   const unsigned long long gate_word = io.gate != nullptr ? *io.gate : ~0ULL;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -987,9 +987,25 @@ __device__ __forceinline__ void small_tile_body(const SmallDesc& P, const SmallI
   // launches behind this one are gated and x = fx is the final update anyway), whether the pass is rejected (1: the
   // diagonal entry of the Gram row), everything (2: a mixing step: wave 0 of every workgroup works it out, the same
   // operations everywhere).  The state is written by an extra workgroup that has no tile (the last one), off every
-  // tile's path.  One copy of the code, in front of the tile's own work: unrolled twice it was 130 KB of instructions
-  // that every launch fetched cold (tools/probes/anderson_fused_probe.hip: 15 us for the row sums alone).
+  // tile's path.  (The first form of this code, ring sums and solve unrolled per wave, was 130 KB of instructions that
+  // every launch fetched cold -- tools/probes/anderson_fused_probe.hip: 15 us for the row sums alone.)
   int and_mode = 0, and_open = 1, and_prev = 0;
+  // the whole step, by a workgroup: Gram row (all waves), control step and solve (wave 0), decision to every wave
+  auto and_step_site = [&](bool writer, int nonfinite) {
+    AndStepLds& sh = *reinterpret_cast<AndStepLds*>(and_raw);
+    SDFS_AND_STAMP(0);
+    and_row_sums16(an->partial, an->nb, an->m, -1, sh.row);
+    __syncthreads();
+    SDFS_AND_STAMP(1);
+    if (wave == 0)
+      and_step_wave<AND_FUSE_M + 1, true>(sh, lane, an->m, an->pos, an->rel, an->Sin, an->Sout, writer, an->err_slot, an->kind_slot, an->par, nonfinite);
+    __syncthreads();
+    SDFS_AND_STAMP(2);
+    and_mode = __builtin_amdgcn_readfirstlane(sh.mix_mode);
+    and_open = __builtin_amdgcn_readfirstlane(sh.open);
+    and_prev = __builtin_amdgcn_readfirstlane(sh.prev_pos);
+  };
+  int and_nonfinite = 0;
   if (ANDF) {
     const bool ctrl = blockIdx.x == gridDim.x - 1;
     if (an->Sin->gate == 0ULL) {                // the loop has ended: carry its final state along
@@ -997,6 +1013,7 @@ __device__ __forceinline__ void small_tile_body(const SmallDesc& P, const SmallI
       return;
     }
     const int nonfinite = (int)(*an->flag != 0u);
+    and_nonfinite = nonfinite;
     if (!ctrl && an->step_kind == 1) {
       // the pass behind a mixing step: is it rejected?  (its push has recorded whether it met a non-finite residual)
       if (nonfinite) {
@@ -1007,22 +1024,10 @@ __device__ __forceinline__ void small_tile_body(const SmallDesc& P, const SmallI
           and_open = (sqrt(Sp->G[pp * an->m + pp]) > an->par.tol && Sp->it + 1.0 < an->par.max_iter) ? 1 : 0;
         }
       }
-    } else if (ctrl || an->step_kind == 2) {
-      AndStepLds& sh = *reinterpret_cast<AndStepLds*>(and_raw);
-      const bool full = ctrl || an->step_kind == 2;
-      SDFS_AND_STAMP(0);
-      and_row_sums16(an->partial, an->nb, an->m, full ? -1 : an->pos, sh.row);
-      __syncthreads();
-      SDFS_AND_STAMP(1);
-      if (wave == 0)
-        and_step_wave<AND_FUSE_M + 1, true>(sh, lane, an->m, an->pos, an->rel, an->Sin, an->Sout, ctrl, an->err_slot, an->kind_slot, an->par, nonfinite);
-      __syncthreads();
-      SDFS_AND_STAMP(2);
-      and_mode = __builtin_amdgcn_readfirstlane(sh.mix_mode);
-      and_open = __builtin_amdgcn_readfirstlane(sh.open);
-      and_prev = __builtin_amdgcn_readfirstlane(sh.prev_pos);
+    } else if (ctrl) {
+      and_step_site(true, nonfinite);
+      return;
     }
-    if (ctrl) return;
   }
   double acc[ANDL ? AND_FUSE_M : 1];            // Anderson, last pass: <r, R_j> over this thread's elements
 #pragma unroll
@@ -1111,6 +1116,8 @@ __device__ __forceinline__ void small_tile_body(const SmallDesc& P, const SmallI
             if (k == 0 || TPT * k < total) hx[ANDF ? j : 0][k] = px[base + g[k]];
         }
       }
+      // a mixing step: every workgroup works it out (the same operations everywhere), with the tile and the history in flight
+      if (full) and_step_site(false, and_nonfinite);
       const int mix_mode = and_mode;
       if (mix_mode == 1 && full) {
         // x = sum_j coef_j Y_j
@@ -1326,24 +1333,24 @@ __device__ __forceinline__ void small_tile_body(const SmallDesc& P, const SmallI
   }
   if (ANDL) {
     if (__any(rnan) && lane == 0) atomicOr(an->flag, 1u);          // (rare: a mixing step left the domain)
+    // <r, R_j> of the workgroup through LDS: every thread parks its m sums, 16 lanes per stream add 16 each and meet
+    // in one DPP row (ten wave reductions, DPP and v_readlane chains, were 2500 of the kernel's 9000 cycles)
 #pragma unroll
     for (int j = 0; j < AND_FUSE_M; ++j)
-      if (j < an->m) {
-        // the 16 lanes of a DPP row, then 4 rows x 4 waves through LDS (the v_readlane tail of wave_sum_f64, ten times
-        // over, was 2500 of the kernel's 9000 cycles)
-        double sj = acc[ANDL ? j : 0];
-        sj += dpp_mov_f64<0xB1>(sj);
-        sj += dpp_mov_f64<0x4E>(sj);
-        sj += dpp_mov_f64<0x141>(sj);
-        sj += dpp_mov_f64<0x140>(sj);
-        if ((lane & 15) == 0) redj[ANDL ? j * 16 + wave * 4 + (lane >> 4) : 0] = sj;
-      }
+      if (j < an->m) redj[ANDL ? j * 256 + tid : 0] = acc[ANDL ? j : 0];
     __syncthreads();
-    if (tid < an->m) {
+    if (wave < 3) {                                     // (m <= 12 streams of 16 lanes; all lanes of a participating wave: DPP)
+      const int j = tid >> 4, q = tid & 15;
       double sj = 0.0;
+      if (j < an->m) {
 #pragma unroll
-      for (int q = 0; q < 16; ++q) sj += redj[ANDL ? tid * 16 + q : 0];
-      an->partial_out[blockIdx.x + tid * gridDim.x] = sj;
+        for (int i = 0; i < 16; ++i) sj += redj[ANDL ? j * 256 + q + 16 * i : 0];
+      }
+      sj += dpp_mov_f64<0xB1>(sj);
+      sj += dpp_mov_f64<0x4E>(sj);
+      sj += dpp_mov_f64<0x141>(sj);
+      sj += dpp_mov_f64<0x140>(sj);
+      if (q == 0 && j < an->m) an->partial_out[blockIdx.x + j * gridDim.x] = sj;
     }
   }
   if (CES && (io.resid != nullptr || io.part_out != nullptr)) {
