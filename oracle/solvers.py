@@ -155,36 +155,46 @@ def anderson_solver(f, x_init, tol=default_tolerance, max_iter=10000, verbose=Tr
 
 def fixed_point_via_gradient_decent(f, x_init, vjp, maxiter=1000, tol=1e-4, maxls=15, decrease_factor=0.5):
     """code/solvers.py:127-140: jaxopt.GradientDescent(fun=|f(x) - x|^2, maxiter=1000, tol=1e-4, stepsize=0.0).
-    jaxopt is not vendored (UNPINNED, restated from its documented behaviour): proximal gradient with the
-    identity prox, FISTA acceleration (its default) and, because stepsize <= 0, a backtracking line search per
-    iteration (sufficient decrease f(x+) <= f(y) + <g, x+ - y> + |x+ - y|^2 / (2 s), at most `maxls` halvings,
-    the next search starts from s / decrease_factor); error = |x+ - y| / s.  `vjp(x, u)` = dT(x)^T u.
+    jaxopt is not vendored (UNPINNED, restated from ProximalGradient's update): identity prox, FISTA acceleration
+    (its default) and, because stepsize <= 0, a backtracking line search per iteration -- the state's step starts
+    at 1, is halved (at most `maxls` times) while  s (f(x+) - f(y)) > s <x+ - y, g> + |x+ - y|^2 / 2 + eps,  and the
+    next search starts from the accepted step / decrease_factor, or from 1 once a step has fallen to 1e-6; the loop
+    runs while error > tol, the error being the gradient mapping at the new extrapolated point with the new step
+    (identity prox: |grad loss(y)|).  `vjp(x, u)` = dT(x)^T u.
     Returns (x, iterations), the errors in ``fixed_point_via_gradient_decent.last_errors``."""
     shape = np.asarray(x_init).shape
     x = np.asarray(x_init, dtype=np.float64).copy()
+    eps = float(np.finfo(np.float64).eps)
+
+    def loss_and_grad(y):
+        r = np.asarray(f(y), dtype=np.float64) - y
+        return float(np.vdot(r, r)), 2.0 * (np.asarray(vjp(y, r), dtype=np.float64) - r)
+
+    def loss(z):
+        rz = np.asarray(f(z), dtype=np.float64) - z
+        return float(np.vdot(rz, rz))
+
     y, t, s = x.copy(), 1.0, 1.0
     errs = []
     it = 0
-    while it < maxiter:
-        r = np.asarray(f(y), dtype=np.float64) - y
-        fy = float(np.vdot(r, r))
-        g = 2.0 * (np.asarray(vjp(y, r), dtype=np.float64) - r)
-        s = s / decrease_factor
+    err = np.inf
+    fy, g = loss_and_grad(y)
+    while err > tol and it < maxiter:
+        xn = y - s * g
         for _ in range(maxls):
-            xn = y - s * g
-            rn = np.asarray(f(xn), dtype=np.float64) - xn
             d = xn - y
-            if float(np.vdot(rn, rn)) <= fy + float(np.vdot(g, d)) + float(np.vdot(d, d)) / (2.0 * s):
+            if not (s * (loss(xn) - fy) > s * float(np.vdot(d, g)) + 0.5 * float(np.vdot(d, d)) + eps):
                 break
             s *= decrease_factor
-        err = float(np.sqrt(np.vdot(d, d))) / s
-        errs.append(err)
+            xn = y - s * g
+        s = 1.0 if s <= 1e-6 else s / decrease_factor
         tn = 0.5 * (1.0 + np.sqrt(1.0 + 4.0 * t * t))
         y = xn + (t - 1.0) / tn * (xn - x)
         x, t = xn, tn
+        fy, g = loss_and_grad(y)
+        err = float(np.sqrt(np.vdot(g, g)))
+        errs.append(err)
         it += 1
-        if err <= tol:
-            break
     fixed_point_via_gradient_decent.last_errors = errs
     return x.reshape(shape), it
 

@@ -224,42 +224,61 @@ def anderson_solver(f, x_init, tol=default_tolerance, max_iter=10000, verbose=Tr
     return x.reshape(shape), it
 
 
+class GDState(dict):
+    """State returned by "gd": ``state.iter_num`` / ``state.error`` / ``state.stepsize`` / ``state.t`` as jaxopt's
+    ProxGradState names them (attribute access, as the reference's callers would use it), also a dict (``state["errors"]``
+    holds the error after every iteration)."""
+    __getattr__ = dict.__getitem__
+
+
 def _gd_loop(value_and_grad, value, axpy, dot, x, maxiter, tol, maxls, decrease_factor):
     """FISTA + backtracking line search (see fixed_point_via_gradient_decent) on abstract vectors:
-    value_and_grad(y) -> (f, g);  value(x) -> f;  axpy(a, u, v) -> a*u + v;  dot(u, v) -> float."""
+    value_and_grad(y) -> (f, g);  value(x) -> f;  axpy(a, u, v) -> a*u + v;  dot(u, v) -> float.
+    Returns (x, GDState)."""
+    eps = float(np.finfo(np.float64).eps)
     y, t, s, it, errs = x, 1.0, 1.0, 0, []
-    while it < maxiter:
-        fy, g = value_and_grad(y)
-        s = s / decrease_factor
+    err = float("inf")
+    fy, g = None, None
+    while err > tol and it < maxiter:
+        if g is None:
+            fy, g = value_and_grad(y)
+        # line search from the carried step: halve while  s (f(x+) - f(y)) > s <x+ - y, g> + |x+ - y|^2 / 2 + eps
+        xn = axpy(-s, g, y)
         for _ in range(maxls):
-            xn = axpy(-s, g, y)
             d = axpy(-1.0, y, xn)
-            if value(xn) <= fy + dot(g, d) + dot(d, d) / (2.0 * s):
+            if not (s * (value(xn) - fy) > s * dot(d, g) + 0.5 * dot(d, d) + eps):
                 break
             s *= decrease_factor
-        err = dot(d, d) ** 0.5 / s
-        errs.append(err)
+            xn = axpy(-s, g, y)
+        # a step that has become tiny restarts at 1, otherwise the next search tries a larger one
+        s = 1.0 if s <= 1e-6 else s / decrease_factor
         tn = 0.5 * (1.0 + (1.0 + 4.0 * t * t) ** 0.5)
         y = axpy((t - 1.0) / tn, axpy(-1.0, x, xn), xn)
         x, t = xn, tn
+        # the error is the gradient mapping at the NEW y with the NEW step; with the identity prox that is |grad(y)|
+        fy, g = value_and_grad(y)
+        err = dot(g, g) ** 0.5
+        errs.append(err)
         it += 1
-        if err <= tol:
-            break
-    return x, it, errs
+    return x, GDState(iter_num=it, error=err, stepsize=s, t=t, errors=np.array(errs))
 
 
 def fixed_point_via_gradient_decent(f, x_init, maxiter=1000, tol=1e-4, maxls=15, decrease_factor=0.5):
     """Registry entry "gd" (code/solvers.py:127-140): ``jaxopt.GradientDescent(fun=loss, maxiter=1000,
     tol=0.0001, stepsize=0.0).run(x_init)`` with ``loss(x) = |f(x) - x|^2``; returns ``(solution, state)``.
 
-    jaxopt is not vendored by the reference (unpinned): restated from its documented behaviour -- proximal
-    gradient with the identity prox, FISTA acceleration (jaxopt's default) and, since ``stepsize <= 0``, a
-    backtracking line search per iteration (sufficient decrease, at most 15 halvings, the next search starting
-    from twice the accepted step); the error is the gradient-mapping norm ``|x+ - y| / s``.  The gradient
+    jaxopt is not vendored by the reference (unpinned): restated from ProximalGradient's update -- identity prox,
+    FISTA acceleration (jaxopt's default) and, since ``stepsize <= 0``, a backtracking line search per iteration:
+    the state's step starts at 1, is halved (at most ``maxls`` times) while the sufficient-decrease test
+    ``s (f(x+) - f(y)) > s <x+ - y, g> + |x+ - y|^2 / 2 + eps`` fails, and the next search starts from twice the
+    accepted step -- or from 1 again once a step has fallen to 1e-6.  The error that stops the loop is the gradient
+    mapping at the NEW extrapolated point with the new step, which for the identity prox is ``|grad loss(y)|``
+    (one gradient per iteration: it is the next iteration's).  **Parity is with `oracle/solvers.py`'s restatement of
+    the same rules, not with jaxopt itself.**  The gradient
     ``2 (dT(x)^T r - r)`` needs the vector-Jacobian product: for (a closure over) a device operator the loop
     runs on the GPU (T, its linearisation and ``sdfs_apply_vjp_dev`` on device-resident vectors); a foreign
-    callable must bring ``f.vjp(x, u)`` (the reference gets it from jax.grad).  ``state`` is a dict with
-    ``iter_num``, ``error`` and the error trace."""
+    callable must bring ``f.vjp(x, u)`` (the reference gets it from jax.grad).  ``state``: `GDState`
+    (``state.iter_num``, ``state.error``, ``state.stepsize``, ``state.t``; ``state["errors"]`` the trace)."""
     op = _resolve_operator(f, x_init)
     if op is not None:
         import torch
@@ -286,14 +305,14 @@ def fixed_point_via_gradient_decent(f, x_init, maxiter=1000, tol=1e-4, maxls=15,
             return float(torch.dot(r.view(-1), r.view(-1))), g.mul_(2.0)
 
         try:
-            x, it, errs = _gd_loop(value_and_grad, value, lambda a, u, v: torch.add(v, u, alpha=a),
-                                   lambda u, v: float(torch.dot(u.view(-1), v.view(-1))), x0,
-                                   maxiter, tol, maxls, decrease_factor)
+            x, state = _gd_loop(value_and_grad, value, lambda a, u, v: torch.add(v, u, alpha=a),
+                                lambda u, v: float(torch.dot(u.view(-1), v.view(-1))), x0,
+                                maxiter, tol, maxls, decrease_factor)
             x = x.cpu().numpy().reshape(shape)
         finally:
             op.set_stream(None, use_own=True)
         if _confirm(f, op, x):
-            return x, dict(iter_num=it, error=errs[-1] if errs else float("nan"), errors=np.array(errs))
+            return x, state
         print("Warning: the callable is not a pure closure over one device operator; repeating on the host")
     vjp = getattr(f, "vjp", None)
     if vjp is None:
@@ -309,9 +328,8 @@ def fixed_point_via_gradient_decent(f, x_init, maxiter=1000, tol=1e-4, maxls=15,
         r = np.asarray(f(x), dtype=np.float64) - x
         return float(np.vdot(r, r))
 
-    x, it, errs = _gd_loop(value_and_grad, value, lambda a, u, v: a * u + v, lambda u, v: float(np.vdot(u, v)),
-                           x0, maxiter, tol, maxls, decrease_factor)
-    return x, dict(iter_num=it, error=errs[-1] if errs else float("nan"), errors=np.array(errs))
+    return _gd_loop(value_and_grad, value, lambda a, u, v: a * u + v, lambda u, v: float(np.vdot(u, v)),
+                    x0, maxiter, tol, maxls, decrease_factor)
 
 
 # == List solvers for simple access == #

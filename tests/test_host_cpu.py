@@ -216,7 +216,9 @@ def test_solver_front_end_fallback_and_registry(capsys):
 
 def test_gd_host_path_matches_oracle_restatement():
     """Registry entry "gd" (code/solvers.py:127-140) on a foreign callable that brings its own vjp: the host loop
-    equals the oracle's restatement of jaxopt.GradientDescent (FISTA + backtracking; unpinned third party)."""
+    equals the oracle's restatement of jaxopt.GradientDescent (FISTA + backtracking; unpinned third party -- parity
+    here is with that restatement of ProximalGradient's rules, NOT with jaxopt itself).  The state answers to the
+    attribute names of jaxopt's ProxGradState."""
     import sdfs_via_autodiff_amd as S
     from oracle import solvers as osol
     A = np.array([[0.5, 0.2, 0.0], [0.1, 0.4, 0.1], [0.0, 0.3, 0.5]])
@@ -231,7 +233,11 @@ def test_gd_host_path_matches_oracle_restatement():
     f = F()
     x, state = S.fixed_point_via_gradient_decent(f, np.zeros(3))
     xo, no = osol.fixed_point_via_gradient_decent(f, np.zeros(3), f.vjp)
-    assert state["iter_num"] == no and no < 1000
+    assert state["iter_num"] == state.iter_num == no and no < 1000
+    assert state.error <= 1e-4 and state.error == state["errors"][-1] and state.stepsize > 0 and state.t > 1
+    np.testing.assert_allclose(state["errors"], osol.fixed_point_via_gradient_decent.last_errors, rtol=1e-12)
+    # the stopping error is the gradient of the loss at the extrapolated point: the loop ends at the first one <= tol
+    assert np.all(state["errors"][:-1] > 1e-4)
     np.testing.assert_allclose(x, xo, rtol=0, atol=1e-12)
     np.testing.assert_allclose(x, np.linalg.solve(np.eye(3) - A, b), atol=1e-3)
     np.testing.assert_allclose(S.solver(f, np.zeros(3), algorithm="gd"), xo, atol=1e-12)

@@ -16,6 +16,10 @@ VARIANTS = {
     "small run 1": {"SDFS_SMALL_R": "1"},
     "small run 4": {"SDFS_SMALL_R": "4"},
     "generic tiles": {"SDFS_SMALL_PLAN": "0"},
+    # beyond 400 k points the planner leaves the small-grid kernels; SDFS_PLAN=pair keeps them wherever they are legal
+    "small forced": {"SDFS_PLAN": "pair"},
+    "small forced run 4": {"SDFS_PLAN": "pair", "SDFS_SMALL_R": "4"},
+    "small forced, launch order plain": {"SDFS_PLAN": "pair", "SDFS_SMALL_XCD": "0"},
 }
 DEFAULT = ["5,5,5,5", "10,10,10,10", "15,15,15,15", "16,16,16,16", "6,6,6,6,6,6", "8,8,8,8,8,8", "10,10,10,10,10,10",
            "12,12,12,12,12,12", "14,14,14,14,14,14"]
@@ -46,6 +50,8 @@ def main():
                 T.solve(w0, "successive_approx", tol=0.0, max_iter=n_it, check_every=128)
                 best = min(best, time.perf_counter() - t0)
             row.append(f"{name}: {best / n_it * 1e6:8.2f} us")
+            if os.environ.get("AB_SMALL_PLANS"):
+                print("   ", name, "|", T.describe_plan().splitlines()[0][:150], flush=True)
             del T
         print(f"{'x'.join(map(str, shapes)):>20s}  " + "   ".join(row), flush=True)
 
