@@ -1455,7 +1455,7 @@ inline small_fn small_variant(int mode, int r, int wpt) {
 inline small_and_fn small_and_variant(int mode, int r, int wpt) {
   if (mode == SM_AND_FIRST) {
     if (wpt == 4) return r == 1 ? (small_and_fn)small_and_kernel<SM_AND_FIRST, 1, 4> : (r == 4 ? (small_and_fn)small_and_kernel<SM_AND_FIRST, 4, 4> : nullptr);
-    return r == 1 ? (small_and_fn)small_and_kernel<SM_AND_FIRST, 1, 1> : (r == 4 ? (small_and_fn)small_and_kernel<SM_AND_FIRST, 4, 1> : nullptr);
+    return r == 1 ? (small_and_fn)small_and_kernel<SM_AND_FIRST, 1, 1> : nullptr;     // (runs of 4 on wave tiles: 16 elements per lane, the history of a mixing step would spill)
   }
   if (mode != SM_AND_LAST) return nullptr;
   if (wpt == 4) return r == 1 ? (small_and_fn)small_and_kernel<SM_AND_LAST, 1, 4> : (r == 4 ? (small_and_fn)small_and_kernel<SM_AND_LAST, 4, 4> : nullptr);

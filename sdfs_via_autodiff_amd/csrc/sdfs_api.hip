@@ -1799,7 +1799,9 @@ bool anderson_fused_ok(const sdfs_handle* h, int m) {
   // (pair order reversed: the application ends on the fastest pair, whose tiles are contiguous -- the push's history
   // streams then cost 4 lines per wave request instead of 64)
   const FastPass& L = h->fast.passes.front();
-  return (int)small_grid(L.sm, L.wpt) <= AND_FUSE_RING && L.sm.a3 != nullptr && h->fast.passes.back().sm.a3 != nullptr;
+  const FastPass& F = h->fast.passes.back();
+  return (int)small_grid(L.sm, L.wpt) <= AND_FUSE_RING && L.sm.a3 != nullptr && F.sm.a3 != nullptr &&
+         small_and_variant(SM_AND_FIRST, F.r, F.wpt) != nullptr && small_and_variant(SM_AND_LAST, L.r, L.wpt) != nullptr;
 }
 
 // The same loop with its control on the device (vec_kernels.hpp, AndState / k_and_step / k_and_mix_dev): per pass
