@@ -23,6 +23,7 @@
 #include "pass_kernel.hpp"
 #include "fast_kernels.hpp"
 #include "stream_kernels.hpp"
+#include "pad_kernels.hpp"
 #include "cont_kernel.hpp"
 #include "dense_kernel.hpp"
 #include "vec_kernels.hpp"
@@ -86,12 +87,15 @@ struct FastPass {
   int r = 1;                   // its run length
   int wpt = 1;                 // ... and waves per tile
   SmallDesc sm;
+  bool pad = false;            // padded form: run-time extents <= 16 on 16 x 16 tiles, real strides (pad_kernels.hpp)
+  PadDesc pd;
   double q_bytes = 0, flops = 0;
   std::string label;
 };
 struct FastPlan {
   bool ok = false;
   bool small = false;          // built from small_tile_kernel passes
+  bool pad = false;            // built from pad_kernels.hpp passes
   bool f32_ok = false;         // every line pass walks whole 16-element chunks: fp32 J.v forms exist
   std::vector<FastPass> passes;
 };
@@ -109,6 +113,7 @@ struct Knobs {
   int small_plan = 1;          // SDFS_SMALL_PLAN: 0 = never use the small-grid pair plan
   int small_r = 0;             // SDFS_SMALL_R: force the run length of its line passes (1 or 4)
   int small_wpt = 0;           // SDFS_SMALL_WPT: force its waves per tile (1 or 4)
+  int pad_plan = 1;            // SDFS_PAD_PLAN: 0 = 6-D grids with extents <= 16 beyond the small-grid plan's size keep the generic tiles
   int small_xcd = 1;           // SDFS_SMALL_XCD: 0 = its strided passes launch tile b on workgroup b (no XCD-aware order)
   int no_bicg_merge = 0;       // SDFS_NO_BICG_MERGE: 1 = BiCGSTAB keeps its finishing kernels as launches of their own on small grids too
   int and_host = 0;            // SDFS_AND_HOST: 1 = Anderson with the Gram solve on the host (one synchronisation per iteration)
@@ -275,6 +280,7 @@ Knobs read_knobs() {
   k.sa_fused = env_int("SDFS_SA_FUSED", -1);
   k.small_wpt = env_int("SDFS_SMALL_WPT", 0);
   k.small_xcd = env_int("SDFS_SMALL_XCD", 1);
+  k.pad_plan = env_int("SDFS_PAD_PLAN", 1);
   k.and_host = env_int("SDFS_AND_HOST", 0);
   k.and_fused = env_int("SDFS_AND_FUSED", 1);
   const char* pl = getenv("SDFS_PLAN");
@@ -738,6 +744,7 @@ int upload_ints(sdfs_handle* h, const std::vector<int>& v, int** out) {
 int build_fast_plan(sdfs_handle* h) {
   h->fast.ok = false;
   h->fast.small = false;
+  h->fast.pad = false;
   h->fast.passes.clear();
   const int D = h->ndim;
   if (h->knobs.plan == 1 || h->sharded || h->cont || h->dense || (D != 4 && D != 6) || h->a3 == nullptr) return 0;
@@ -982,6 +989,79 @@ int build_small_plan(sdfs_handle* h) {
   return 0;
 }
 
+// 6-D grids between the plans (pad_kernels.hpp): every extent <= 16, unconditional tensors, more points than the
+// latency-tuned small-grid kernels are good for (10^6 ... 15^6, ragged shapes): the pair plan on padded 16 x 16 tiles.
+int build_pad_plan(sdfs_handle* h) {
+  const int D = h->ndim;
+  if (h->fast.ok || h->knobs.plan == 1 || h->knobs.pad_plan == 0 || h->sharded || h->cont || h->dense || D != 6 || h->a3 == nullptr) return 0;
+  if (h->N >= (1LL << 31)) return 0;
+  for (int a = 0; a < D; ++a) {
+    if (h->ax[a].qcount != 1 || h->shape[a] > 16 || !h->ax[a].Qp || !h->ax[a].Qtp) return 0;
+    for (int c = 0; c < D; ++c) if (h->ax[a].qs[c] != 0) return 0;
+    if (h->ax[a].a3s < 0 || h->ax[a].a3s >= (1 << 24)) return 0;
+  }
+  long long stride[MAXD];
+  { long long st = 1; for (int a = D - 1; a >= 0; --a) { stride[a] = st; st *= h->shape[a]; } }
+  std::vector<int> pairs = {D - 2};
+  {
+    std::vector<int> rest;
+    for (int a = D - 4; a >= 0; a -= 2) rest.push_back(a);
+    if (h->knobs.pair_order == 1) std::reverse(rest.begin(), rest.end());
+    pairs.insert(pairs.end(), rest.begin(), rest.end());
+  }
+  std::vector<FastPass> passes;
+  for (size_t i = 0; i < pairs.size(); ++i) {
+    const int a = pairs[i];
+    FastPass P;
+    P.pad = true; P.line = i > 0; P.n = 16; P.ax0 = a; P.ax1 = a + 1;
+    memset(&P.sd, 0, sizeof P.sd); memset(&P.ld, 0, sizeof P.ld); memset(&P.sm, 0, sizeof P.sm); memset(&P.pd, 0, sizeof P.pd);
+    PadDesc& S = P.pd;
+    S.nx = h->shape[a]; S.ny = h->shape[a + 1];
+    S.mxy = (unsigned)(((1u << 20) + S.nx * S.ny - 1) / (S.nx * S.ny));
+    S.my = (unsigned)(((1u << 20) + S.ny - 1) / S.ny);
+    const long long lrest = stride[a + 1];
+    const long long nouter = h->N / ((long long)S.nx * S.ny * lrest);
+    S.lrest = lrest; S.nouter = nouter;
+    S.nchunks = (int)((lrest + LINE_R - 1) / LINE_R);
+    S.ntiles = nouter * S.nchunks;
+    S.nslices = nouter;                      // (slice form: lrest = 1)
+    if (S.ntiles >= (1LL << 31)) return 0;
+    S.Qx = h->ax[a].Qp; S.Qy = h->ax[a + 1].Qp;
+    S.theta = h->theta; S.inv_theta = 1.0 / h->theta; S.beta = h->beta;
+    S.a3x = h->ax[a].a3s; S.a3y = h->ax[a + 1].a3s;
+    P.q_bytes = 2 * 8.0 * 256; P.flops = 2.0 * (double)h->N * (S.nx + S.ny);
+    P.label = std::string(i == 0 ? "slices[" : "lines[") + h->ax[a].name + "," + h->ax[a + 1].name + "|" +
+              std::to_string(S.nx) + "x" + std::to_string(S.ny) + " on 16x16]";
+    if (i + 1 == pairs.size()) {
+      // a3 index tables of the last pass (as build_small_plan)
+      std::vector<int> outv((size_t)nouter, 0), restv((size_t)lrest, 0);
+      for (long long o = 0; o < nouter; ++o) {
+        long long q = o; int idx = 0;
+        for (int c = a - 1; c >= 0; --c) { idx += (int)(q % h->shape[c]) * h->ax[c].a3s; q /= h->shape[c]; }
+        outv[(size_t)o] = idx;
+      }
+      for (long long q0 = 0; q0 < lrest; ++q0) {
+        long long q = q0; int idx = 0;
+        for (int c = D - 1; c > a + 1; --c) { idx += (int)(q % h->shape[c]) * h->ax[c].a3s; q /= h->shape[c]; }
+        restv[(size_t)q0] = idx;
+      }
+      int *od = nullptr, *rd = nullptr;
+      int rc;
+      if ((rc = upload_ints(h, outv, &od)) || (rc = upload_ints(h, restv, &rd))) return rc;
+      S.a3 = h->a3; S.out_idx = od; S.rest_idx = rd;
+    }
+    passes.push_back(P);
+  }
+  // enough tiles to fill the chip, else the generic kernel's finer tiles do better
+  if (passes[0].pd.nslices < 8LL * h->num_cus) return 0;
+  h->fast.passes = passes;
+  h->fast.f32_ok = false;
+  h->fast.small = false;
+  h->fast.pad = true;
+  h->fast.ok = true;
+  return 0;
+}
+
 // persistent middle pass of stream_kernels.hpp: a multiple of 8 workgroups (one ticket range per XCD)
 unsigned stream_mid_grid(const sdfs_handle* h, const FastPass& P) {
   long long g = std::min<long long>(P.ld.ntiles, (long long)line_stream_wpc_mid(P.n) * h->num_cus);
@@ -1025,7 +1105,38 @@ int run_fast_plan(sdfs_handle* h, int mode, const double* in, double* out, const
     double bytes = 2 * n8 + P.q_bytes;
     const double* pin = (i == 0) ? in : h->tmp;
     double* pout = last ? out : h->tmp;
-    if (P.small) {
+    if (P.pad) {
+      PadDesc d = P.pd;
+      d.minus_identity = minus_identity;
+      if (vjp) { d.Qx = h->ax[P.ax0].Qtp; d.Qy = h->ax[P.ax1].Qtp; }
+      int cid = -1;
+      if (!P.line) {
+        SliceIO io;
+        memset(&io, 0, sizeof io);
+        io.in = pin; io.out = pout; io.gate = gate; io.gate_tol = gate_tol;
+        io.zero = (mode != MODE_JVP) ? resid : nullptr;
+        int sm = S_TFIRST;
+        if (mode == MODE_T_LIN) { sm = S_TFIRST_LIN; io.aux_out = h->c1; bytes += n8; }
+        else if (mode == MODE_JVP) { sm = S_JFIRST; io.aux_in = vjp ? h->c2 : h->c1; bytes += n8; }
+        if (h->profiling) { char nm[48]; snprintf(nm, sizeof nm, "%s:%s", tag, P.label.c_str()); cid = counter_id(h, nm, bytes, P.flops); }
+        const long long ntile = (d.nslices + PAD_G - 1) / PAD_G;
+        ProfScope ps(h, cid);
+        hipLaunchKernelGGL(pad_slice_variant(sm), dim3((unsigned)((ntile + 3) / 4)), dim3(256), 0, h->stream, d, io);
+      } else {
+        LineIO io;
+        memset(&io, 0, sizeof io);
+        io.in = pin; io.out = pout; io.gate = gate; io.gate_tol = gate_tol;
+        int lm = L_MID;
+        if (last) {
+          if (mode == MODE_T) { lm = L_TLAST; io.old = old; io.resid = resid; if (resid) bytes += n8; }
+          else if (mode == MODE_T_LIN) { lm = L_TLAST_LIN; io.old = old; io.resid = resid; io.aux_out = h->c2; bytes += n8; if (resid) bytes += n8; }
+          else { lm = L_JLAST; io.aux_in = vjp ? h->c1 : h->c2; io.old = old; bytes += n8; if (minus_identity) { bytes += n8; io.dotp = dotp; } }
+        }
+        if (h->profiling) { char nm[48]; snprintf(nm, sizeof nm, "%s:%s", tag, P.label.c_str()); cid = counter_id(h, nm, bytes, P.flops); }
+        ProfScope ps(h, cid);
+        hipLaunchKernelGGL(pad_line_variant(lm), dim3((unsigned)d.ntiles), dim3(256), 0, h->stream, d, io);
+      }
+    } else if (P.small) {
       SmallIO io;
       memset(&io, 0, sizeof io);
       io.in = pin; io.out = pout; io.gate = gate; io.gate_tol = gate_tol;
@@ -1123,6 +1234,7 @@ long long jvp_last_tiles(sdfs_handle* h) {
   if (h->cont || h->dense) return 0;
   if (h->fast.ok && h->fast.small) return h->krylov_f32 ? h->plan[0].passes.back().d.ntiles : (long long)small_grid(h->fast.passes.back().sm, h->fast.passes.back().wpt);
   if (h->fast.ok && h->krylov_f32 && h->fast.f32_ok) return h->fast.passes.back().ld.ntiles;
+  if (h->fast.ok && h->fast.pad) return h->krylov_f32 ? (h->plan[0].passes.empty() ? 0 : h->plan[0].passes.back().d.ntiles) : h->fast.passes.back().pd.ntiles;
   if (h->fast.ok && !h->krylov_f32) return line_grid(h, h->fast.passes.back());
   return h->plan[0].passes.empty() ? 0 : h->plan[0].passes.back().d.ntiles;
 }
@@ -1377,9 +1489,9 @@ int solve_sa(sdfs_handle* h, const sdfs_opts& o, double* w, int64_t* n_iter, int
   const bool fused = h->fast.ok && h->fast.small && !h->cont && !h->dense && h->knobs.sa_fused != 0;
   if (fused && (rc = small_sa_prologue(h, h->buf0))) return rc;
   // 6-D pair plan: plain slice pass + fused line pass per iteration
-  bool streamed = h->fast.ok && !h->fast.small && h->fast.passes.size() == 3 && (h->knobs.line_stream & 3) == 3;
+  bool streamed = h->fast.ok && !h->fast.small && !h->fast.pad && h->fast.passes.size() == 3 && (h->knobs.line_stream & 3) == 3;
   for (const FastPass& P : h->fast.passes) if (P.line && !P.stream) streamed = false;
-  const bool fusedbig = h->fast.ok && !h->fast.small && h->fast.passes.size() == 3 && !h->cont && !h->dense && h->knobs.sa_fused != 0 &&
+  const bool fusedbig = h->fast.ok && !h->fast.small && !h->fast.pad && h->fast.passes.size() == 3 && !h->cont && !h->dense && h->knobs.sa_fused != 0 &&
                         !(h->knobs.sa_fused < 0 && streamed) && !h->t32_active;
   if (fusedbig && (rc = big_sa_line(h, 2, true, h->buf0, nullptr, nullptr, nullptr, nullptr, 0.0))) return rc;
   // ... and the residual without atomics: per-workgroup maxima, reduced by the next iteration's kernels
@@ -2196,6 +2308,8 @@ int create_common(int model, int ndim, const int64_t* shapes, const double* para
     if (rc) return bail(rc);
     rc = build_small_plan(h);
     if (rc) return bail(rc);
+    rc = build_pad_plan(h);
+    if (rc) return bail(rc);
   } else {
     if (axis_a >= ndim || axis_b < 0 || axis_b >= ndim || axis_a == axis_b)
       return bail(fail(h, SDFS_ERR_ARG, "bad shard axes %d / %d", axis_a, axis_b));
@@ -2844,7 +2958,11 @@ int sdfs_describe_plan(const sdfs_handle* h, char* buf, int64_t cap) {
     for (size_t i = 0; i < h->fast.passes.size(); ++i) {
       const FastPass& P = h->fast.passes[i];
       int occ = -1;
-      if (P.small) {
+      if (P.pad) {
+        snprintf(line, sizeof line, "padded pair plan pass %zu: %s %s\n", i, P.label.c_str(),
+                 P.line ? (std::string("tiles ") + std::to_string(P.pd.ntiles) + " (rows of 16 positions, real strides)").c_str()
+                        : (std::string("wave tiles ") + std::to_string((P.pd.nslices + PAD_G - 1) / PAD_G) + " of 4 slices").c_str());
+      } else if (P.small) {
         snprintf(line, sizeof line, "small-grid plan pass %zu: %s %d wave%s per tile, run %d, tiles %lld, workgroups %u\n", i,
                  P.label.c_str(), P.wpt, P.wpt == 1 ? "" : "s", P.r, P.sm.ntiles, small_grid(P.sm, P.wpt));
       } else if (!P.line) {

@@ -15,11 +15,11 @@ VARIANTS = {
     "small (auto run)": {},
     "small run 1": {"SDFS_SMALL_R": "1"},
     "small run 4": {"SDFS_SMALL_R": "4"},
-    "generic tiles": {"SDFS_SMALL_PLAN": "0"},
+    "generic tiles": {"SDFS_SMALL_PLAN": "0", "SDFS_PAD_PLAN": "0"},
     # beyond 400 k points the planner leaves the small-grid kernels; SDFS_PLAN=pair keeps them wherever they are legal
-    "small forced": {"SDFS_PLAN": "pair"},
-    "small forced run 4": {"SDFS_PLAN": "pair", "SDFS_SMALL_R": "4"},
-    "small forced, launch order plain": {"SDFS_PLAN": "pair", "SDFS_SMALL_XCD": "0"},
+    "small forced": {"SDFS_PLAN": "pair", "SDFS_PAD_PLAN": "0"},
+    # 6-D grids beyond the small-grid plan's size: the padded pair plan (pad_kernels.hpp), the default there
+    "padded pair plan": {"SDFS_PAD_PLAN": "1"},
 }
 DEFAULT = ["5,5,5,5", "10,10,10,10", "15,15,15,15", "16,16,16,16", "6,6,6,6,6,6", "8,8,8,8,8,8", "10,10,10,10,10,10",
            "12,12,12,12,12,12", "14,14,14,14,14,14"]
