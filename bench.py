@@ -395,6 +395,25 @@ def main():
                                     "final_err": info["final_err"]}
             if algo == "newton" and not args.no_cpu:
                 sec["ssy15_newton"]["cpu_twin"] = cpu_time_to_converge("ssy", shp, m.params, S.discretize_ssy(m, shp), n, info["n_apply"], full=True)
+        T.close()
+        # a grid between the plans (every extent <= 16, more points than the small-grid plan takes): GCY 15^6 on the padded
+        # pair plan (csrc/pad_kernels.hpp) -- resident-HBM step of T with its residual, as the headline's
+        g15 = S.GCY(); shp15 = (15,) * 6
+        T15 = S.gcy_operator(shp15, g15.params, S.discretize_gcy(g15, shp15))
+        dev = torch.device("cuda", 0)
+        a15 = torch.full(shp15, 800.0, dtype=torch.float64, device=dev); b15 = torch.empty_like(a15)
+        r15 = torch.zeros(1, dtype=torch.float64, device=dev)
+        for _ in range(20):
+            T15.apply_dev(a15.data_ptr(), b15.data_ptr(), r15.data_ptr()); a15, b15 = b15, a15
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(100):
+            T15.apply_dev(a15.data_ptr(), b15.data_ptr(), r15.data_ptr()); a15, b15 = b15, a15
+        torch.cuda.synchronize()
+        t15 = (time.perf_counter() - t0) / 100
+        sec["gcy15_padded_pair_plan"] = {"ms_per_step": t15 * 1e3, "iterations_per_s": 1.0 / t15, "points": 15 ** 6,
+                                         "alg_GBps": 56.0 * 15 ** 6 / t15 / 1e9, "plan": T15.describe_plan().strip().split("\n")[:3]}
+        T15.close(); del a15, b15
         if not args.no_cpu:
             sec["cpu_literal_formulation"] = cpu_literal_apply()
         # continuous-state SSY at the reference's default size (10, 10, 10, 20; Gauss-Hermite d = 5)
