@@ -357,6 +357,18 @@ def main():
             t = time.perf_counter() - t0
             sec["gcy20_sa_device_loop"] = {"iterations": n_sa, "seconds": t, "ms_per_iteration": t / n_sa * 1e3,
                                            "iterations_per_s": n_sa / t, "final_err": info["final_err"]}
+            # Anderson on the device-resident grid (batched-Gram loop, vec_kernels.hpp): to 1e-6, the tolerance the
+            # accelerated iteration reaches at this grid before its history turns collinear
+            ws.fill_(800.0)
+            op.solve_dev(ws.data_ptr(), "anderson", tol=0.0, max_iter=40)
+            ws.fill_(800.0)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            n_a, info = op.solve_dev(ws.data_ptr(), "anderson", tol=1e-6, max_iter=5000)
+            torch.cuda.synchronize()
+            t = time.perf_counter() - t0
+            sec["gcy20_anderson_1e-6_device"] = {"iterations": n_a, "seconds": t, "ms_per_iteration": t / max(n_a, 1) * 1e3,
+                                                 "final_err": info["final_err"]}
             del ws
             # the conditional-tensor kernels at full size: Rouwenhorst tensors are slice-identical, so the headline
             # runs the merged (unconditional) plan; SDFS_NO_SLICE_MERGE keeps z_Q (25.6 MB) / z_pi_Q conditional

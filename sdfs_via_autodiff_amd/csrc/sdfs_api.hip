@@ -150,6 +150,7 @@ struct sdfs_handle {
   unsigned* sched = nullptr;          // tile tickets of the persistent line passes (SCHED_WORDS per pass, zero between launches)
   AndState* and_state = nullptr;      // device-resident Anderson loop: state (two buffers: the fused small-grid form alternates), per-chunk record of its passes
   AndState* and_state_host = nullptr;
+  double* and_gram_partial = nullptr; // large grids: partial sums of the whole Gram matrix (k_and_gram_full)
   unsigned* and_flag = nullptr;       // fused form: per pass of a chunk, set by a push that met a non-finite residual
   double* and_err = nullptr; int* and_kind = nullptr; int and_slots = 0;
   double* and_err_host = nullptr; int* and_kind_host = nullptr;
@@ -1939,6 +1940,17 @@ int solve_anderson(sdfs_handle* h, const sdfs_opts& o, double* w, int64_t* n_ite
   // alternates between two buffers (even chunks end where they began) and the passes whose step can mix are fixed at
   // capture time (chunks are multiples of the mixing frequency).
   bool fusedp = !h->profiling && anderson_fused_ok(h, m);
+  // large grids (the loop is HBM-bound there): the Gram matrix in one sweep where a solve is due (vec_kernels.hpp)
+  const bool lazyp = h->knobs.and_fused && !fusedp && !h->sharded && m <= AND_LAZY_M && h->N >= (1LL << 21);
+  if (lazyp) {
+    auto lcm = [](long long a, long long b) { long long x = a, y = b; while (y) { const long long t = x % y; x = y; y = t; } return a / x * b; };
+    const long long unit = lcm(m, o.mixing_freq);
+    chunk = (int)(((chunk + unit - 1) / unit) * unit);
+    if (!h->and_gram_partial) {
+      HIPCHK(h, hipMalloc((void**)&h->and_gram_partial, sizeof(double) * (size_t)AND_LAZY_PAIRS * AND_LAZY_BLOCKS));
+      h->misc_allocs.push_back(h->and_gram_partial);
+    }
+  }
   if (fusedp) {
     auto lcm = [](long long a, long long b) { long long x = a, y = b; while (y) { const long long t = x % y; x = y; y = t; } return a / x * b; };
     const long long unit = lcm(lcm(m, 2), o.mixing_freq);
@@ -2071,7 +2083,31 @@ int solve_anderson(sdfs_handle* h, const sdfs_opts& o, double* w, int64_t* n_ite
     HIPCHK(h, hipMemcpyAsync(h->and_state_host, S + (count & 1), sizeof(AndState), hipMemcpyDeviceToHost, st));
     return 0;
   };
-  auto enqueue_any = [&](int count) -> int { return fusedp ? enqueue_fused(count) : enqueue(count); };
+  // Large grids: <r, r> per pass, the whole Gram matrix in one sweep where a solve is due, history as Y_j (vec_kernels.hpp)
+  auto enqueue_lazy = [&](int count) -> int {
+    HIPCHK(h, hipMemsetAsync(h->and_kind, 0, sizeof(int) * (size_t)chunk, st));
+    const int gb = (int)std::min<long long>(AND_LAZY_BLOCKS, std::max<long long>(1, (n + 2 * VEC_BLOCK - 1) / (2 * VEC_BLOCK)));
+    for (int i = 0; i < count; ++i) {
+      const int pos = i % m;
+      int r2 = apply_T_dev(h, x, fx, nullptr, &S->gate, 0.0);
+      if (r2) return r2;
+      ProfScope ps(h, cvec);
+      hipLaunchKernelGGL(k_and_push_lite, dim3(g), dim3(VEC_BLOCK), 0, st, (const double*)x, (const double*)fx, hp.X[pos], hp.R[pos], o.beta, n, h->partial,
+                         (const unsigned long long*)&S->gate);
+      const int refresh = ((i + 1) % (int)o.mixing_freq) == 0 ? 1 : 0;
+      if (refresh)
+        hipLaunchKernelGGL(k_and_gram_full, dim3(gb), dim3(VEC_BLOCK), 0, st, hp, m, (int)o.mixing_freq, n, h->and_gram_partial, (const AndState*)S);
+      hipLaunchKernelGGL(k_and_step_lazy, dim3(1), dim3(VEC_BLOCK), 0, st, (const double*)h->partial, g, (const double*)h->and_gram_partial, gb, refresh,
+                         m, pos, i, S, h->and_err + i, h->and_kind + i, o.tol, (double)o.max_iter, (int)o.mixing_freq, o.ridge);
+      hipLaunchKernelGGL(k_and_mix_y, dim3(g), dim3(VEC_BLOCK), 0, st, hp, (const AndState*)S, m, o.beta, x, (const double*)fx, pos, i, n);
+    }
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipMemcpyAsync(h->and_err_host, h->and_err, sizeof(double) * (size_t)count, hipMemcpyDeviceToHost, st));
+    HIPCHK(h, hipMemcpyAsync(h->and_kind_host, h->and_kind, sizeof(int) * (size_t)count, hipMemcpyDeviceToHost, st));
+    HIPCHK(h, hipMemcpyAsync(h->and_state_host, S, sizeof(AndState), hipMemcpyDeviceToHost, st));
+    return 0;
+  };
+  auto enqueue_any = [&](int count) -> int { return fusedp ? enqueue_fused(count) : (lazyp ? enqueue_lazy(count) : enqueue(count)); };
   const bool graph = o.use_graph && !h->profiling && st != nullptr && chunk > 1;
   const double key[4] = {o.tol, (double)o.max_iter, o.beta, o.ridge};
   if (graph && (h->and_graph == nullptr || h->and_graph_chunk != chunk || h->and_graph_m != m || h->and_graph_freq != (int)o.mixing_freq ||

@@ -556,6 +556,157 @@ k_and_mix_dev(AndPtrs h, const AndState* __restrict__ S, int m, double beta, dou
 #undef BODY
 }
 
+// ---- Anderson on large grids: the Gram matrix when a solve is due, not a row per pass ---------------------------------
+// A pass of the loop above reads the whole residual history (m - 1 streams) for one row of the Gram matrix, yet the
+// matrix is only used by the solve of every `mixing_freq`-th pass; the stopping test and the safeguard need the diagonal
+// entry <r, r> alone.  At GCY 20^6 that row was 1.3 of the 3.1 ms of a pass.  Here: the push writes its slot
+// (Y = x + beta r, see AndArgs, and r) and <r, r>; a pass whose step can mix recomputes the WHOLE matrix from the m
+// residual streams in one sweep (m streams per mixing_freq passes instead of m - 1 per pass); the update reads the m
+// streams Y_j.  Per four passes at m = 10: 71 grid streams instead of 107.
+constexpr int AND_LAZY_M = 12;                                   // register budget of the sweep: m (m + 1) / 2 sums
+constexpr int AND_LAZY_PAIRS = AND_LAZY_M * (AND_LAZY_M + 1) / 2;
+constexpr int AND_LAZY_BLOCKS = 512;
+
+__global__ void __launch_bounds__(VEC_BLOCK)
+k_and_push_lite(const double* __restrict__ x, const double* __restrict__ fx, double* __restrict__ ypos, double* __restrict__ rpos,
+                double beta, long long n, double* __restrict__ partial, const unsigned long long* gate) {
+  SDFS_GATED(gate);
+  double acc[1] = {0.0};
+#define BODY(W_) { double x_[W_], f_[W_], r_[W_], y_[W_]; LDx<W_>(x, e, x_); LDx<W_>(fx, e, f_); \
+                   _Pragma("unroll") for (int q = 0; q < W_; ++q) { r_[q] = f_[q] - x_[q]; y_[q] = fma(beta, r_[q], x_[q]); acc[0] = fma(r_[q], r_[q], acc[0]); } \
+                   STx<W_>(ypos, e, y_); STx<W_>(rpos, e, r_); }
+  SDFS_PACKET_LOOP(double, n, BODY)
+#undef BODY
+  block_partials<1>(acc, partial);
+}
+
+// does the step of the pass that is running mix?  (the state before that step; the same test as and_step_wave's, but for
+// the finiteness of the new residual, which only ever cancels a mixing step)
+__device__ __forceinline__ bool and_mix_due(const AndState* __restrict__ S, int m, int mixing_freq) {
+  const double it1 = S->it + 1.0;
+  return it1 >= m && it1 >= S->no_mix_until && ((long long)it1) % mixing_freq == 0;
+}
+
+// partial sums of <R_i, R_j>, i <= j < m, pair (i, j) at index i m - i (i - 1) / 2 + (j - i): partial[pair * gridDim.x + block]
+__global__ void __launch_bounds__(VEC_BLOCK)
+k_and_gram_full(AndPtrs h, int m, int mixing_freq, long long n, double* __restrict__ partial, const AndState* __restrict__ S) {
+  if (S->gate == 0ULL || !and_mix_due(S, m, mixing_freq)) return;
+  double acc[AND_LAZY_PAIRS];
+#pragma unroll
+  for (int p = 0; p < AND_LAZY_PAIRS; ++p) acc[p] = 0.0;
+  for (long long e = ((long long)blockIdx.x * VEC_BLOCK + threadIdx.x) * 2; e < n; e += (long long)gridDim.x * VEC_BLOCK * 2) {
+    double2 r[AND_LAZY_M];
+    const bool two = e + 1 < n;
+#pragma unroll
+    for (int j = 0; j < AND_LAZY_M; ++j) {
+      const double* const pj = h.R[j < m ? j : 0];
+      r[j] = two ? *reinterpret_cast<const double2*>(pj + e) : make_double2(pj[e], 0.0);      // (n even or the tail: e is even, the streams 16-byte aligned)
+    }
+    int p = 0;
+#pragma unroll
+    for (int i = 0; i < AND_LAZY_M; ++i)
+#pragma unroll
+      for (int j = i; j < AND_LAZY_M; ++j, ++p)
+        if (j < m) acc[p] = fma(r[i].y, r[j].y, fma(r[i].x, r[j].x, acc[p]));
+  }
+  // block sums: 16 lanes per DPP row, then rows and waves through LDS
+  __shared__ double red[AND_LAZY_PAIRS * 16];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int p = 0; p < AND_LAZY_PAIRS; ++p) {
+    double sj = acc[p];
+    sj += dpp_mov_f64<0xB1>(sj); sj += dpp_mov_f64<0x4E>(sj); sj += dpp_mov_f64<0x141>(sj); sj += dpp_mov_f64<0x140>(sj);
+    if ((lane & 15) == 0) red[p * 16 + wave * 4 + (lane >> 4)] = sj;
+  }
+  __syncthreads();
+  for (int p = threadIdx.x; p < AND_LAZY_PAIRS; p += VEC_BLOCK) {
+    double sj = 0.0;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) sj += red[p * 16 + q];
+    partial[(size_t)p * gridDim.x + blockIdx.x] = sj;
+  }
+}
+
+// the control step of that loop: <r, r> of the pass, the fresh matrix where a solve is due, then and_step_wave in place
+__global__ void __launch_bounds__(VEC_BLOCK)
+k_and_step_lazy(const double* __restrict__ partial_rr, int nb, const double* __restrict__ gram_partial, int gb, int refresh,
+                int m, int pos, int rel, AndState* S, double* __restrict__ err_slot, int* __restrict__ kind_slot,
+                double tol, double max_iter, int mixing_freq, double ridge) {
+  __shared__ AndStepLds sh;
+  __shared__ double rr_s;
+  if (S->gate == 0ULL) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const bool fresh = refresh != 0 && and_mix_due(S, m, mixing_freq);          // uniform
+  {
+    const double s = finish_sum(partial_rr, nb, 0);
+    if (tid == 0) rr_s = s;
+  }
+  if (fresh) {
+    // pair p = (i, j): wave w takes pairs w, w + 4, ...
+    int p = 0;
+    for (int i = 0; i < m; ++i)
+      for (int j = i; j < AND_LAZY_M; ++j, ++p) {
+        if (j >= m || (p & 3) != wave) continue;
+        double sj = 0.0;
+        for (int q = lane; q < gb; q += 64) sj += gram_partial[(size_t)p * gb + q];
+        sj = wave_sum(sj);
+        if (lane == 0) { S->G[i * m + j] = sj; S->G[j * m + i] = sj; }
+      }
+  }
+  __threadfence_block();
+  __syncthreads();
+  if (tid >= 64) return;
+  if (lane < AND_MAX_M) sh.row[lane] = lane == pos ? rr_s : (lane < m ? S->G[pos * m + lane] : 0.0);
+  and_wsync();
+  AndStepPar par;
+  par.tol = tol; par.max_iter = max_iter; par.ridge = ridge; par.mixing_freq = mixing_freq;
+  and_step_wave<AND_LAZY_M + 1, true>(sh, lane, m, pos, rel, S, S, true, err_slot, kind_slot, par);
+}
+
+// the update of x that pass `rel` decided on, history as Y_j = x_j + beta r_j
+__global__ void __launch_bounds__(VEC_BLOCK)
+k_and_mix_y(AndPtrs h, const AndState* __restrict__ S, int m, double beta, double* __restrict__ x, const double* __restrict__ fx,
+            int pos, int rel, long long n) {
+  if (S->mix_rel != rel) return;
+  const int mode = S->mix_mode;
+  if (mode == 0) {
+#define BODY(W_) { double f_[W_]; LDx<W_>(fx, e, f_); STx<W_>(x, e, f_); }
+    SDFS_PACKET_LOOP(double, n, BODY)
+#undef BODY
+    return;
+  }
+  if (mode == 1) {
+    double ca[AND_LAZY_M];
+#pragma unroll
+    for (int j = 0; j < AND_LAZY_M; ++j) ca[j] = j < m ? S->coef[j] : 0.0;
+#define BODY(W_) { double xa[W_], ys_[AND_LAZY_M][W_]; \
+                   _Pragma("unroll") for (int j = 0; j < AND_LAZY_M; ++j) { if (j < m) LDx<W_>((const double*)h.X[j], e, ys_[j]); } \
+                   _Pragma("unroll") for (int q = 0; q < W_; ++q) xa[q] = 0.0; \
+                   _Pragma("unroll") for (int j = 0; j < AND_LAZY_M; ++j) { if (j < m) { _Pragma("unroll") for (int q = 0; q < W_; ++q) xa[q] = fma(ca[j], ys_[j][q], xa[q]); } } \
+                   STx<W_>(x, e, xa); }
+    SDFS_PACKET_LOOP(double, n, BODY)
+#undef BODY
+    return;
+  }
+  // rejected step: x = x_prev + r_prev = Y_prev + (1 - beta) R_prev; the poisoned slot is cleared
+  const int prev = (int)S->prev_pos;
+  const double* py = h.X[0];
+  const double* pr = h.R[0];
+#pragma unroll
+  for (int j = 1; j < AND_LAZY_M; ++j)
+    if (j == prev) { py = h.X[j]; pr = h.R[j]; }
+#define BODY(W_) { double y_[W_], r_[W_], z_[W_]; LDx<W_>(py, e, y_); LDx<W_>(pr, e, r_); \
+                   _Pragma("unroll") for (int q = 0; q < W_; ++q) { y_[q] = fma(1.0 - beta, r_[q], y_[q]); z_[q] = 0.0; } \
+                   STx<W_>(x, e, y_); STx<W_>(yclr, e, y_); STx<W_>(rclr, e, z_); }
+  double* yclr = h.X[0];
+  double* rclr = h.R[0];
+#pragma unroll
+  for (int j = 1; j < AND_LAZY_M; ++j)
+    if (j == pos) { yclr = h.X[j]; rclr = h.R[j]; }
+  SDFS_PACKET_LOOP(double, n, BODY)
+#undef BODY
+}
+
 // ---- re-shard pack / unpack (multi-GPU exchange buffers) -----------------------------------------------------------------
 // grid = [outer][n_axis][inner] (C order), packed = concat_j [outer][size_j][inner] with block j = axis indices
 // offs[j] .. offs[j+1].  One launch moves the whole shard (the host side used one strided copy per peer).  U = unit type

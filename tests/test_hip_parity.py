@@ -723,6 +723,36 @@ def test_anderson_fused_loop_through_the_safeguard(S):
     assert sum(h[3] > 0 for h in hits) >= 2, f"the starts of this test did not reach the safeguard in the fused loop: {hits}"
 
 
+def test_anderson_batched_gram_loop_on_large_grids(S):
+    """Grids of 2^21 points and more: the push writes its history slot and <r, r>, the whole Gram matrix is recomputed
+    in one sweep over the residual history where a solve is due (every mixing_freq-th pass) and the history holds
+    Y_j = x_j + beta r_j (vec_kernels.hpp, k_and_push_lite / k_and_gram_full / k_and_step_lazy / k_and_mix_y), against
+    the loop that adds one Gram row per pass (SDFS_AND_FUSED=0, itself held to the host-controlled loop above).  On a
+    well-conditioned system (ridge 1e9, beta 1) the whole path agrees to rounding -- plain, mixing and chunk-boundary
+    passes alike; with the reference's parameters both reach the same fixed point through the safeguard (GCY 12^6
+    rejects mixing steps)."""
+    build = _anderson_builder(S)
+    for shapes in ((12,) * 6, (16, 16, 8, 8, 16, 16)):
+        Tl, Tr = build("gcy", shapes, False, fused=True), build("gcy", shapes, False, fused=False)
+        w0 = np.full(shapes, 800.0)
+        kw = dict(ridge=1e9, beta=1.0, record_errors=True)
+        for k, extra in ((13, {}), (41, {}), (57, dict(check_every=7)), (30, dict(history=3, mixing_freq=2))):
+            xl, nl, il = Tl.solve(w0, "anderson", tol=0.0, max_iter=k, **kw, **extra)
+            xr, nr, ir = Tr.solve(w0, "anderson", tol=0.0, max_iter=k, **kw, **extra)
+            assert nl == nr == k and len(il["errors"]) == len(ir["errors"]) == k
+            np.testing.assert_allclose(il["errors"], ir["errors"], rtol=1e-9)
+            np.testing.assert_allclose(xl, xr, rtol=1e-11)
+        xl, nl, il = Tl.solve(w0, "anderson", tol=1e-6, max_iter=5000, record_errors=True)
+        xr, nr, ir = Tr.solve(w0, "anderson", tol=1e-6, max_iter=5000, record_errors=True)
+        assert il["status"] == 0 and il["final_err"] <= 1e-6 and np.all(np.isfinite(xl))
+        assert abs(nl - nr) <= max(8, nr // 5), (nl, nr)
+        np.testing.assert_allclose(xl, xr, rtol=0, atol=1e-5)
+        assert np.max(np.abs(Tl(xl) - xl)) <= 1e-6
+        if shapes == (12,) * 6:
+            assert len(il["errors"]) < nl            # rejected passes run but stay out of the trace
+        Tl.close(); Tr.close()
+
+
 @pytest.mark.parametrize("model,shapes,beta,gamma,psi,level", [
     ("ssy", (15, 15, 15, 15), 0.99, 13.68, 1.5, 5.0),          # theta = -38, start far below the fast opening power's range
     ("ssy", (16, 16, 16, 16), 0.9987, 12.5, 1.97, 300.0),
