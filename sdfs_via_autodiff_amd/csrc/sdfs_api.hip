@@ -1944,7 +1944,7 @@ int solve_anderson(sdfs_handle* h, const sdfs_opts& o, double* w, int64_t* n_ite
   const bool lazyp = h->knobs.and_fused && !fusedp && !h->sharded && m <= AND_LAZY_M && h->N >= (1LL << 21);
   if (lazyp) {
     auto lcm = [](long long a, long long b) { long long x = a, y = b; while (y) { const long long t = x % y; x = y; y = t; } return a / x * b; };
-    const long long unit = lcm(m, o.mixing_freq);
+    const long long unit = lcm(lcm(m, o.mixing_freq), 2);
     chunk = (int)(((chunk + unit - 1) / unit) * unit);
     if (!h->and_gram_partial) {
       HIPCHK(h, hipMalloc((void**)&h->and_gram_partial, sizeof(double) * (size_t)AND_LAZY_PAIRS * AND_LAZY_BLOCKS));
@@ -2089,17 +2089,21 @@ int solve_anderson(sdfs_handle* h, const sdfs_opts& o, double* w, int64_t* n_ite
     const int gb = (int)std::min<long long>(AND_LAZY_BLOCKS, std::max<long long>(1, (n + 2 * VEC_BLOCK - 1) / (2 * VEC_BLOCK)));
     for (int i = 0; i < count; ++i) {
       const int pos = i % m;
-      int r2 = apply_T_dev(h, x, fx, nullptr, &S->gate, 0.0);
+      // the iterate alternates between the two buffers (chunks are even): a plain step x = T x is then no copy at all,
+      // a mixing step writes over T x, which the push has consumed
+      double* const xi = (i & 1) ? fx : x;
+      double* const xo = (i & 1) ? x : fx;
+      int r2 = apply_T_dev(h, xi, xo, nullptr, &S->gate, 0.0);
       if (r2) return r2;
       ProfScope ps(h, cvec);
-      hipLaunchKernelGGL(k_and_push_lite, dim3(g), dim3(VEC_BLOCK), 0, st, (const double*)x, (const double*)fx, hp.X[pos], hp.R[pos], o.beta, n, h->partial,
+      hipLaunchKernelGGL(k_and_push_lite, dim3(g), dim3(VEC_BLOCK), 0, st, (const double*)xi, (const double*)xo, hp.X[pos], hp.R[pos], o.beta, n, h->partial,
                          (const unsigned long long*)&S->gate);
       const int refresh = ((i + 1) % (int)o.mixing_freq) == 0 ? 1 : 0;
       if (refresh)
         hipLaunchKernelGGL(k_and_gram_full, dim3(gb), dim3(VEC_BLOCK), 0, st, hp, m, (int)o.mixing_freq, n, h->and_gram_partial, (const AndState*)S);
       hipLaunchKernelGGL(k_and_step_lazy, dim3(1), dim3(VEC_BLOCK), 0, st, (const double*)h->partial, g, (const double*)h->and_gram_partial, gb, refresh,
                          m, pos, i, S, h->and_err + i, h->and_kind + i, o.tol, (double)o.max_iter, (int)o.mixing_freq, o.ridge);
-      hipLaunchKernelGGL(k_and_mix_y, dim3(g), dim3(VEC_BLOCK), 0, st, hp, (const AndState*)S, m, o.beta, x, (const double*)fx, pos, i, n);
+      hipLaunchKernelGGL(k_and_mix_y, dim3(g), dim3(VEC_BLOCK), 0, st, hp, (const AndState*)S, m, o.beta, xo, (const double*)xo, pos, i, n);
     }
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipMemcpyAsync(h->and_err_host, h->and_err, sizeof(double) * (size_t)count, hipMemcpyDeviceToHost, st));
@@ -2143,7 +2147,8 @@ int solve_anderson(sdfs_handle* h, const sdfs_opts& o, double* w, int64_t* n_ite
   const AndState& F = *h->and_state_host;
   const long long it = (long long)F.it;
   const double err = F.err;
-  HIPCHK(h, hipMemcpyAsync(w, x, nb, hipMemcpyDeviceToDevice, st));
+  // (batched-Gram loop: pass i leaves the iterate in buffer (i + 1) & 1)
+  HIPCHK(h, hipMemcpyAsync(w, (lazyp && (it & 1)) ? fx : x, nb, hipMemcpyDeviceToDevice, st));
   HIPCHK(h, hipStreamSynchronize(st));
   *n_iter = it; *n_apply = it; *final_err = err;
   if (F.status != 0.0) return fail(h, SDFS_ERR_NUMERIC, "non-finite Anderson residual at iteration %lld", it);

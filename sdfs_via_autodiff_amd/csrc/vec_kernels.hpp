@@ -665,11 +665,12 @@ k_and_step_lazy(const double* __restrict__ partial_rr, int nb, const double* __r
 
 // the update of x that pass `rel` decided on, history as Y_j = x_j + beta r_j
 __global__ void __launch_bounds__(VEC_BLOCK)
-k_and_mix_y(AndPtrs h, const AndState* __restrict__ S, int m, double beta, double* __restrict__ x, const double* __restrict__ fx,
+k_and_mix_y(AndPtrs h, const AndState* __restrict__ S, int m, double beta, double* x, const double* fx,
             int pos, int rel, long long n) {
   if (S->mix_rel != rel) return;
   const int mode = S->mix_mode;
   if (mode == 0) {
+    if (x == fx) return;                  // (the caller alternates its buffers: T x already sits where the next pass reads)
 #define BODY(W_) { double f_[W_]; LDx<W_>(fx, e, f_); STx<W_>(x, e, f_); }
     SDFS_PACKET_LOOP(double, n, BODY)
 #undef BODY
