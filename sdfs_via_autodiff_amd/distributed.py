@@ -526,35 +526,36 @@ def anderson_sharded(op, w_loc, tol=1e-7, max_iter=10000, history_size=10, mixin
                      errors=None, stats=None):
     """Anderson acceleration (code/solvers.py:98-124: jaxopt.AndersonAcceleration with m = 10, mixing every 4th
     iteration, beta = 8, ridge 1e-6; semantics restated in oracle/solvers.py, iterate parity UNPINNED) on a sharded
-    grid, fixed layout.  Per iteration: one sharded application of T (two exchanges), the history write, and ONE
-    all-reduce (SUM) of m + 1 doubles -- the new Gram row <r_pos, r_j> with |r|^2 as its last entry.  The
-    (m+1)^2 system is solved redundantly on every rank from the all-reduced Gram matrix (identical inputs, identical
-    result), the extrapolation is local.  A mixing step that leaves the domain (w <= 0 or not finite; at large grids
+    grid, fixed layout.  Per iteration: one sharded application of T (two exchanges), the history write and ONE
+    all-reduce (SUM) of |r|^2; where a solve is due (every mixing_frequency-th iteration) the whole Gram matrix is
+    recomputed in one sweep over the residual history and all-reduced (m^2 doubles -- SURVEY 8e's Gram all-reduce, per
+    solve instead of a row per iteration: the rows in between were only ever used by that solve).  The (m+1)^2 system
+    is solved redundantly on every rank from the all-reduced matrix (identical inputs, identical result), the
+    extrapolation is local.  A mixing step that leaves the domain (w <= 0 or not finite; at large grids
     N r^2 dwarfs the absolute ridge) is rejected as in the single-GPU loop: plain step, history restarted.
     Returns (w_loc, n_iter); the error is the reference's: the Euclidean norm of T(w) - w."""
     m = int(history_size)
     dev = w_loc.device
     n = w_loc.numel()
-    X = torch.zeros((m, n), dtype=torch.float64, device=dev)
+    # history slot j: Y_j = x_j + beta r_j and r_j, so that a mixing step reads m streams (x = sum_j alpha_j Y_j)
+    Y = torch.zeros((m, n), dtype=torch.float64, device=dev)
     R = torch.zeros((m, n), dtype=torch.float64, device=dev)
     G = np.zeros((m, m))
     x = w_loc.contiguous().clone()
     it, error, filled, pause = 0, float("inf"), 0, 0
     n_rejected = 0
+    rr = torch.empty(1, dtype=torch.float64, device=dev)
     while error > tol and it < max_iter:
         fx = op.apply_T(x)
         pos = it % m
         r = R[pos]
         torch.sub(fx.reshape(-1), x.reshape(-1), out=r)
-        X[pos].copy_(x.reshape(-1))
-        row = torch.empty(m + 1, dtype=torch.float64, device=dev)
-        torch.mv(R, r, out=row[:m])                     # <r_j, r_pos> for every slot (stale slots are zero rows)
-        row[m] = row[pos]
-        op.allreduce_sum(row)
-        rowh = row.tolist()                               # the one host read of the iteration
-        G[pos, :] = rowh[:m]
-        G[:, pos] = rowh[:m]
-        error = float(np.sqrt(rowh[m])) if rowh[m] == rowh[m] else float("inf")
+        torch.add(x.reshape(-1), r, alpha=beta, out=Y[pos])
+        rr[0] = torch.dot(r, r)
+        op.allreduce_sum(rr)
+        rrh = float(rr.item())                            # the one host read of a plain iteration
+        G[pos, pos] = rrh
+        error = float(np.sqrt(rrh)) if rrh == rrh else float("inf")
         if errors is not None:
             errors.append(error)
         filled = min(filled + 1, m)
@@ -562,6 +563,11 @@ def anderson_sharded(op, w_loc, tol=1e-7, max_iter=10000, history_size=10, mixin
         if pause > 0:
             pause -= 1
         elif it + 1 >= m and (it + 1) % mixing_frequency == 0 and filled == m and np.isfinite(error):
+            # the Gram matrix where a solve is due: one sweep over the residual history (m streams per mixing_frequency
+            # iterations instead of m per iteration), one all-reduce of m^2 doubles
+            Gd = torch.mm(R, R.t()).reshape(-1)
+            op.allreduce_sum(Gd)
+            G[:, :] = Gd.cpu().numpy().reshape(m, m)
             Hm = np.zeros((m + 1, m + 1))
             Hm[0, 1:] = 1.0
             Hm[1:, 0] = 1.0
@@ -574,7 +580,7 @@ def anderson_sharded(op, w_loc, tol=1e-7, max_iter=10000, history_size=10, mixin
                 alphas = None
             if alphas is not None and np.all(np.isfinite(alphas)):
                 a = torch.from_numpy(alphas).to(dev)
-                cand = torch.mv(X.t(), a).add_(torch.mv(R.t(), a), alpha=beta)
+                cand = torch.mv(Y.t(), a)
                 # reject a step that leaves the domain (every rank must agree: all-reduced flag)
                 bad = torch.stack([(~torch.isfinite(cand)).any() | (cand <= 0).any()]).to(torch.float64)
                 op.allreduce_max(bad)
@@ -583,10 +589,10 @@ def anderson_sharded(op, w_loc, tol=1e-7, max_iter=10000, history_size=10, mixin
                     mixed = True
                 else:
                     n_rejected += 1
-                    R.zero_(); X.zero_(); G[:] = 0.0
+                    R.zero_(); Y.zero_(); G[:] = 0.0
                     filled, pause = 0, m
         if not mixed:
-            x = fx.clone()
+            x = fx.clone()                                # (apply_T hands out its cached output buffer: the next call writes over it)
         it += 1
     if stats is not None:
         stats["rejected_mixes"] = n_rejected
