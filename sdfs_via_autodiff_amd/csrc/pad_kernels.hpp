@@ -1,12 +1,13 @@
-// pad_kernels.hpp -- the pair plan for 6-D grids between the plans: every extent <= 16 (10^6 ... 15^6, ragged shapes),
-// too many points for the latency-tuned small-grid kernels, no extent the compile-time pair kernels exist for.
+// pad_kernels.hpp -- the pair plan for the grids between the plans: extents the compile-time pair kernels do not exist
+// for (10^6 ... 15^6, 17^6 ... 19^6, 25^6, ragged shapes up to 32 per axis), too many points for the latency-tuned
+// small-grid kernels.
 //
 // Same factorisation as fast_kernels.hpp (code/gcy/discrete/gcy_wc_ratio.py:134-238: H is a Kronecker product, so an
-// application is three passes, one per adjacent axis pair), with RUN-TIME extents nx, ny <= 16 on compile-time 16 x 16
-// MFMA tiles: global addresses follow the real strides -- HBM traffic is the grid's, not the padded one's -- the LDS
-// image is padded to 16 x 16 with zeros and the matrices are the zero-padded 16 x 16 copies the small-grid plan keeps
-// (padded rows and columns contribute exact zeros, ctile<16, .> runs unmasked).
-//   pad_slice_kernel  the two fastest axes: a tile is G = 4 consecutive slices of nx * ny contiguous doubles per wave,
+// application is three passes, one per adjacent axis pair), with RUN-TIME extents nx, ny <= NT on compile-time NT x NT
+// MFMA tiles (NT = 16, 24, 32, chosen per pass): global addresses follow the real strides -- HBM traffic is the grid's,
+// not the padded one's -- the LDS image is padded to NT x NT with zeros and the matrices are zero-padded NT x NT copies
+// (padded rows and columns contribute exact zeros, ctile<NT, .> runs unmasked).
+//   pad_slice_kernel  the two fastest axes: a tile is G = 4 / 2 / 1 consecutive slices of nx * ny contiguous doubles per wave,
 //                     elements in memory order (8-byte requests, 512 contiguous bytes per wave request);
 //   pad_line_kernel   a slower pair: a tile is all (x, y) rows of 16 consecutive positions behind the pair (one
 //                     128-byte line per row when the remainder is a multiple of 16 doubles; rows of a ragged
@@ -22,13 +23,13 @@ namespace sdfs {
 
 struct PadDesc {
   int nx, ny;               // extents of the contracted pair (X slower)
-  unsigned mxy, my;         // ceil(2^20 / (nx ny)), ceil(2^20 / ny): e / d == (e * m) >> 20 for e < 4096
+  unsigned mxy, my;         // ceil(2^20 / (nx ny)), ceil(2^20 / ny): e / d == (e * m) >> 20 for e < 4096 (and d >= 4)
   long long nslices;        // slice form: slices of nx * ny contiguous doubles
   long long lrest;          // line form: contiguous doubles behind Y
   int nchunks;              //            ceil(lrest / 16)
   long long nouter;         //            product of the extents before X
   long long ntiles;         //            nouter * nchunks
-  const double* Qx;         // 16 x 16 zero-padded matrices
+  const double* Qx;         // NT x NT zero-padded matrices
   const double* Qy;
   double theta, inv_theta, beta;
   const double* a3;         // aggregator scale: index = out_idx[o] + x * a3x + y * a3y + rest_idx[pos]
@@ -38,14 +39,21 @@ struct PadDesc {
   int minus_identity;
 };
 
-constexpr int PAD_G = 4;                        // slices per wave tile
-constexpr int PAD_RS = 18;                      // LDS row stride (conflict-free columns, see SliceGeo)
-constexpr int PAD_LT = PAD_G * 16 * PAD_RS;     // doubles of LDS per wave tile
-constexpr int PAD_EPL = PAD_G * 256 / 64;       // elements per lane of a full tile
+// slice form: G slices per wave tile, LDS row stride NT + 2 (conflict-free columns, see SliceGeo)
+template <int NT> struct PadSliceGeo {
+  static constexpr int G = NT == 16 ? 4 : (NT == 24 ? 2 : 1);      // (static LDS of the four wave tiles stays below 64 KB)
+  static constexpr int RS = NT + 2;
+  static constexpr int LT = G * NT * RS;            // doubles of LDS per wave tile
+  static constexpr int EPL = G * NT * NT / 64;      // elements per lane of a full tile
+  static constexpr int OCC = NT == 16 ? 3 : 2;      // workgroups per CU the register budget is set for
+  static_assert((G * NT) % 16 == 0 && (G * NT * NT) % 64 == 0, "whole column tiles and lane loops");
+};
 
-template <int MODE>
-__global__ void __launch_bounds__(256, 3)
+template <int MODE, int NT>
+__global__ void __launch_bounds__(256, PadSliceGeo<NT>::OCC)
 pad_slice_kernel(const PadDesc P, const SliceIO io) {
+  using Geo = PadSliceGeo<NT>;
+  constexpr int PAD_G = Geo::G, PAD_RS = Geo::RS, PAD_LT = Geo::LT, PAD_EPL = Geo::EPL;
   constexpr bool POWP = MODE == S_TFIRST || MODE == S_TFIRST_LIN;
   constexpr bool LIN = MODE == S_TFIRST_LIN;
   constexpr bool MULP = MODE == S_JFIRST;
@@ -75,16 +83,17 @@ pad_slice_kernel(const PadDesc P, const SliceIO io) {
   }
   // ---- zero image, element -> (slice, x, y) -> LDS offset -------------------------------------------------------
 #pragma unroll
-  for (int k = 0; k < PAD_LT / 64; ++k) wl[lane + 64 * k] = 0.0;
+  for (int k = 0; k < (PAD_LT + 63) / 64; ++k)
+    if (PAD_LT % 64 == 0 || lane + 64 * k < PAD_LT) wl[lane + 64 * k] = 0.0;
   int lo[PAD_EPL];
 #pragma unroll
   for (int k = 0; k < PAD_EPL; ++k) {
     const unsigned e = (unsigned)(lane + 64 * k);
     const unsigned s = (e * P.mxy) >> 20, r = e - s * (unsigned)nxy;
     const unsigned x = (r * P.my) >> 20, y = r - x * (unsigned)P.ny;
-    lo[k] = (int)((s * 16u + x) * (unsigned)PAD_RS + y);
+    lo[k] = (int)((s * (unsigned)NT + x) * (unsigned)PAD_RS + y);
   }
-  QFrag<16> qf;
+  QFrag<NT> qf;
   qf.load(P.Qy, lane);
   wave_lds_fence();
   // ---- x = w^theta (c1 = w^(theta-1)) or v c1 on the registers, then parked -------------------------------------
@@ -109,19 +118,24 @@ pad_slice_kernel(const PadDesc P, const SliceIO io) {
   }
   wave_lds_fence();
   const int li = lane & 15, lk = lane >> 4;
+  constexpr int NCT = PAD_G * NT / 16;                           // column tiles of either contraction
   // ---- contraction over the fastest axis: column c = (slice, x) at wl + c * RS, rows contiguous -----------------
   {
     double* const p0 = wl + li * PAD_RS + lk;
 #pragma unroll
-    for (int ct = 0; ct < PAD_G; ++ct) ctile<16, 1>(p0 + ct * 16 * PAD_RS, qf);
+    for (int ct = 0; ct < NCT; ++ct) ctile<NT, 1>(p0 + ct * 16 * PAD_RS, qf);
   }
   wave_lds_fence();
-  // ---- contraction over the second axis: column c = (slice g, y) at wl + g 16 RS + y, row stride RS -------------
+  // ---- contraction over the second axis: column c = (slice g, y) at wl + g NT RS + y, row stride RS -------------
   {
-    QFrag<16> qe;
+    QFrag<NT> qe;
     qe.load(P.Qx, lane);
 #pragma unroll
-    for (int g = 0; g < PAD_G; ++g) ctile<16, PAD_RS>(wl + g * (16 * PAD_RS) + li + lk * PAD_RS, qe);
+    for (int ct = 0; ct < NCT; ++ct) {
+      const int c = 16 * ct + li;
+      const int g = c / NT, f = c - g * NT;
+      ctile<NT, PAD_RS>(wl + g * (NT * PAD_RS) + f + lk * PAD_RS, qe);
+    }
   }
   wave_lds_fence();
 #pragma unroll
@@ -129,17 +143,29 @@ pad_slice_kernel(const PadDesc P, const SliceIO io) {
     if (lane + 64 * k < nval) io.out[gbase + lane + 64 * k] = wl[lo[k]];
 }
 
-// Line form.  Unit u = tid + 256 k (k < 8) is the double2 c2 = tid & 7 of row u >> 3 = (x, y) = ((tid >> 7) + 2 k,
-// (tid >> 3) & 15): a thread keeps its y and its two positions, x advances by 2 per unit.
-template <int MODE>
-__global__ void __launch_bounds__(256, 3)
+// Line form.  Unit u = tid + B k is the double2 c2 = tid & 7 of row u >> 3 = (x, y) = (row / NT, row % NT); a thread keeps
+// its two positions.  LDS: NT * NT rows of 16 doubles (dynamic: 32 / 72 / 128 KB).
+template <int NT> struct PadLineGeo {
+  static constexpr int B = NT <= 24 ? 256 : 512;
+  static constexpr int W = B / 64;
+  static constexpr int UNITS = NT * NT * LINE_R / 2;
+  static constexpr int EPT = UNITS / B;
+  static constexpr int LX = NT * LINE_R;
+  static constexpr int OCC = NT == 16 ? 3 : (NT == 24 ? 2 : 1);
+  static constexpr size_t LDS_BYTES = (size_t)NT * NT * LINE_R * 8;
+  static_assert(UNITS % B == 0 && NT % W == 0, "whole units per thread, column tiles split evenly over the waves");
+};
+
+template <int MODE, int NT>
+__global__ void __launch_bounds__(PadLineGeo<NT>::B, PadLineGeo<NT>::OCC * PadLineGeo<NT>::B / 256)
 pad_line_kernel(const PadDesc P, const LineIO io) {
+  using Geo = PadLineGeo<NT>;
   constexpr bool CES = MODE == L_TLAST || MODE == L_TLAST_LIN;
   constexpr bool LINE = MODE == L_TLAST_LIN;
   constexpr bool MULE = MODE == L_JLAST;
-  constexpr int EPT = 8;
-  __shared__ __attribute__((aligned(16))) double lds[16 * 16 * LINE_R];
-  __shared__ double red[16];
+  constexpr int EPT = Geo::EPT, B = Geo::B;
+  extern __shared__ double lds[];
+  __shared__ double red[32];
   if (io.gate != nullptr) {
     const unsigned long long g = *io.gate;
     if (g <= (unsigned long long)__double_as_longlong(io.gate_tol)) return;
@@ -149,69 +175,79 @@ pad_line_kernel(const PadDesc P, const LineIO io) {
   const unsigned t = (unsigned)xcd_remap((long long)blockIdx.x, P.ntiles);
   const unsigned o = t / (unsigned)P.nchunks;
   const int chunk = (int)(t - o * (unsigned)P.nchunks);
-  const int c2 = tid & 7, y = (tid >> 3) & 15, x0 = tid >> 7;
+  const int c2 = tid & 7;
   const long long pos = (long long)chunk * LINE_R + 2 * c2;
-  const bool yok = y < P.ny;
-  const bool ok0 = yok && pos < P.lrest, ok1 = yok && pos + 1 < P.lrest;
-  const long long tbase = (long long)o * (P.nx * P.ny) * P.lrest + (long long)chunk * LINE_R;
-  const long long off0 = ((long long)x0 * P.ny + y) * P.lrest + 2 * c2;       // element offset of unit 0 against tbase
-  const long long ostep = 2LL * P.ny * P.lrest;
+  const bool pk0 = pos < P.lrest, pk1 = pos + 1 < P.lrest;
+  const long long tbase = (long long)o * (P.nx * P.ny) * P.lrest + (long long)chunk * LINE_R + 2 * c2;
   const bool need_old = CES ? io.resid != nullptr : (MULE && P.minus_identity);
+  // unit k of this thread: row -> (x, y), validity, element offset against tbase
+  auto unit_of = [&](const int k, int& x, int& y, bool& rok, long long& off) {
+    const int row = (tid + B * k) >> 3;
+    x = row / NT; y = row - x * NT;
+    rok = x < P.nx && y < P.ny;
+    off = ((long long)x * P.ny + y) * P.lrest;
+  };
   // ---- loads: the tile and the side stream that crosses the contractions -----------------------------------------
-  const double* const inb = io.in + tbase + off0;
-  const double* const oldb = io.old + tbase + off0;
-  double2 v[EPT], s1[(CES || MULE) ? EPT : 1];
-#pragma unroll
-  for (int k = 0; k < EPT; ++k) {
-    const bool xok = x0 + 2 * k < P.nx;
-    v[k] = make_double2((ok0 && xok) ? inb[k * ostep] : 0.0, (ok1 && xok) ? inb[k * ostep + 1] : 0.0);
-    if ((CES || MULE) && need_old)
-      s1[(CES || MULE) ? k : 0] = make_double2((ok0 && xok) ? oldb[k * ostep] : 0.0, (ok1 && xok) ? oldb[k * ostep + 1] : 0.0);
-  }
-#pragma unroll
-  for (int k = 0; k < EPT; ++k) *reinterpret_cast<double2*>(lds + 2 * (tid + 256 * k)) = v[k];     // (every slot has its owner: no zero fill)
+  const double* const inb = io.in + tbase;
+  const double* const oldb = io.old + tbase;
+  double2 s1[(CES || MULE) ? EPT : 1];
   {
-    QFrag<16> q;
+    double2 v[EPT];
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) {
+      int x, y; bool rok; long long off;
+      unit_of(k, x, y, rok, off);
+      v[k] = make_double2((pk0 && rok) ? inb[off] : 0.0, (pk1 && rok) ? inb[off + 1] : 0.0);
+      if ((CES || MULE) && need_old)
+        s1[(CES || MULE) ? k : 0] = make_double2((pk0 && rok) ? oldb[off] : 0.0, (pk1 && rok) ? oldb[off + 1] : 0.0);
+    }
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) *reinterpret_cast<double2*>(lds + 2 * (tid + B * k)) = v[k];     // (every slot has its owner: no zero fill)
+  }
+  {
+    QFrag<NT> q;
     q.load(P.Qx, lane);
     __syncthreads();
-    // contraction over X: column = (y, r) = LDS offset, row stride 16 * 16
+    // contraction over X: column = (y, r) = LDS offset, row stride NT * 16
     {
-      double* const p0 = lds + li + lk * (16 * LINE_R);
+      double* const p0 = lds + li + lk * Geo::LX;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) ctile<16, 16 * LINE_R>(p0 + (wave + j * 4) * 16, q);
+      for (int j = 0; j < NT / Geo::W; ++j) ctile<NT, Geo::LX>(p0 + (wave + j * Geo::W) * 16, q);
     }
     q.load(P.Qy, lane);
     __syncthreads();
-    // contraction over Y: column = (x, r) at x * 256 + r, row stride 16
+    // contraction over Y: column = (x, r) at x * LX + r, row stride 16
     {
       double* const p0 = lds + li + lk * LINE_R;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) ctile<16, LINE_R>(p0 + (wave + j * 4) * (16 * LINE_R), q);
+      for (int j = 0; j < NT / Geo::W; ++j) ctile<NT, LINE_R>(p0 + (wave + j * Geo::W) * Geo::LX, q);
     }
     __syncthreads();
   }
   // ---- epilogue --------------------------------------------------------------------------------------------------
-  double* const outb = io.out + tbase + off0;
+  double* const outb = io.out + tbase;
   double rmax = 0.0, dot_yv = 0.0, dot_yy = 0.0;
   bool rnan = false;
   if (CES) {
     const PowLane PT = pow_lane_init(lane);
     const unsigned io0 = (unsigned)P.out_idx[o];
-    const unsigned ia = ok0 ? io0 + (unsigned)P.rest_idx[pos] + (unsigned)y * (unsigned)P.a3y : 0u;
-    const unsigned ib = ok1 ? io0 + (unsigned)P.rest_idx[pos + 1] + (unsigned)y * (unsigned)P.a3y : 0u;
+    const unsigned ia = pk0 ? io0 + (unsigned)P.rest_idx[pos] : 0u;
+    const unsigned ib = pk1 ? io0 + (unsigned)P.rest_idx[pos + 1] : 0u;
     double2 s2[EPT];
 #pragma unroll
     for (int k = 0; k < EPT; ++k) {
-      const bool xok = x0 + 2 * k < P.nx;
-      const unsigned ix = (unsigned)(x0 + 2 * k) * (unsigned)P.a3x;
-      s2[k] = make_double2(P.a3[(ok0 && xok) ? ia + ix : 0u], P.a3[(ok1 && xok) ? ib + ix : 0u]);
+      int x, y; bool rok; long long off;
+      unit_of(k, x, y, rok, off);
+      const unsigned ixy = (unsigned)x * (unsigned)P.a3x + (unsigned)y * (unsigned)P.a3y;
+      s2[k] = make_double2(P.a3[(pk0 && rok) ? ia + ixy : 0u], P.a3[(pk1 && rok) ? ib + ixy : 0u]);
     }
-    double* const auxo = io.aux_out + tbase + off0;
+    double* const auxo = io.aux_out + tbase;
 #pragma unroll
     for (int k = 0; k < EPT; ++k) {
-      const bool xok = x0 + 2 * k < P.nx;
-      const bool a = ok0 && xok, b = ok1 && xok;
-      const double2 sv = *reinterpret_cast<const double2*>(lds + 2 * (tid + 256 * k));
+      int x, y; bool rok; long long off;
+      unit_of(k, x, y, rok, off);
+      const bool a = pk0 && rok, b = pk1 && rok;
+      const double2 sv = *reinterpret_cast<const double2*>(lds + 2 * (tid + B * k));
       // Tw = 1 + beta (a3 S)^(1/theta), c2 = beta u / S, |Tw - w|; every lane runs the power (its table gathers need the
       // whole wave), masked lanes feed it 1
       const double ks[2] = {a ? s2[k].x * sv.x : 1.0, b ? s2[k].y * sv.y : 1.0};
@@ -219,31 +255,33 @@ pad_line_kernel(const PadDesc P, const LineIO io) {
       pow_fast_n<false, 2>(ks, P.inv_theta, PT, uu);
       const double y0 = 1.0 + P.beta * uu[0], y1 = 1.0 + P.beta * uu[1];
       if (a) {
-        if (LINE) auxo[k * ostep] = P.beta * uu[0] / sv.x;
+        if (LINE) auxo[off] = P.beta * uu[0] / sv.x;
         if (need_old) { const double r0 = fabs(y0 - s1[k].x); rnan |= (r0 != r0); rmax = fmax(rmax, r0); }
-        outb[k * ostep] = y0;
+        outb[off] = y0;
       }
       if (b) {
-        if (LINE) auxo[k * ostep + 1] = P.beta * uu[1] / sv.y;
+        if (LINE) auxo[off + 1] = P.beta * uu[1] / sv.y;
         if (need_old) { const double r1 = fabs(y1 - s1[k].y); rnan |= (r1 != r1); rmax = fmax(rmax, r1); }
-        outb[k * ostep + 1] = y1;
+        outb[off + 1] = y1;
       }
     }
   } else {
-    const double* const auxb = io.aux_in + tbase + off0;
+    const double* const auxb = io.aux_in + tbase;
     double2 s2[MULE ? EPT : 1];
     if (MULE) {
 #pragma unroll
       for (int k = 0; k < EPT; ++k) {
-        const bool xok = x0 + 2 * k < P.nx;
-        s2[MULE ? k : 0] = make_double2((ok0 && xok) ? auxb[k * ostep] : 0.0, (ok1 && xok) ? auxb[k * ostep + 1] : 0.0);
+        int x, y; bool rok; long long off;
+        unit_of(k, x, y, rok, off);
+        s2[MULE ? k : 0] = make_double2((pk0 && rok) ? auxb[off] : 0.0, (pk1 && rok) ? auxb[off + 1] : 0.0);
       }
     }
 #pragma unroll
     for (int k = 0; k < EPT; ++k) {
-      const bool xok = x0 + 2 * k < P.nx;
-      const bool a = ok0 && xok, b = ok1 && xok;
-      double2 y2 = *reinterpret_cast<const double2*>(lds + 2 * (tid + 256 * k));
+      int x, y; bool rok; long long off;
+      unit_of(k, x, y, rok, off);
+      const bool a = pk0 && rok, b = pk1 && rok;
+      double2 y2 = *reinterpret_cast<const double2*>(lds + 2 * (tid + B * k));
       if (MULE) {
         y2.x *= s2[MULE ? k : 0].x; y2.y *= s2[MULE ? k : 0].y;
         if (P.minus_identity) {
@@ -253,18 +291,20 @@ pad_line_kernel(const PadDesc P, const LineIO io) {
           if (b) { dot_yv = fma(y2.y, o2.y, dot_yv); dot_yy = fma(y2.y, y2.y, dot_yy); }
         }
       }
-      if (a) outb[k * ostep] = y2.x;
-      if (b) outb[k * ostep + 1] = y2.y;
+      if (a) outb[off] = y2.x;
+      if (b) outb[off + 1] = y2.y;
     }
   }
   // ---- per-workgroup reductions ------------------------------------------------------------------------------------
   if (MULE && io.dotp != nullptr) {
     dot_yv = wave_sum_f64(dot_yv); dot_yy = wave_sum_f64(dot_yy);
-    if (lane == 0) { red[wave] = dot_yv; red[8 + wave] = dot_yy; }
+    if (lane == 0) { red[wave] = dot_yv; red[16 + wave] = dot_yy; }
     __syncthreads();
     if (tid == 0) {
-      io.dotp[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
-      io.dotp[gridDim.x + blockIdx.x] = (red[8] + red[9]) + (red[10] + red[11]);
+      double sa = 0.0, sb = 0.0;
+      for (int w = 0; w < Geo::W; ++w) { sa += red[w]; sb += red[16 + w]; }
+      io.dotp[blockIdx.x] = sa;
+      io.dotp[gridDim.x + blockIdx.x] = sb;
     }
   }
   if (CES && io.resid != nullptr) {
@@ -272,30 +312,43 @@ pad_line_kernel(const PadDesc P, const LineIO io) {
     rmax = wave_max_f64(rmax);
     if (lane == 0) red[wave] = rmax;
     __syncthreads();
-    if (tid == 0) atomicMax(io.resid, (unsigned long long)__double_as_longlong(fmax(fmax(red[0], red[1]), fmax(red[2], red[3]))));
+    if (tid == 0) {
+      double r = red[0];
+      for (int w = 1; w < Geo::W; ++w) r = fmax(r, red[w]);
+      atomicMax(io.resid, (unsigned long long)__double_as_longlong(r));
+    }
   }
 }
 
 typedef void (*pad_slice_fn)(const PadDesc, const SliceIO);
 typedef void (*pad_line_fn)(const PadDesc, const LineIO);
 #ifndef SDFS_NO_VARIANT_TABLES
-inline pad_slice_fn pad_slice_variant(int mode) {
+template <int NT> inline pad_slice_fn pad_slice_variant_n(int mode) {
   switch (mode) {
-    case S_TFIRST: return pad_slice_kernel<S_TFIRST>;
-    case S_TFIRST_LIN: return pad_slice_kernel<S_TFIRST_LIN>;
-    case S_JFIRST: return pad_slice_kernel<S_JFIRST>;
+    case S_TFIRST: return pad_slice_kernel<S_TFIRST, NT>;
+    case S_TFIRST_LIN: return pad_slice_kernel<S_TFIRST_LIN, NT>;
+    case S_JFIRST: return pad_slice_kernel<S_JFIRST, NT>;
     default: return nullptr;
   }
 }
-inline pad_line_fn pad_line_variant(int mode) {
+template <int NT> inline pad_line_fn pad_line_variant_n(int mode) {
   switch (mode) {
-    case L_MID: return pad_line_kernel<L_MID>;
-    case L_TLAST: return pad_line_kernel<L_TLAST>;
-    case L_TLAST_LIN: return pad_line_kernel<L_TLAST_LIN>;
-    case L_JLAST: return pad_line_kernel<L_JLAST>;
+    case L_MID: return pad_line_kernel<L_MID, NT>;
+    case L_TLAST: return pad_line_kernel<L_TLAST, NT>;
+    case L_TLAST_LIN: return pad_line_kernel<L_TLAST_LIN, NT>;
+    case L_JLAST: return pad_line_kernel<L_JLAST, NT>;
     default: return nullptr;
   }
+}
+inline pad_slice_fn pad_slice_variant(int nt, int mode) {
+  return nt == 16 ? pad_slice_variant_n<16>(mode) : (nt == 24 ? pad_slice_variant_n<24>(mode) : (nt == 32 ? pad_slice_variant_n<32>(mode) : nullptr));
+}
+inline pad_line_fn pad_line_variant(int nt, int mode) {
+  return nt == 16 ? pad_line_variant_n<16>(mode) : (nt == 24 ? pad_line_variant_n<24>(mode) : (nt == 32 ? pad_line_variant_n<32>(mode) : nullptr));
 }
 #endif
+inline int pad_slice_g(int nt) { return nt == 16 ? PadSliceGeo<16>::G : (nt == 24 ? PadSliceGeo<24>::G : PadSliceGeo<32>::G); }
+inline int pad_line_block(int nt) { return nt <= 24 ? 256 : 512; }
+inline size_t pad_line_lds(int nt) { return (size_t)nt * nt * LINE_R * 8; }
 
 }  // namespace sdfs

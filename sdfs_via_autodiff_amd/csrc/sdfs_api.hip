@@ -45,6 +45,8 @@ struct AxisInfo {
   const double* Qt = nullptr;  // its transpose, for unconditional tensors only (the vector-Jacobian product)
   const double* Qp = nullptr;  // unconditional, n <= 16: the matrix and its transpose zero-padded to 16 x 16
   const double* Qtp = nullptr; // (small-grid pair plan)
+  const double* Qpad[3] = {nullptr, nullptr, nullptr};   // unconditional: zero-padded to 16 / 24 / 32 squared where n fits (padded pair plan)
+  const double* Qtpad[3] = {nullptr, nullptr, nullptr};
   int qs[MAXD] = {0, 0, 0, 0, 0, 0};  // matrix-index stride per conditioning axis
   long long qcount = 0;        // number of n x n matrices in Q
   int a3s = 0;                 // index stride of this axis in the a3 table (when it is kept as a table)
@@ -87,7 +89,8 @@ struct FastPass {
   int r = 1;                   // its run length
   int wpt = 1;                 // ... and waves per tile
   SmallDesc sm;
-  bool pad = false;            // padded form: run-time extents <= 16 on 16 x 16 tiles, real strides (pad_kernels.hpp)
+  bool pad = false;            // padded form: run-time extents <= nt on nt x nt tiles (16 / 24 / 32), real strides (pad_kernels.hpp)
+  int nt = 16;
   PadDesc pd;
   double q_bytes = 0, flops = 0;
   std::string label;
@@ -113,7 +116,8 @@ struct Knobs {
   int small_plan = 1;          // SDFS_SMALL_PLAN: 0 = never use the small-grid pair plan
   int small_r = 0;             // SDFS_SMALL_R: force the run length of its line passes (1 or 4)
   int small_wpt = 0;           // SDFS_SMALL_WPT: force its waves per tile (1 or 4)
-  int pad_plan = 1;            // SDFS_PAD_PLAN: 0 = 6-D grids with extents <= 16 beyond the small-grid plan's size keep the generic tiles
+  int pad_plan = 1;            // SDFS_PAD_PLAN: 0 = 6-D grids with extents <= 16 beyond the small-grid plan's size keep the generic tiles;
+                               // 2 = the padded plan also for extents up to 32 (24- / 32-wide tiles) and 4-D grids (measured: no gain)
   int small_xcd = 1;           // SDFS_SMALL_XCD: 0 = its strided passes launch tile b on workgroup b (no XCD-aware order)
   int no_bicg_merge = 0;       // SDFS_NO_BICG_MERGE: 1 = BiCGSTAB keeps its finishing kernels as launches of their own on small grids too
   int and_host = 0;            // SDFS_AND_HOST: 1 = Anderson with the Gram solve on the host (one synchronisation per iteration)
@@ -990,14 +994,22 @@ int build_small_plan(sdfs_handle* h) {
   return 0;
 }
 
-// 6-D grids between the plans (pad_kernels.hpp): every extent <= 16, unconditional tensors, more points than the
-// latency-tuned small-grid kernels are good for (10^6 ... 15^6, ragged shapes): the pair plan on padded 16 x 16 tiles.
+// Grids between the plans (pad_kernels.hpp): unconditional tensors, every extent <= 32, neither the compile-time pair
+// kernels' shapes nor the latency-tuned small-grid kernels' sizes (10^6 ... 15^6, 17^6 ... 19^6, ragged shapes): the
+// pair plan on padded 16 / 24 / 32-wide tiles, chosen per pass.
 int build_pad_plan(sdfs_handle* h) {
   const int D = h->ndim;
-  if (h->fast.ok || h->knobs.plan == 1 || h->knobs.pad_plan == 0 || h->sharded || h->cont || h->dense || D != 6 || h->a3 == nullptr) return 0;
+  if (h->fast.ok || h->knobs.plan == 1 || h->knobs.pad_plan == 0 || h->sharded || h->cont || h->dense || (D != 4 && D != 6) || h->a3 == nullptr) return 0;
   if (h->N >= (1LL << 31)) return 0;
+  // Default: 6-D, every extent <= 16 (16-wide tiles, three workgroups per CU).  The 24- and 32-wide tiles and 4-D grids
+  // are built and tested behind SDFS_PAD_PLAN=2 but do not pay as one tile per workgroup (72 / 128 KB of LDS leave two /
+  // one workgroups per CU: 17^6 759 against 750 us per SA iteration on the generic tiles, 18^6 989 against 830, 20^4 32
+  // against 26; 32^4 49 against 56 -- profiles/round3_ab_small_mid_grids.txt).
+  const bool wide = h->knobs.pad_plan >= 2;
+  if (!wide && D != 6) return 0;
+  const int max_ext = wide ? 32 : 16;
   for (int a = 0; a < D; ++a) {
-    if (h->ax[a].qcount != 1 || h->shape[a] > 16 || !h->ax[a].Qp || !h->ax[a].Qtp) return 0;
+    if (h->ax[a].qcount != 1 || h->shape[a] > max_ext || !h->ax[a].Qpad[2] || !h->ax[a].Qtpad[2]) return 0;
     for (int c = 0; c < D; ++c) if (h->ax[a].qs[c] != 0) return 0;
     if (h->ax[a].a3s < 0 || h->ax[a].a3s >= (1 << 24)) return 0;
   }
@@ -1014,10 +1026,13 @@ int build_pad_plan(sdfs_handle* h) {
   for (size_t i = 0; i < pairs.size(); ++i) {
     const int a = pairs[i];
     FastPass P;
-    P.pad = true; P.line = i > 0; P.n = 16; P.ax0 = a; P.ax1 = a + 1;
+    P.pad = true; P.line = i > 0; P.ax0 = a; P.ax1 = a + 1;
     memset(&P.sd, 0, sizeof P.sd); memset(&P.ld, 0, sizeof P.ld); memset(&P.sm, 0, sizeof P.sm); memset(&P.pd, 0, sizeof P.pd);
     PadDesc& S = P.pd;
     S.nx = h->shape[a]; S.ny = h->shape[a + 1];
+    const int nmax = std::max(S.nx, S.ny);
+    const int cls = nmax <= 16 ? 0 : (nmax <= 24 ? 1 : 2);
+    P.nt = cls == 0 ? 16 : (cls == 1 ? 24 : 32); P.n = P.nt;
     S.mxy = (unsigned)(((1u << 20) + S.nx * S.ny - 1) / (S.nx * S.ny));
     S.my = (unsigned)(((1u << 20) + S.ny - 1) / S.ny);
     const long long lrest = stride[a + 1];
@@ -1027,12 +1042,15 @@ int build_pad_plan(sdfs_handle* h) {
     S.ntiles = nouter * S.nchunks;
     S.nslices = nouter;                      // (slice form: lrest = 1)
     if (S.ntiles >= (1LL << 31)) return 0;
-    S.Qx = h->ax[a].Qp; S.Qy = h->ax[a + 1].Qp;
+    S.Qx = h->ax[a].Qpad[cls]; S.Qy = h->ax[a + 1].Qpad[cls];
     S.theta = h->theta; S.inv_theta = 1.0 / h->theta; S.beta = h->beta;
     S.a3x = h->ax[a].a3s; S.a3y = h->ax[a + 1].a3s;
-    P.q_bytes = 2 * 8.0 * 256; P.flops = 2.0 * (double)h->N * (S.nx + S.ny);
+    P.q_bytes = 2 * 8.0 * P.nt * P.nt; P.flops = 2.0 * (double)h->N * (S.nx + S.ny);
     P.label = std::string(i == 0 ? "slices[" : "lines[") + h->ax[a].name + "," + h->ax[a + 1].name + "|" +
-              std::to_string(S.nx) + "x" + std::to_string(S.ny) + " on 16x16]";
+              std::to_string(S.nx) + "x" + std::to_string(S.ny) + " on " + std::to_string(P.nt) + "x" + std::to_string(P.nt) + "]";
+    if (P.line && pad_line_lds(P.nt) > 64 * 1024)
+      for (int lm : {L_MID, L_TLAST, L_TLAST_LIN, L_JLAST})
+        hipFuncSetAttribute((const void*)pad_line_variant(P.nt, lm), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad_line_lds(P.nt));
     if (i + 1 == pairs.size()) {
       // a3 index tables of the last pass (as build_small_plan)
       std::vector<int> outv((size_t)nouter, 0), restv((size_t)lrest, 0);
@@ -1053,8 +1071,9 @@ int build_pad_plan(sdfs_handle* h) {
     }
     passes.push_back(P);
   }
-  // enough tiles to fill the chip, else the generic kernel's finer tiles do better
-  if (passes[0].pd.nslices < 8LL * h->num_cus) return 0;
+  // enough tiles to fill the chip, else the generic kernel's finer tiles do better (4-D grids never have them: both
+  // ways are latency-bound there, and this one has fewer launches)
+  if (D == 6 && passes[0].pd.nslices < 8LL * h->num_cus) return 0;
   h->fast.passes = passes;
   h->fast.f32_ok = false;
   h->fast.small = false;
@@ -1109,7 +1128,8 @@ int run_fast_plan(sdfs_handle* h, int mode, const double* in, double* out, const
     if (P.pad) {
       PadDesc d = P.pd;
       d.minus_identity = minus_identity;
-      if (vjp) { d.Qx = h->ax[P.ax0].Qtp; d.Qy = h->ax[P.ax1].Qtp; }
+      const int cls = P.nt == 16 ? 0 : (P.nt == 24 ? 1 : 2);
+      if (vjp) { d.Qx = h->ax[P.ax0].Qtpad[cls]; d.Qy = h->ax[P.ax1].Qtpad[cls]; }
       int cid = -1;
       if (!P.line) {
         SliceIO io;
@@ -1120,9 +1140,9 @@ int run_fast_plan(sdfs_handle* h, int mode, const double* in, double* out, const
         if (mode == MODE_T_LIN) { sm = S_TFIRST_LIN; io.aux_out = h->c1; bytes += n8; }
         else if (mode == MODE_JVP) { sm = S_JFIRST; io.aux_in = vjp ? h->c2 : h->c1; bytes += n8; }
         if (h->profiling) { char nm[48]; snprintf(nm, sizeof nm, "%s:%s", tag, P.label.c_str()); cid = counter_id(h, nm, bytes, P.flops); }
-        const long long ntile = (d.nslices + PAD_G - 1) / PAD_G;
+        const long long ntile = (d.nslices + pad_slice_g(P.nt) - 1) / pad_slice_g(P.nt);
         ProfScope ps(h, cid);
-        hipLaunchKernelGGL(pad_slice_variant(sm), dim3((unsigned)((ntile + 3) / 4)), dim3(256), 0, h->stream, d, io);
+        hipLaunchKernelGGL(pad_slice_variant(P.nt, sm), dim3((unsigned)((ntile + 3) / 4)), dim3(256), 0, h->stream, d, io);
       } else {
         LineIO io;
         memset(&io, 0, sizeof io);
@@ -1135,7 +1155,7 @@ int run_fast_plan(sdfs_handle* h, int mode, const double* in, double* out, const
         }
         if (h->profiling) { char nm[48]; snprintf(nm, sizeof nm, "%s:%s", tag, P.label.c_str()); cid = counter_id(h, nm, bytes, P.flops); }
         ProfScope ps(h, cid);
-        hipLaunchKernelGGL(pad_line_variant(lm), dim3((unsigned)d.ntiles), dim3(256), 0, h->stream, d, io);
+        hipLaunchKernelGGL(pad_line_variant(P.nt, lm), dim3((unsigned)d.ntiles), dim3(pad_line_block(P.nt)), pad_line_lds(P.nt), h->stream, d, io);
       }
     } else if (P.small) {
       SmallIO io;
@@ -2323,6 +2343,16 @@ int create_common(int model, int ndim, const int64_t* shapes, const double* para
       if ((rc = upload(h, &dp, qp.data(), 256)) || (rc = upload(h, &dtp, qtp.data(), 256))) return bail(rc);
       h->ax[a].Qp = dp; h->ax[a].Qtp = dtp;
     }
+    for (int c = 0; c < 3; ++c) {
+      const int nt = c == 0 ? 16 : (c == 1 ? 24 : 32);
+      if (n > nt) continue;
+      if (c == 0) { h->ax[a].Qpad[0] = h->ax[a].Qp; h->ax[a].Qtpad[0] = h->ax[a].Qtp; continue; }
+      std::vector<double> qp((size_t)nt * nt, 0.0), qtp((size_t)nt * nt, 0.0);
+      for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) { qp[(size_t)i * nt + j] = q[(size_t)i * n + j]; qtp[(size_t)j * nt + i] = q[(size_t)i * n + j]; }
+      double *dp = nullptr, *dtp = nullptr;
+      if ((rc = upload(h, &dp, qp.data(), qp.size())) || (rc = upload(h, &dtp, qtp.data(), qtp.size()))) return bail(rc);
+      h->ax[a].Qpad[c] = dp; h->ax[a].Qtpad[c] = dtp;
+    }
   }
   // dynamic LDS above 64 KB has to be allowed per kernel variant (and per device)
   static unsigned long long attr_done = 0;
@@ -3002,7 +3032,8 @@ int sdfs_describe_plan(const sdfs_handle* h, char* buf, int64_t cap) {
       if (P.pad) {
         snprintf(line, sizeof line, "padded pair plan pass %zu: %s %s\n", i, P.label.c_str(),
                  P.line ? (std::string("tiles ") + std::to_string(P.pd.ntiles) + " (rows of 16 positions, real strides)").c_str()
-                        : (std::string("wave tiles ") + std::to_string((P.pd.nslices + PAD_G - 1) / PAD_G) + " of 4 slices").c_str());
+                        : (std::string("wave tiles ") + std::to_string((P.pd.nslices + pad_slice_g(P.nt) - 1) / pad_slice_g(P.nt)) + " of " +
+                           std::to_string(pad_slice_g(P.nt)) + " slice(s)").c_str());
       } else if (P.small) {
         snprintf(line, sizeof line, "small-grid plan pass %zu: %s %d wave%s per tile, run %d, tiles %lld, workgroups %u\n", i,
                  P.label.c_str(), P.wpt, P.wpt == 1 ? "" : "s", P.r, P.sm.ntiles, small_grid(P.sm, P.wpt));

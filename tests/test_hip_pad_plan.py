@@ -1,8 +1,9 @@
 """
-GPU parity tests of the padded pair plan (csrc/pad_kernels.hpp): 6-D grids with every extent <= 16 and more points than
-the small-grid plan takes -- 10^6 ... 15^6 and ragged shapes -- run the pair plan's three passes on 16 x 16 tiles with
-run-time extents and the grid's real strides.  Against the C oracle (oracle/c, a restatement of
-code/gcy/discrete/gcy_wc_ratio.py:134-238) on the same inputs: T with its residual, the linearising T + J.v, the
+GPU parity tests of the padded pair plan (csrc/pad_kernels.hpp): grids between the plans -- every extent <= 32, neither
+the compile-time pair kernels' shapes nor the small-grid plan's sizes (10^6 ... 15^6, 17^6, ragged shapes, 4-D grids
+with extents above 16) -- run the pair plan's passes on 16 / 24 / 32-wide tiles with run-time extents and the grid's
+real strides.  Against the C oracle (oracle/c, a restatement of
+code/gcy/discrete/gcy_wc_ratio.py:134-238 and code/ssy/discrete/ssy_wc_ratio.py:82-151) on the same inputs: T with its residual, the linearising T + J.v, the
 adjoint identity for J^T.v, the device SA loop, Newton-Krylov; and against the generic tiles (SDFS_PAD_PLAN=0), which
 these grids ran on before.
 """
@@ -13,7 +14,9 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
-SHAPES = [(10,) * 6, (12, 11, 9, 13, 10, 7), (15,) * 6, (16, 15, 14, 13, 12, 11), (9, 16, 5, 16, 16, 15), (13, 13, 16, 16, 3, 4)]
+SHAPES = [(10,) * 6, (12, 11, 9, 13, 10, 7), (15,) * 6, (16, 15, 14, 13, 12, 11), (9, 16, 5, 16, 16, 15), (13, 13, 16, 16, 3, 4),
+          # 24- and 32-wide tiles, mixed per pass; 4-D grids beyond the small-grid plan
+          (17,) * 6, (25, 19, 9, 9, 12, 7), (32, 32, 5, 5, 6, 24), (3, 30, 22, 21, 17, 18), (20,) * 4, (25, 18, 32, 7), (32,) * 4]
 
 
 @pytest.fixture(scope="module")
@@ -23,12 +26,16 @@ def S():
 
 
 def build(S, shapes, pad=True):
-    g = S.GCY()
-    arr = S.discretize_gcy(g, shapes)
+    model = "gcy" if len(shapes) == 6 else "ssy"
+    g = S.GCY() if model == "gcy" else S.SSY()
+    arr = (S.discretize_gcy if model == "gcy" else S.discretize_ssy)(g, shapes)
     old = os.environ.get("SDFS_PAD_PLAN")
-    os.environ["SDFS_PAD_PLAN"] = "1" if pad else "0"
+    # (extents above 16 and 4-D grids: the 24- / 32-wide tiles sit behind SDFS_PAD_PLAN=2 -- correct, but no faster than
+    # the generic tiles as one tile per workgroup, so not the default)
+    wide = max(shapes) > 16 or len(shapes) == 4
+    os.environ["SDFS_PAD_PLAN"] = ("2" if wide else "1") if pad else "0"
     try:
-        T = S.KoopmansOperator("gcy", shapes, g.params, arr)
+        T = S.KoopmansOperator(model, shapes, g.params, arr)
     finally:
         if old is None:
             del os.environ["SDFS_PAD_PLAN"]
@@ -41,8 +48,8 @@ def build(S, shapes, pad=True):
 def test_padded_pair_plan_vs_c_oracle(S, shapes):
     from oracle.c_oracle import COperator
     T, params, arr = build(S, shapes)
-    assert T.describe_plan().count("padded pair plan pass") == 3, T.describe_plan()
-    oc = COperator("gcy", shapes, params, arr)
+    assert T.describe_plan().count("padded pair plan pass") == len(shapes) // 2, T.describe_plan()
+    oc = COperator("gcy" if len(shapes) == 6 else "ssy", shapes, params, arr)
     rng = np.random.default_rng(sum(shapes))
     w = 300 + 600 * rng.random(shapes)
     v = rng.standard_normal(shapes)
@@ -69,7 +76,7 @@ def test_padded_pair_plan_vs_c_oracle(S, shapes):
     T.close()
 
 
-@pytest.mark.parametrize("shapes", [(10,) * 6, (12, 11, 9, 13, 10, 7)])
+@pytest.mark.parametrize("shapes", [(10,) * 6, (12, 11, 9, 13, 10, 7), (20, 17, 9, 9, 6, 5), (20,) * 4])
 def test_padded_pair_plan_solvers_match_generic_tiles(S, shapes):
     """Newton-Krylov (fused dots out of the last J.v pass), Anderson and SA to a tolerance: the same counts and fixed
     point as on the generic tiles."""
@@ -101,3 +108,8 @@ def test_padded_plan_is_not_taken_where_other_plans_are(S):
         T, _, _ = build(S, shapes)
         assert "padded pair plan" not in T.describe_plan()
         T.close()
+    # by default neither for extents above 16 nor for 4-D grids
+    g = S.GCY(); shapes = (17, 17, 9, 9, 12, 7)
+    T = S.KoopmansOperator("gcy", shapes, g.params, S.discretize_gcy(g, shapes))
+    assert "padded pair plan" not in T.describe_plan()
+    T.close()

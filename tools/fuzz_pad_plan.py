@@ -1,4 +1,4 @@
-"""Fuzz of the padded pair plan (csrc/pad_kernels.hpp): random 6-D shapes with extents 2..16 and 4e5 < N <= FUZZ_MAX
+"""Fuzz of the padded pair plan (csrc/pad_kernels.hpp): random 6-D shapes with extents 2..16 / 2..32 (alternating) and 4e5 < N <= FUZZ_MAX
 points (default 3e6), GCY calibration, against the C oracle (oracle/c, test infrastructure): T with its residual, J.v,
 the adjoint identity for J^T.v and three iterations of the device SA loop.  Exit code 1 beyond 1e-11 relative.
     python tools/fuzz_pad_plan.py > profiles/round3_fuzz_pad_plan.txt"""
@@ -8,6 +8,7 @@ import sys
 import numpy as np
 
 sys.path.insert(0, ".")
+os.environ.setdefault("SDFS_PAD_PLAN", "2")          # also the 24- / 32-wide tiles (not the default: no faster than the generic tiles)
 import sdfs_via_autodiff_amd as S  # noqa: E402
 from oracle.c_oracle import COperator  # noqa: E402
 
@@ -19,7 +20,7 @@ fixed = [(16, 16, 16, 16, 3, 3), (3, 3, 16, 16, 16, 16), (16, 3, 16, 3, 16, 16),
 tries = 0
 while done < int(os.environ.get("FUZZ_N", "24")) and tries < 100000:
     tries += 1
-    shapes = fixed.pop(0) if fixed else tuple(int(x) for x in rng.integers(2, 17, 6))
+    shapes = fixed.pop(0) if fixed else tuple(int(x) for x in rng.integers(2, 33 if done % 2 else 17, 6))
     n = int(np.prod(shapes))
     if not (4e5 < n <= MAXP):
         continue
