@@ -41,12 +41,13 @@ struct PadDesc {
 
 // slice form: G slices per wave tile, LDS row stride NT + 2 (conflict-free columns, see SliceGeo)
 template <int NT> struct PadSliceGeo {
-  static constexpr int G = NT == 16 ? 4 : (NT == 24 ? 2 : 1);      // (static LDS of the four wave tiles stays below 64 KB)
+  static constexpr int G = NT == 16 ? 4 : (NT == 20 ? 4 : (NT == 24 ? 2 : 1));      // (static LDS of the four wave tiles stays below 64 KB)
   static constexpr int RS = NT + 2;
   static constexpr int LT = G * NT * RS;            // doubles of LDS per wave tile
-  static constexpr int EPL = G * NT * NT / 64;      // elements per lane of a full tile
+  static constexpr int EPL = 2 * ((G * NT * NT + 127) / 128);      // elements per lane of a full tile, rounded up to even (the power runs on pairs)
   static constexpr int OCC = NT == 16 ? 3 : 2;      // workgroups per CU the register budget is set for
-  static_assert((G * NT) % 16 == 0 && (G * NT * NT) % 64 == 0, "whole column tiles and lane loops");
+  static_assert(EPL % 2 == 0, "the power runs on pairs");
+  static_assert((G * NT) % 16 == 0, "whole column tiles");
 };
 
 template <int MODE, int NT>
@@ -143,23 +144,29 @@ pad_slice_kernel(const PadDesc P, const SliceIO io) {
     if (lane + 64 * k < nval) io.out[gbase + lane + 64 * k] = wl[lo[k]];
 }
 
-// Line form.  Unit u = tid + B k is the double2 c2 = tid & 7 of row u >> 3 = (x, y) = (row / NT, row % NT); a thread keeps
-// its two positions.  LDS: NT * NT rows of 16 doubles (dynamic: 32 / 72 / 128 KB).
-template <int NT> struct PadLineGeo {
+// Line form.  A tile is all (x, y) rows of R consecutive positions behind the pair (R = 16: a 128-byte line per row;
+// R = 8, the wide tiles: 64-byte rows hold 4.7 of the 5.4 TB/s of whole lines as a memory skeleton -- tile_copy_probe,
+// round 3 -- and halve the LDS of a tile: 37 / 64 KB at 24 / 32 wide).  Unit u = tid + B k is double2 c2 = tid % (R / 2)
+// of row u / (R / 2) = (x, y) = (row / NT, row % NT); a thread keeps its two positions.  LDS: NT * NT rows of R doubles.
+template <int NT, int R> struct PadLineGeo {
   static constexpr int B = NT <= 24 ? 256 : 512;
   static constexpr int W = B / 64;
-  static constexpr int UNITS = NT * NT * LINE_R / 2;
-  static constexpr int EPT = UNITS / B;
-  static constexpr int LX = NT * LINE_R;
-  static constexpr int OCC = NT == 16 ? 3 : (NT == 24 ? 2 : 1);
-  static constexpr size_t LDS_BYTES = (size_t)NT * NT * LINE_R * 8;
-  static_assert(UNITS % B == 0 && NT % W == 0, "whole units per thread, column tiles split evenly over the waves");
+  static constexpr int UPR = R / 2;                              // double2 units per row
+  static constexpr int UNITS = NT * NT * UPR;
+  static constexpr int EPT = (UNITS + B - 1) / B;
+  static constexpr bool PARTIAL = UNITS % B != 0;
+  static constexpr int LX = NT * R;
+  static constexpr int NCT = NT * R / 16;                        // column tiles of either contraction
+  static constexpr int OCC = B == 512 ? 1 : ((size_t)NT * NT * R * 8 <= 40 * 1024 ? 3 : 2);      // (512 threads: 256 VGPRs, no spills in the last pass)
+  static_assert(R == 8 || R == 16, "row lengths");
+  static_assert((NT * R) % 16 == 0, "whole column tiles");
 };
 
-template <int MODE, int NT>
-__global__ void __launch_bounds__(PadLineGeo<NT>::B, PadLineGeo<NT>::OCC * PadLineGeo<NT>::B / 256)
+template <int MODE, int NT, int R>
+__global__ void __launch_bounds__((PadLineGeo<NT, R>::B), (PadLineGeo<NT, R>::OCC * PadLineGeo<NT, R>::B / 256))
 pad_line_kernel(const PadDesc P, const LineIO io) {
-  using Geo = PadLineGeo<NT>;
+  using Geo = PadLineGeo<NT, R>;
+  constexpr int UPR = Geo::UPR;
   constexpr bool CES = MODE == L_TLAST || MODE == L_TLAST_LIN;
   constexpr bool LINE = MODE == L_TLAST_LIN;
   constexpr bool MULE = MODE == L_JLAST;
@@ -175,16 +182,16 @@ pad_line_kernel(const PadDesc P, const LineIO io) {
   const unsigned t = (unsigned)xcd_remap((long long)blockIdx.x, P.ntiles);
   const unsigned o = t / (unsigned)P.nchunks;
   const int chunk = (int)(t - o * (unsigned)P.nchunks);
-  const int c2 = tid & 7;
-  const long long pos = (long long)chunk * LINE_R + 2 * c2;
+  const int c2 = tid & (UPR - 1);
+  const long long pos = (long long)chunk * R + 2 * c2;
   const bool pk0 = pos < P.lrest, pk1 = pos + 1 < P.lrest;
-  const long long tbase = (long long)o * (P.nx * P.ny) * P.lrest + (long long)chunk * LINE_R + 2 * c2;
+  const long long tbase = (long long)o * (P.nx * P.ny) * P.lrest + (long long)chunk * R + 2 * c2;
   const bool need_old = CES ? io.resid != nullptr : (MULE && P.minus_identity);
   // unit k of this thread: row -> (x, y), validity, element offset against tbase
   auto unit_of = [&](const int k, int& x, int& y, bool& rok, long long& off) {
-    const int row = (tid + B * k) >> 3;
+    const int row = (tid + B * k) / UPR;
     x = row / NT; y = row - x * NT;
-    rok = x < P.nx && y < P.ny;
+    rok = x < P.nx && y < P.ny && (!Geo::PARTIAL || tid + B * k < Geo::UNITS);
     off = ((long long)x * P.ny + y) * P.lrest;
   };
   // ---- loads: the tile and the side stream that crosses the contractions -----------------------------------------
@@ -202,25 +209,29 @@ pad_line_kernel(const PadDesc P, const LineIO io) {
         s1[(CES || MULE) ? k : 0] = make_double2((pk0 && rok) ? oldb[off] : 0.0, (pk1 && rok) ? oldb[off + 1] : 0.0);
     }
 #pragma unroll
-    for (int k = 0; k < EPT; ++k) *reinterpret_cast<double2*>(lds + 2 * (tid + B * k)) = v[k];     // (every slot has its owner: no zero fill)
+    for (int k = 0; k < EPT; ++k)
+      if (!Geo::PARTIAL || tid + B * k < Geo::UNITS) *reinterpret_cast<double2*>(lds + 2 * (tid + B * k)) = v[k];     // (every slot has its owner: no zero fill)
   }
   {
     QFrag<NT> q;
     q.load(P.Qx, lane);
     __syncthreads();
-    // contraction over X: column = (y, r) = LDS offset, row stride NT * 16
+    // contraction over X: column = (y, r) = LDS offset y R + r, row stride NT R; column tile j = offsets 16 j ...
     {
       double* const p0 = lds + li + lk * Geo::LX;
 #pragma unroll
-      for (int j = 0; j < NT / Geo::W; ++j) ctile<NT, Geo::LX>(p0 + (wave + j * Geo::W) * 16, q);
+      for (int j = 0; j < (Geo::NCT + Geo::W - 1) / Geo::W; ++j)
+        if (Geo::NCT % Geo::W == 0 || wave + j * Geo::W < Geo::NCT) ctile<NT, Geo::LX>(p0 + (wave + j * Geo::W) * 16, q);
     }
     q.load(P.Qy, lane);
     __syncthreads();
-    // contraction over Y: column = (x, r) at x * LX + r, row stride 16
+    // contraction over Y: column = (x, r) at x LX + r, row stride R; a column tile is 16 / R values of x
     {
-      double* const p0 = lds + li + lk * LINE_R;
+      constexpr int XPT = 16 / R;
+      double* const p0 = lds + (li / R) * Geo::LX + (li % R) + lk * R;
 #pragma unroll
-      for (int j = 0; j < NT / Geo::W; ++j) ctile<NT, LINE_R>(p0 + (wave + j * Geo::W) * Geo::LX, q);
+      for (int j = 0; j < (Geo::NCT + Geo::W - 1) / Geo::W; ++j)
+        if (Geo::NCT % Geo::W == 0 || wave + j * Geo::W < Geo::NCT) ctile<NT, R>(p0 + (wave + j * Geo::W) * XPT * Geo::LX, q);
     }
     __syncthreads();
   }
@@ -247,7 +258,7 @@ pad_line_kernel(const PadDesc P, const LineIO io) {
       int x, y; bool rok; long long off;
       unit_of(k, x, y, rok, off);
       const bool a = pk0 && rok, b = pk1 && rok;
-      const double2 sv = *reinterpret_cast<const double2*>(lds + 2 * (tid + B * k));
+      const double2 sv = *reinterpret_cast<const double2*>(lds + 2 * ((!Geo::PARTIAL || tid + B * k < Geo::UNITS) ? tid + B * k : tid));
       // Tw = 1 + beta (a3 S)^(1/theta), c2 = beta u / S, |Tw - w|; every lane runs the power (its table gathers need the
       // whole wave), masked lanes feed it 1
       const double ks[2] = {a ? s2[k].x * sv.x : 1.0, b ? s2[k].y * sv.y : 1.0};
@@ -281,7 +292,7 @@ pad_line_kernel(const PadDesc P, const LineIO io) {
       int x, y; bool rok; long long off;
       unit_of(k, x, y, rok, off);
       const bool a = pk0 && rok, b = pk1 && rok;
-      double2 y2 = *reinterpret_cast<const double2*>(lds + 2 * (tid + B * k));
+      double2 y2 = *reinterpret_cast<const double2*>(lds + 2 * ((!Geo::PARTIAL || tid + B * k < Geo::UNITS) ? tid + B * k : tid));
       if (MULE) {
         y2.x *= s2[MULE ? k : 0].x; y2.y *= s2[MULE ? k : 0].y;
         if (P.minus_identity) {
@@ -331,24 +342,26 @@ template <int NT> inline pad_slice_fn pad_slice_variant_n(int mode) {
     default: return nullptr;
   }
 }
-template <int NT> inline pad_line_fn pad_line_variant_n(int mode) {
+template <int NT, int R> inline pad_line_fn pad_line_variant_n(int mode) {
   switch (mode) {
-    case L_MID: return pad_line_kernel<L_MID, NT>;
-    case L_TLAST: return pad_line_kernel<L_TLAST, NT>;
-    case L_TLAST_LIN: return pad_line_kernel<L_TLAST_LIN, NT>;
-    case L_JLAST: return pad_line_kernel<L_JLAST, NT>;
+    case L_MID: return pad_line_kernel<L_MID, NT, R>;
+    case L_TLAST: return pad_line_kernel<L_TLAST, NT, R>;
+    case L_TLAST_LIN: return pad_line_kernel<L_TLAST_LIN, NT, R>;
+    case L_JLAST: return pad_line_kernel<L_JLAST, NT, R>;
     default: return nullptr;
   }
 }
 inline pad_slice_fn pad_slice_variant(int nt, int mode) {
-  return nt == 16 ? pad_slice_variant_n<16>(mode) : (nt == 24 ? pad_slice_variant_n<24>(mode) : (nt == 32 ? pad_slice_variant_n<32>(mode) : nullptr));
+  return nt == 16 ? pad_slice_variant_n<16>(mode) : (nt == 20 ? pad_slice_variant_n<20>(mode) : (nt == 24 ? pad_slice_variant_n<24>(mode) : (nt == 32 ? pad_slice_variant_n<32>(mode) : nullptr)));
 }
+// (rows of 16 doubles on the 16-wide tiles, of 8 on the wide ones)
 inline pad_line_fn pad_line_variant(int nt, int mode) {
-  return nt == 16 ? pad_line_variant_n<16>(mode) : (nt == 24 ? pad_line_variant_n<24>(mode) : (nt == 32 ? pad_line_variant_n<32>(mode) : nullptr));
+  return nt == 16 ? pad_line_variant_n<16, 16>(mode) : (nt == 20 ? pad_line_variant_n<20, 8>(mode) : (nt == 24 ? pad_line_variant_n<24, 8>(mode) : (nt == 32 ? pad_line_variant_n<32, 8>(mode) : nullptr)));
 }
 #endif
-inline int pad_slice_g(int nt) { return nt == 16 ? PadSliceGeo<16>::G : (nt == 24 ? PadSliceGeo<24>::G : PadSliceGeo<32>::G); }
+inline int pad_slice_g(int nt) { return nt == 16 ? PadSliceGeo<16>::G : (nt == 20 ? PadSliceGeo<20>::G : (nt == 24 ? PadSliceGeo<24>::G : PadSliceGeo<32>::G)); }
+inline int pad_line_r(int nt) { return nt == 16 ? 16 : 8; }
 inline int pad_line_block(int nt) { return nt <= 24 ? 256 : 512; }
-inline size_t pad_line_lds(int nt) { return (size_t)nt * nt * LINE_R * 8; }
+inline size_t pad_line_lds(int nt) { return (size_t)nt * nt * pad_line_r(nt) * 8; }
 
 }  // namespace sdfs

@@ -45,8 +45,8 @@ struct AxisInfo {
   const double* Qt = nullptr;  // its transpose, for unconditional tensors only (the vector-Jacobian product)
   const double* Qp = nullptr;  // unconditional, n <= 16: the matrix and its transpose zero-padded to 16 x 16
   const double* Qtp = nullptr; // (small-grid pair plan)
-  const double* Qpad[3] = {nullptr, nullptr, nullptr};   // unconditional: zero-padded to 16 / 24 / 32 squared where n fits (padded pair plan)
-  const double* Qtpad[3] = {nullptr, nullptr, nullptr};
+  const double* Qpad[4] = {nullptr, nullptr, nullptr, nullptr};   // unconditional: zero-padded to 16 / 20 / 24 / 32 squared where n fits (padded pair plan)
+  const double* Qtpad[4] = {nullptr, nullptr, nullptr, nullptr};
   int qs[MAXD] = {0, 0, 0, 0, 0, 0};  // matrix-index stride per conditioning axis
   long long qcount = 0;        // number of n x n matrices in Q
   int a3s = 0;                 // index stride of this axis in the a3 table (when it is kept as a table)
@@ -116,8 +116,8 @@ struct Knobs {
   int small_plan = 1;          // SDFS_SMALL_PLAN: 0 = never use the small-grid pair plan
   int small_r = 0;             // SDFS_SMALL_R: force the run length of its line passes (1 or 4)
   int small_wpt = 0;           // SDFS_SMALL_WPT: force its waves per tile (1 or 4)
-  int pad_plan = 1;            // SDFS_PAD_PLAN: 0 = 6-D grids with extents <= 16 beyond the small-grid plan's size keep the generic tiles;
-                               // 2 = the padded plan also for extents up to 32 (24- / 32-wide tiles) and 4-D grids (measured: no gain)
+  int pad_plan = 1;            // SDFS_PAD_PLAN: 0 = the grids between the plans keep the generic tiles; 2 = the padded plan also for
+                               // shapes that mix extents above and below 16 (measured: no gain)
   int small_xcd = 1;           // SDFS_SMALL_XCD: 0 = its strided passes launch tile b on workgroup b (no XCD-aware order)
   int no_bicg_merge = 0;       // SDFS_NO_BICG_MERGE: 1 = BiCGSTAB keeps its finishing kernels as launches of their own on small grids too
   int and_host = 0;            // SDFS_AND_HOST: 1 = Anderson with the Gram solve on the host (one synchronisation per iteration)
@@ -1001,15 +1001,18 @@ int build_pad_plan(sdfs_handle* h) {
   const int D = h->ndim;
   if (h->fast.ok || h->knobs.plan == 1 || h->knobs.pad_plan == 0 || h->sharded || h->cont || h->dense || (D != 4 && D != 6) || h->a3 == nullptr) return 0;
   if (h->N >= (1LL << 31)) return 0;
-  // Default: 6-D, every extent <= 16 (16-wide tiles, three workgroups per CU).  The 24- and 32-wide tiles and 4-D grids
-  // are built and tested behind SDFS_PAD_PLAN=2 but do not pay as one tile per workgroup (72 / 128 KB of LDS leave two /
-  // one workgroups per CU: 17^6 759 against 750 us per SA iteration on the generic tiles, 18^6 989 against 830, 20^4 32
-  // against 26; 32^4 49 against 56 -- profiles/round3_ab_small_mid_grids.txt).
-  const bool wide = h->knobs.pad_plan >= 2;
-  if (!wide && D != 6) return 0;
-  const int max_ext = wide ? 32 : 16;
+  // Default: 6-D grids with every extent <= 16 (16-wide tiles, rows of 16 doubles), and grids -- 4-D or 6-D -- with every
+  // extent in 17 ... 32 (20- / 24- / 32-wide tiles, rows of 8 doubles): 17^6 614 against 744 us per SA iteration on the
+  // generic tiles, 21^6 2202 against 5272, 20^4 / 25^4 / 32^4 23 / 25 / 39 against 26 / 30 / 56.  Shapes that mix wide pairs
+  // with small ones measured no gain (24x24x12x12x8x8: 169 against 156 us, 30x30x9x9x5x5: 115 against 102) and keep the
+  // generic tiles unless SDFS_PAD_PLAN=2 (profiles/round3_ab_small_mid_grids.txt).
+  int lo = 1 << 30, hi = 0;
+  for (int a = 0; a < D; ++a) { lo = std::min(lo, h->shape[a]); hi = std::max(hi, h->shape[a]); }
+  const bool all_small = hi <= 16, all_wide = lo >= 17 && hi <= 32;
+  if (!(h->knobs.pad_plan >= 2 || (D == 6 && all_small) || all_wide)) return 0;
+  const int max_ext = 32;
   for (int a = 0; a < D; ++a) {
-    if (h->ax[a].qcount != 1 || h->shape[a] > max_ext || !h->ax[a].Qpad[2] || !h->ax[a].Qtpad[2]) return 0;
+    if (h->ax[a].qcount != 1 || h->shape[a] > max_ext || !h->ax[a].Qpad[3] || !h->ax[a].Qtpad[3]) return 0;
     for (int c = 0; c < D; ++c) if (h->ax[a].qs[c] != 0) return 0;
     if (h->ax[a].a3s < 0 || h->ax[a].a3s >= (1 << 24)) return 0;
   }
@@ -1031,14 +1034,14 @@ int build_pad_plan(sdfs_handle* h) {
     PadDesc& S = P.pd;
     S.nx = h->shape[a]; S.ny = h->shape[a + 1];
     const int nmax = std::max(S.nx, S.ny);
-    const int cls = nmax <= 16 ? 0 : (nmax <= 24 ? 1 : 2);
-    P.nt = cls == 0 ? 16 : (cls == 1 ? 24 : 32); P.n = P.nt;
+    const int cls = nmax <= 16 ? 0 : (nmax <= 20 ? 1 : (nmax <= 24 ? 2 : 3));
+    P.nt = cls == 0 ? 16 : (cls == 1 ? 20 : (cls == 2 ? 24 : 32)); P.n = P.nt;
     S.mxy = (unsigned)(((1u << 20) + S.nx * S.ny - 1) / (S.nx * S.ny));
     S.my = (unsigned)(((1u << 20) + S.ny - 1) / S.ny);
     const long long lrest = stride[a + 1];
     const long long nouter = h->N / ((long long)S.nx * S.ny * lrest);
     S.lrest = lrest; S.nouter = nouter;
-    S.nchunks = (int)((lrest + LINE_R - 1) / LINE_R);
+    S.nchunks = (int)((lrest + pad_line_r(P.nt) - 1) / pad_line_r(P.nt));
     S.ntiles = nouter * S.nchunks;
     S.nslices = nouter;                      // (slice form: lrest = 1)
     if (S.ntiles >= (1LL << 31)) return 0;
@@ -1128,7 +1131,7 @@ int run_fast_plan(sdfs_handle* h, int mode, const double* in, double* out, const
     if (P.pad) {
       PadDesc d = P.pd;
       d.minus_identity = minus_identity;
-      const int cls = P.nt == 16 ? 0 : (P.nt == 24 ? 1 : 2);
+      const int cls = P.nt == 16 ? 0 : (P.nt == 20 ? 1 : (P.nt == 24 ? 2 : 3));
       if (vjp) { d.Qx = h->ax[P.ax0].Qtpad[cls]; d.Qy = h->ax[P.ax1].Qtpad[cls]; }
       int cid = -1;
       if (!P.line) {
@@ -2343,8 +2346,8 @@ int create_common(int model, int ndim, const int64_t* shapes, const double* para
       if ((rc = upload(h, &dp, qp.data(), 256)) || (rc = upload(h, &dtp, qtp.data(), 256))) return bail(rc);
       h->ax[a].Qp = dp; h->ax[a].Qtp = dtp;
     }
-    for (int c = 0; c < 3; ++c) {
-      const int nt = c == 0 ? 16 : (c == 1 ? 24 : 32);
+    for (int c = 0; c < 4; ++c) {
+      const int nt = c == 0 ? 16 : (c == 1 ? 20 : (c == 2 ? 24 : 32));
       if (n > nt) continue;
       if (c == 0) { h->ax[a].Qpad[0] = h->ax[a].Qp; h->ax[a].Qtpad[0] = h->ax[a].Qtp; continue; }
       std::vector<double> qp((size_t)nt * nt, 0.0), qtp((size_t)nt * nt, 0.0);

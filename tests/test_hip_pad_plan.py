@@ -30,9 +30,9 @@ def build(S, shapes, pad=True):
     g = S.GCY() if model == "gcy" else S.SSY()
     arr = (S.discretize_gcy if model == "gcy" else S.discretize_ssy)(g, shapes)
     old = os.environ.get("SDFS_PAD_PLAN")
-    # (extents above 16 and 4-D grids: the 24- / 32-wide tiles sit behind SDFS_PAD_PLAN=2 -- correct, but no faster than
-    # the generic tiles as one tile per workgroup, so not the default)
-    wide = max(shapes) > 16 or len(shapes) == 4
+    # (shapes that mix extents above and below 16 take the padded plan only under SDFS_PAD_PLAN=2 -- correct, measured
+    # no faster than the generic tiles; all-small 6-D and all-wide shapes take it by default)
+    wide = max(shapes) > 16 and min(shapes) <= 16
     os.environ["SDFS_PAD_PLAN"] = ("2" if wide else "1") if pad else "0"
     try:
         T = S.KoopmansOperator(model, shapes, g.params, arr)
@@ -108,8 +108,13 @@ def test_padded_plan_is_not_taken_where_other_plans_are(S):
         T, _, _ = build(S, shapes)
         assert "padded pair plan" not in T.describe_plan()
         T.close()
-    # by default neither for extents above 16 nor for 4-D grids
+    # by default not for shapes that mix extents above and below 16 ...
     g = S.GCY(); shapes = (17, 17, 9, 9, 12, 7)
     T = S.KoopmansOperator("gcy", shapes, g.params, S.discretize_gcy(g, shapes))
     assert "padded pair plan" not in T.describe_plan()
+    T.close()
+    # ... but for every extent in 17 .. 32, 4-D and 6-D (20- / 24- / 32-wide tiles)
+    m = S.SSY(); shapes = (20, 25, 18, 32)
+    T = S.KoopmansOperator("ssy", shapes, m.params, S.discretize_ssy(m, shapes))
+    assert T.describe_plan().count("padded pair plan pass") == 2
     T.close()

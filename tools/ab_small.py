@@ -19,7 +19,7 @@ VARIANTS = {
     # beyond 400 k points the planner leaves the small-grid kernels; SDFS_PLAN=pair keeps them wherever they are legal
     "small forced": {"SDFS_PLAN": "pair", "SDFS_PAD_PLAN": "0"},
     # 6-D grids beyond the small-grid plan's size: the padded pair plan (pad_kernels.hpp), the default there
-    "padded pair plan": {"SDFS_PAD_PLAN": "2"},      # (2: also extents up to 32 and 4-D grids, which the default leaves to the generic tiles)
+    "padded pair plan": {"SDFS_PAD_PLAN": "2"},      # (2: also shapes that mix extents above and below 16, which the default leaves to the generic tiles)
 }
 DEFAULT = ["5,5,5,5", "10,10,10,10", "15,15,15,15", "16,16,16,16", "6,6,6,6,6,6", "8,8,8,8,8,8", "10,10,10,10,10,10",
            "12,12,12,12,12,12", "14,14,14,14,14,14"]

@@ -8,7 +8,7 @@ import sys
 import numpy as np
 
 sys.path.insert(0, ".")
-os.environ.setdefault("SDFS_PAD_PLAN", "2")          # also the 24- / 32-wide tiles (not the default: no faster than the generic tiles)
+os.environ.setdefault("SDFS_PAD_PLAN", "2")          # also shapes that mix extents above and below 16 (not the default: no faster than the generic tiles)
 import sdfs_via_autodiff_amd as S  # noqa: E402
 from oracle.c_oracle import COperator  # noqa: E402
 

@@ -10,7 +10,7 @@ import sdfs_via_autodiff_amd as S  # noqa: E402
 
 
 def run(shapes, pad):
-    os.environ["SDFS_PAD_PLAN"] = "1" if pad else "0"
+    os.environ["SDFS_PAD_PLAN"] = "2" if pad else "0"
     g = S.GCY()
     arr = S.discretize_gcy(g, shapes)
     T = S.KoopmansOperator("gcy", shapes, g.params, arr)
