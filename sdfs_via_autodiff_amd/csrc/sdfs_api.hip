@@ -118,7 +118,7 @@ struct Knobs {
   int small_wpt = 0;           // SDFS_SMALL_WPT: force its waves per tile (1 or 4)
   int pad_plan = 1;            // SDFS_PAD_PLAN: 0 = the grids between the plans keep the generic tiles; 2 = the padded plan also for
                                // shapes that mix extents above and below 16 (measured: no gain)
-  int small_xcd = 1;           // SDFS_SMALL_XCD: 0 = its strided passes launch tile b on workgroup b (no XCD-aware order)
+  int small_xcd = 1;           // SDFS_SMALL_XCD (-DSDFS_DIAG builds only): 0 = its strided passes launch tile b on workgroup b (no XCD-aware order)
   int no_bicg_merge = 0;       // SDFS_NO_BICG_MERGE: 1 = BiCGSTAB keeps its finishing kernels as launches of their own on small grids too
   int and_host = 0;            // SDFS_AND_HOST: 1 = Anderson with the Gram solve on the host (one synchronisation per iteration)
   int and_fused = 1;           // SDFS_AND_FUSED: 0 = Anderson on the small-grid plan keeps push / step / update as launches of their own
@@ -274,6 +274,7 @@ Knobs read_knobs() {
   k.cont_no_tensor = env_int("SDFS_CONT_NO_TENSOR", 0);
   k.cont_lds_cap = env_int("SDFS_CONT_LDS_CAP", 4000);
   k.no_bicg_merge = env_int("SDFS_NO_BICG_MERGE", 0);
+  k.small_xcd = env_int("SDFS_SMALL_XCD", 1);
 #endif
   k.no_slice_merge = env_int("SDFS_NO_SLICE_MERGE", 0);
   k.pair_order = env_int("SDFS_PAIR_ORDER", 1);
@@ -284,7 +285,6 @@ Knobs read_knobs() {
   k.small_r = env_int("SDFS_SMALL_R", 0);
   k.sa_fused = env_int("SDFS_SA_FUSED", -1);
   k.small_wpt = env_int("SDFS_SMALL_WPT", 0);
-  k.small_xcd = env_int("SDFS_SMALL_XCD", 1);
   k.pad_plan = env_int("SDFS_PAD_PLAN", 1);
   k.and_host = env_int("SDFS_AND_HOST", 0);
   k.and_fused = env_int("SDFS_AND_FUSED", 1);
