@@ -8,6 +8,7 @@
 //     state into the OTHER of two state buffers, so that no wave reads what this launch writes.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <stddef.h>
 
 #include "wave_reduce.hpp"
 
@@ -34,6 +35,7 @@ struct AndStepLds {
   double row[AND_MAX_M];                              // in: row `pos` of the Gram matrix
   double Gs[AND_MAX_M * AND_MAX_M];
   double coef[AND_MAX_M];                             // out
+  double pre[8];                                      // PRE: mix_beta, err, it, rejected, no_mix_until, last_mixed, prev_pos, status of the state before
   double mix_beta;                                    // out (mode 2)
   int mix_mode;                                       // out
   int open;                                           // out: the loop goes on
@@ -192,16 +194,21 @@ __device__ __forceinline__ bool and_solve_fast(const double* __restrict__ Gs, in
 // 1 = regular (its error joins the trace), 2 = rejected.  nonfinite: whether the pass produced a non-finite residual,
 // as its push recorded it (fused form: the tiles of a pass that can only be rejected decide on that word alone), or
 // -1: read it off the norm.
-template <int DMAX, bool FAST = false>
+// PRE: the caller has already brought the state before the step into sh (Gs, coef, pre -- and_state_preload /
+// and_state_park around its Gram-row loads, so that the state travels with them instead of behind them).
+template <int DMAX, bool FAST = false, bool PRE = false>
 __device__ __forceinline__ void and_step_wave(AndStepLds& sh, int lane, int m, int pos, int rel, const AndState* Sin,
                                               AndState* Sout, bool writer, double* __restrict__ err_slot, int* __restrict__ kind_slot,
                                               const AndStepPar par, int nonfinite = -1) {
 #pragma clang fp contract(off)
   double* const Gs = sh.Gs;
-  for (int i = lane; i < m * m; i += 64) Gs[i] = Sin->G[i];
-  const double it = Sin->it, prev_pos_d = Sin->prev_pos, last_mixed = Sin->last_mixed, rejected = Sin->rejected,
-               no_mix_until = Sin->no_mix_until, status_in = Sin->status, beta_in = Sin->mix_beta;
-  if (lane < AND_MAX_M) sh.coef[lane] = Sin->coef[lane];
+  if (!PRE) {
+    for (int i = lane; i < m * m; i += 64) Gs[i] = Sin->G[i];
+    if (lane < AND_MAX_M) sh.coef[lane] = Sin->coef[lane];
+  }
+  const double it = PRE ? sh.pre[2] : Sin->it, prev_pos_d = PRE ? sh.pre[6] : Sin->prev_pos, last_mixed = PRE ? sh.pre[5] : Sin->last_mixed,
+               rejected = PRE ? sh.pre[3] : Sin->rejected, no_mix_until = PRE ? sh.pre[4] : Sin->no_mix_until,
+               status_in = PRE ? sh.pre[7] : Sin->status, beta_in = PRE ? sh.pre[0] : Sin->mix_beta;
   and_wsync();
   if (lane < m) { Gs[pos * m + lane] = sh.row[lane]; Gs[lane * m + pos] = sh.row[lane]; }
   and_wsync();
@@ -247,6 +254,25 @@ __device__ __forceinline__ void and_step_wave(AndStepLds& sh, int lane, int m, i
     }
   }
   and_wsync();
+}
+
+// The state before a step, requested by a 256-thread workgroup BEFORE its Gram-row loads and parked in sh behind them
+// (loads return in order: by then it has arrived; a wait in between would put the row loads a round trip later).
+struct AndPreload { double g, c, s; };
+__device__ __forceinline__ AndPreload and_state_preload(const AndState* __restrict__ Sin, int m) {
+  static_assert(offsetof(AndState, status) - offsetof(AndState, mix_beta) == 7 * sizeof(double), "eight consecutive doubles from mix_beta");
+  const int tid = threadIdx.x;
+  AndPreload p;
+  p.g = tid < m * m ? Sin->G[tid] : 0.0;                          // (m <= 16: at most 256 entries)
+  p.c = tid < AND_MAX_M ? Sin->coef[tid] : 0.0;
+  p.s = (tid >= 192 && tid < 200) ? (&Sin->mix_beta)[tid - 192] : 0.0;
+  return p;
+}
+__device__ __forceinline__ void and_state_park(AndStepLds& sh, const AndPreload& p, int m) {
+  const int tid = threadIdx.x;
+  if (tid < m * m) sh.Gs[tid] = p.g;
+  if (tid < AND_MAX_M) sh.coef[tid] = p.c;
+  if (tid >= 192 && tid < 200) sh.pre[tid - 192] = p.s;
 }
 
 // the loop had ended before this launch: carry the final state into the other buffer (one wave)

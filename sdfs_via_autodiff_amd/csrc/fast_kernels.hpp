@@ -994,11 +994,13 @@ __device__ __forceinline__ void small_tile_body(const SmallDesc& P, const SmallI
   auto and_step_site = [&](bool writer, int nonfinite) {
     AndStepLds& sh = *reinterpret_cast<AndStepLds*>(and_raw);
     SDFS_AND_STAMP(0);
+    const AndPreload pre = and_state_preload(an->Sin, an->m);
     and_row_sums16(an->partial, an->nb, an->m, -1, sh.row);
+    and_state_park(sh, pre, an->m);
     __syncthreads();
     SDFS_AND_STAMP(1);
     if (wave == 0)
-      and_step_wave<AND_FUSE_M + 1, true>(sh, lane, an->m, an->pos, an->rel, an->Sin, an->Sout, writer, an->err_slot, an->kind_slot, an->par, nonfinite);
+      and_step_wave<AND_FUSE_M + 1, true, true>(sh, lane, an->m, an->pos, an->rel, an->Sin, an->Sout, writer, an->err_slot, an->kind_slot, an->par, nonfinite);
     __syncthreads();
     SDFS_AND_STAMP(2);
     and_mode = __builtin_amdgcn_readfirstlane(sh.mix_mode);
@@ -1389,10 +1391,12 @@ small_and_finish(const AndArgs an, const double* __restrict__ fx, long long n) {
   }
   AndStepLds& sh = *reinterpret_cast<AndStepLds*>(and_raw);
   const int nonfinite = (int)(*an.flag != 0u);
+  const AndPreload pre = and_state_preload(an.Sin, an.m);
   and_row_sums16(an.partial, an.nb, an.m, -1, sh.row);
+  and_state_park(sh, pre, an.m);
   __syncthreads();
   if (wave == 0)
-    and_step_wave<AND_FUSE_M + 1, true>(sh, lane, an.m, an.pos, an.rel, an.Sin, an.Sout, blockIdx.x == 0, an.err_slot, an.kind_slot, an.par, nonfinite);
+    and_step_wave<AND_FUSE_M + 1, true, true>(sh, lane, an.m, an.pos, an.rel, an.Sin, an.Sout, blockIdx.x == 0, an.err_slot, an.kind_slot, an.par, nonfinite);
   __syncthreads();
   const int mode = sh.mix_mode, prev = sh.prev_pos;
   const double* px = an.h.X[0];
