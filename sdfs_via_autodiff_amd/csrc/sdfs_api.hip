@@ -3034,7 +3034,7 @@ int sdfs_describe_plan(const sdfs_handle* h, char* buf, int64_t cap) {
       int occ = -1;
       if (P.pad) {
         snprintf(line, sizeof line, "padded pair plan pass %zu: %s %s\n", i, P.label.c_str(),
-                 P.line ? (std::string("tiles ") + std::to_string(P.pd.ntiles) + " (rows of 16 positions, real strides)").c_str()
+                 P.line ? (std::string("tiles ") + std::to_string(P.pd.ntiles) + " (rows of " + std::to_string(pad_line_r(P.nt)) + " positions, real strides)").c_str()
                         : (std::string("wave tiles ") + std::to_string((P.pd.nslices + pad_slice_g(P.nt) - 1) / pad_slice_g(P.nt)) + " of " +
                            std::to_string(pad_slice_g(P.nt)) + " slice(s)").c_str());
       } else if (P.small) {
