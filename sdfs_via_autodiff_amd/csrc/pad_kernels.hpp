@@ -157,7 +157,7 @@ template <int NT, int R> struct PadLineGeo {
   static constexpr bool PARTIAL = UNITS % B != 0;
   static constexpr int LX = NT * R;
   static constexpr int NCT = NT * R / 16;                        // column tiles of either contraction
-  static constexpr int OCC = B == 512 ? 1 : ((size_t)NT * NT * R * 8 <= 40 * 1024 ? 3 : 2);      // (512 threads: 256 VGPRs, no spills in the last pass)
+  static constexpr int OCC = B == 512 ? 1 : ((size_t)NT * NT * R * 8 <= 26 * 1024 ? 4 : ((size_t)NT * NT * R * 8 <= 40 * 1024 ? 3 : 2));      // (512 threads: 256 VGPRs, no spills in the last pass)
   static_assert(R == 8 || R == 16, "row lengths");
   static_assert((NT * R) % 16 == 0, "whole column tiles");
 };
