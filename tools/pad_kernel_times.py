@@ -11,9 +11,10 @@ import sdfs_via_autodiff_amd as S  # noqa: E402
 
 def run(shapes, pad):
     os.environ["SDFS_PAD_PLAN"] = "2" if pad else "0"
-    g = S.GCY()
-    arr = S.discretize_gcy(g, shapes)
-    T = S.KoopmansOperator("gcy", shapes, g.params, arr)
+    model = "gcy" if len(shapes) == 6 else "ssy"
+    g = S.GCY() if model == "gcy" else S.SSY()
+    arr = (S.discretize_gcy if model == "gcy" else S.discretize_ssy)(g, shapes)
+    T = S.KoopmansOperator(model, shapes, g.params, arr)
     w = np.full(shapes, 800.0)
     v = np.random.default_rng(1).standard_normal(shapes)
     for _ in range(3):
