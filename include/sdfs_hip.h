@@ -224,6 +224,38 @@ enum { SDFS_SC_RR = 9, SDFS_SC_BB = 10, SDFS_SC_ATOL2 = 11, SDFS_SC_BREAK = 13, 
 int sdfs_krylov_step(sdfs_handle* h, int step, int64_t n, int f32, void* const* v, double* sums_dev,
                      double rtol, double atol);
 int sdfs_krylov_scalars(sdfs_handle* h, double* out16_host);
+/* step | SDFS_KS_GATED: the kernels of the step return at once while the handle's gate word is closed.  INIT_FIN opens it
+ * when |b|^2 is above the stopping level, ITER_FIN closes it on convergence, breakdown or a non-finite |r|^2 -- the gate
+ * of the single-GPU loop (csrc/vec_kernels.hpp) -- so a caller enqueues several iterations (stage launches gated on the
+ * same word: sdfs_krylov_gate + sdfs_apply_stage_gated_dev with gate_tol 0, all-reduces on whatever the sums buffer
+ * holds) per sdfs_krylov_scalars; the iterates and SDFS_SC_ITERS are those of the one-iteration-per-read loop. */
+enum { SDFS_KS_GATED = 0x100 };
+int sdfs_krylov_gate(sdfs_handle* h, const void** gate_dev);
+/* sdfs_pack_blocks(unpack = 1) with the Krylov operator's "- v" folded in: grid_out = unpacked - sub_dev (sub_dev laid out
+ * like grid_out; fp64 or fp32 by elem_bytes).  (J - I) v then costs the J v stages plus ONE extra stream in the pass that
+ * scatters the exchanged result back, instead of a subtraction and a copy over the whole shard. */
+int sdfs_unpack_blocks_sub(sdfs_handle* h, const void* packed_dev, void* grid_out_dev, const void* sub_dev, int64_t outer,
+                           int64_t n_axis, int64_t inner, int nblocks, const int64_t* offs, int elem_bytes);
+
+/* Anderson acceleration (jaxopt.AndersonAcceleration as called at code/solvers.py:104-114; semantics restated in
+ * oracle/solvers.py, iterate parity unpinned) on a SHARDED grid: the single-GPU loop's large-grid kernels
+ * (csrc/vec_kernels.hpp: history as Y_j = x_j + beta r_j and r_j, <r, r> per pass, the whole Gram matrix in one sweep
+ * where a solve is due) on this rank's n local points, the loop's control -- Gram matrix, the (m+1)^2 solve, the
+ * domain safeguard, the stopping test -- in the handle's device state, identical on every rank because it only ever sees
+ * all-reduced sums.  Sequence per pass i (0, 1, ...):  x_out = T(x_in) by the caller (stage launches gated on
+ * sdfs_anderson_gate, gate_tol 0);  PUSH -> [all-reduce SUM sums[0]];  if (i + 1) % mixing_freq == 0: GRAM -> [all-reduce SUM
+ * sums[1 .. 1 + SDFS_AND_NPAIRS)];  STEP;  MIX (x_out becomes the next iterate: pass i + 1 reads it as x_in, so the caller
+ * alternates two buffers).  Every kernel is a no-op once the loop has ended; sdfs_anderson_state reads the state back
+ * (out8 = passes executed, error = |T x - x|_2 of the last pass, 1 while the loop runs, 1 if a non-finite residual ended it,
+ * rejected mixing steps, ...) and the errors of passes first .. first + count (a ring of 256).  history <= 12; the history
+ * buffers hold history * n doubles each and stay the caller's. */
+enum { SDFS_AND_PUSH = 0, SDFS_AND_GRAM = 1, SDFS_AND_STEP = 2, SDFS_AND_MIX = 3 };
+enum { SDFS_AND_NPAIRS = 78 };
+int sdfs_anderson_begin(sdfs_handle* h, int64_t n, int history, double* y_hist_dev, double* r_hist_dev, double tol,
+                        int64_t max_iter, double beta, double ridge, int mixing_freq);
+int sdfs_anderson_gate(sdfs_handle* h, const void** gate_dev);
+int sdfs_anderson_step(sdfs_handle* h, int step, int64_t pass, const double* x_in_dev, double* x_out_dev, double* sums_dev);
+int sdfs_anderson_state(sdfs_handle* h, double* out8_host, double* errs_host, int64_t first_pass, int64_t count);
 /* Sharded handles: fp32 storage of the J.v streams and of the linearisation (opts.krylov_f32 of the single-GPU
  * solve) for the stage calls that follow.  `w_ref`: one positive value shared by all ranks (e.g. the geometric
  * mean of the all-reduced min and max of the iterate) from which every rank and both stages derive the same
@@ -240,6 +272,16 @@ int sdfs_get_counters(sdfs_handle* h, sdfs_counters* out);
  * replacement for jnp's `**` at ssy_wc_ratio.py:145,148 / gcy_wc_ratio.py:232,235),
  * so that its accuracy can be checked in isolation. */
 int sdfs_debug_pow(const double* x_host, double y, double* out_host, int64_t n, int device_id);
+/* The same for the routine the kernels use when the exponent is fixed for a launch (theta in the first pass of T,
+ * 1/theta in the last; csrc/pass_kernel.hpp, powy): degree 6 = the form inside the operator kernels (|y| * 1.04e-17
+ * polynomial error on x^y), degree 7 = accurate for any |y| <= 64, degree 0 = sdfs_debug_pow. */
+int sdfs_debug_powy(const double* x_host, double y, double* out_host, int64_t n, int degree, int device_id);
+
+/* Measurement aid (bench.py's `copy_ceiling_GBps`; no counterpart in the reference): dst[0..n) = src[0..n) by the library's
+ * own streaming copy -- one launch on the handle's stream, 16 bytes per lane, eight loads in flight per lane, non-temporal
+ * loads and stores: what a pass that reads and writes every grid point once can reach on this box.  Buffers 16-byte
+ * aligned, not overlapping. */
+int sdfs_stream_copy_dev(sdfs_handle* h, const double* src_dev, double* dst_dev, int64_t n);
 
 /* Human-readable description of the kernel plan (passes, tiles, grid sizes). */
 int sdfs_describe_plan(const sdfs_handle* h, char* buf, int64_t cap);

@@ -77,12 +77,20 @@ SYMBOLS = {
     "sdfs_pack_blocks": (C.c_int, [_P, C.c_int, _P, _P, C.c_int64, C.c_int64, C.c_int64, C.c_int, C.POINTER(C.c_int64), C.c_int]),
     "sdfs_krylov_step": (C.c_int, [_P, C.c_int, C.c_int64, C.c_int, C.POINTER(_P), _P, C.c_double, C.c_double]),
     "sdfs_krylov_scalars": (C.c_int, [_P, _P]),
+    "sdfs_krylov_gate": (C.c_int, [_P, C.POINTER(_P)]),
+    "sdfs_unpack_blocks_sub": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_int64, C.c_int64, C.c_int, C.POINTER(C.c_int64), C.c_int]),
+    "sdfs_anderson_begin": (C.c_int, [_P, C.c_int64, C.c_int, _P, _P, C.c_double, C.c_int64, C.c_double, C.c_double, C.c_int]),
+    "sdfs_anderson_gate": (C.c_int, [_P, C.POINTER(_P)]),
+    "sdfs_anderson_step": (C.c_int, [_P, C.c_int, C.c_int64, _P, _P, _P]),
+    "sdfs_anderson_state": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int64]),
     "sdfs_set_krylov_f32": (C.c_int, [_P, C.c_int, C.c_double]),
     "sdfs_set_profiling": (C.c_int, [_P, C.c_int]),
     "sdfs_reset_counters": (C.c_int, [_P]),
     "sdfs_get_counters": (C.c_int, [_P, C.POINTER(sdfs_counters)]),
     "sdfs_describe_plan": (C.c_int, [_P, C.c_char_p, C.c_int64]),
+    "sdfs_stream_copy_dev": (C.c_int, [_P, _P, _P, C.c_int64]),
     "sdfs_debug_pow": (C.c_int, [_P, C.c_double, _P, C.c_int64, C.c_int]),
+    "sdfs_debug_powy": (C.c_int, [_P, C.c_double, _P, C.c_int64, C.c_int, C.c_int]),
 }
 
 

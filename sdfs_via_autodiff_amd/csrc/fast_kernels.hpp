@@ -202,30 +202,36 @@ struct SliceIO {
   unsigned* sched;          // persistent form (stream_kernels.hpp): TK_WORDS scheduler words, zero between launches
 };
 
-template <int N> struct SliceGeo {
-  static constexpr int G = N == 32 ? 2 : (N == 24 ? 2 : 4);     // slices per wave tile
+// WV = waves per workgroup (every wave owns its tile: no barrier, so WV only sets how LDS is handed out), PAD20: the
+// padded row stride for N = 20 as well (tools/probes/kernel_bench.hip measures both; the library uses the defaults)
+// GX = slices per wave tile (0: the default; G N need not be a multiple of 16 -- the last column tile then computes a few
+// columns twice, see slice_kernel).
+template <int N, int WV = 4, bool PAD20 = false, int GX = 0> struct SliceGeo {
+  static constexpr int G = GX > 0 ? GX : (N == 32 ? 2 : (N == 24 ? 2 : 4));     // slices per wave tile
   // LDS row stride in doubles.  The contraction over the fastest axis reads 16 rows at this stride at once: at a
   // stride of N doubles = 2N banks that is a 2-way bank conflict for N = 20 but 8-way for 16, 4-way for 24, 16-way for
   // 32 (64 banks of 4 bytes) -- the first pass ran at 0.35 of the HBM peak at GCY 16^6 against 0.52 at 20^6.  N + 2
   // makes the 16 rows conflict-free for every N; 20 keeps its linear image (padding it was measured: no gain).
-  static constexpr int RS = N == 20 ? N : N + 2;
+  static constexpr int RS = (N == 20 && !PAD20) ? N : N + 2;
   static constexpr int LTILE = G * N * RS;                        // doubles of LDS per wave tile
   static constexpr int TILE = G * N * N;                          // doubles
   static constexpr int UNITS = TILE / 2;                          // double2 units
   static constexpr int EPT = (UNITS + 63) / 64;
-  static constexpr int NCT = G * N / 16;                          // column tiles of either contraction
-  static constexpr int WAVES = 4;
+  static constexpr int NCT = (G * N + 15) / 16;                   // column tiles of either contraction
+  static constexpr int CPAD = NCT * 16 - G * N;                   // columns of the last tile beyond the wave tile: they repeat
+                                                                  // the columns CPAD places back (same values to the same LDS slots)
+  static constexpr int WAVES = WV;
   static constexpr int UNITS4 = TILE / 4;                         // float4 units (fp32 streams)
   static constexpr int EPT4 = (UNITS4 + 63) / 64;
-  static_assert((G * N) % 16 == 0, "whole column tiles");
+  static_assert(CPAD <= 8, "the repeated columns lie inside the last column tile");
 };
 
 // F32 (opts.krylov_f32): J.v -- every stream (v, c1, the result) holds floats, 16-byte units of four;
 // linearising T -- its own streams stay fp64, c1 is written as scaled floats.  Arithmetic stays fp64.
-template <int N, int MODE, bool F32>
-__global__ void __launch_bounds__(256, 3)
+template <int N, int MODE, bool F32, int WV = 4, bool PAD20 = false, int GX = 0, int OCC = 3>
+__global__ void __launch_bounds__(64 * WV, OCC)
 slice_kernel(const SliceDesc P, const SliceIO io) {
-  using Geo = SliceGeo<N>;
+  using Geo = SliceGeo<N, WV, PAD20, GX>;
   constexpr bool T32 = MODE == S_TFIRST32;                        // fp64 in, scaled floats out
   constexpr bool POWP = MODE == S_TFIRST || MODE == S_TFIRST_LIN || T32;
   constexpr bool LIN = MODE == S_TFIRST_LIN;
@@ -288,8 +294,8 @@ slice_kernel(const SliceDesc P, const SliceIO io) {
     for (int k = 0; k < Geo::EPT; ++k) {
       const int u = lane + 64 * k;
       if (u < nvalid) {
-        v[k] = *reinterpret_cast<const double2*>(inb + (lb + 1024u * k));
-        if (MULP) c1v[MULP ? k : 0] = *reinterpret_cast<const double2*>(auxb + (lb + 1024u * k));
+        v[k] = ldg_stream2(inb + (lb + 1024u * k));
+        if (MULP) c1v[MULP ? k : 0] = ldg_stream2(auxb + (lb + 1024u * k));
       } else {
         v[k] = make_double2(1.0, 1.0);
         if (MULP) c1v[MULP ? k : 0] = make_double2(0.0, 0.0);
@@ -299,8 +305,8 @@ slice_kernel(const SliceDesc P, const SliceIO io) {
     // plain T: w^theta on the registers as they are parked -- one LDS write per unit instead of write + read + write
     // (unrolled: EPT copies of the power routine; the LDS pipe is this pass's second bottleneck: 0.262 -> 0.254 ms at
     // GCY 20^6, tools/probes/kernel_bench.hip).  The linearising and fp32-intermediate forms keep the rolled loop below.
-    PowLane PTr;
-    if (POWREG) PTr = pow_lane_init(lane);
+    PowK<true> PTr;
+    if (POWREG) PTr.init(P.theta, lane);
 #pragma unroll
     for (int k = 0; k < Geo::EPT; ++k) {
       const int u = lane + 64 * k;
@@ -308,7 +314,7 @@ slice_kernel(const SliceDesc P, const SliceIO io) {
       if (POWREG) {
         const double xin[2] = {v[k].x, v[k].y};       // (masked lanes were loaded as 1)
         double xw[2];
-        pow_fast_n<true, 2>(xin, P.theta, PTr, xw);
+        PTr.template run<2>(xin, xw);
         v[k] = make_double2(xw[0], xw[1]);
       }
       if (Geo::UNITS % 64 == 0 || u < Geo::UNITS) *reinterpret_cast<double2*>(wl + lofs(2 * u)) = v[k];
@@ -351,7 +357,10 @@ slice_kernel(const SliceDesc P, const SliceIO io) {
   {
     double* const p0 = wl + li * Geo::RS + lk;
 #pragma unroll
-    for (int ct = 0; ct < Geo::NCT; ++ct) ctile<N, 1>(p0 + ct * 16 * Geo::RS, qf);
+    for (int ct = 0; ct < Geo::NCT; ++ct) {
+      const bool rep = Geo::CPAD > 0 && ct == Geo::NCT - 1;       // (compile time)
+      ctile<N, 1>(p0 + (ct * 16 - ((rep && li >= 16 - Geo::CPAD) ? Geo::CPAD : 0)) * Geo::RS, qf);
+    }
   }
   wave_lds_fence();
   // ---- contraction over the second axis: column c = (slice g, f) at wl + g N RS + f, row stride RS ---
@@ -360,7 +369,8 @@ slice_kernel(const SliceDesc P, const SliceIO io) {
     qe.load(P.Qe, lane);
 #pragma unroll
     for (int ct = 0; ct < Geo::NCT; ++ct) {
-      const int c = 16 * ct + li;
+      const bool rep = Geo::CPAD > 0 && ct == Geo::NCT - 1;
+      const int c = 16 * ct + li - ((rep && li >= 16 - Geo::CPAD) ? Geo::CPAD : 0);
       const int g = c / N, f = c - g * N;
       ctile<N, Geo::RS>(wl + g * (N * Geo::RS) + f + lk * Geo::RS, qe);
     }
@@ -383,7 +393,7 @@ slice_kernel(const SliceDesc P, const SliceIO io) {
 #pragma unroll
     for (int k = 0; k < Geo::EPT; ++k) {
       const int u = lane + 64 * k;
-      if (u < nvalid) *reinterpret_cast<double2*>(outb + (lb + 1024u * k)) = *reinterpret_cast<const double2*>(wl + lofs(2 * u));
+      if (u < nvalid) stg_stream2(outb + (lb + 1024u * k), *reinterpret_cast<const double2*>(wl + lofs(2 * u)));
     }
   }
 }
@@ -647,6 +657,8 @@ line_kernel(const LineDesc P, const LineIO io) {
   bool rnan = false;
   PowLane PT;
   if (CES) PT = pow_lane_init(lane);
+  PowK<false> PK;                                                // the aggregator's power (exponent fixed for the launch)
+  if (CES) PK.init(P.inv_theta, lane);
   double lin_scale = 1.0;                                        // fp32 c2 = beta u / S * 2^-k
   if (LINE && F32) lin_scale = lin_scale_of(io.old[P.ref_off], 1.0 / P.inv_theta, PT, true);
 
@@ -749,7 +761,7 @@ line_kernel(const LineDesc P, const LineIO io) {
         // tile, whatever they are, the result is dropped).
         const double ks[2] = {(FULLC || ok) ? s2.x * sv.x : 1.0, (FULLC || ok) ? s2.y * sv.y : 1.0};
         double uu[2];
-        pow_fast_n<false, 2>(ks, P.inv_theta, PT, uu);
+        PK.template run<2>(ks, uu);
         const double2 y2 = make_double2(1.0 + P.beta * uu[0], 1.0 + P.beta * uu[1]);
         if (ok) {
           if (LINE) {
@@ -1470,9 +1482,15 @@ inline unsigned small_grid(const SmallDesc& d, int wpt) { return d.cpx != 0u ? 8
 inline unsigned small_cpx(long long ntiles, int wpt) { return (small_grid(ntiles, wpt) + 7u) / 8u; }
 
 
+// The plain first pass of T at N = 20: three slices per wave tile (9.6 KB of LDS per wave, 114 VGPRs: sixteen waves per
+// CU instead of twelve; the last of the four column tiles repeats four columns).  Measured with the power routine and the
+// non-temporal streams of round 4: 0.231-0.233 against 0.240 ms (profiles/round4_kernel_bench.txt); the other roles keep
+// four slices (their streams and register sets differ).
+template <int N> struct SliceTFirst { static constexpr int G = 0, OCC = 3; };
+template <> struct SliceTFirst<20> { static constexpr int G = 3, OCC = 4; };
 template <int N> inline slice_fn slice_variant_n(int mode, bool f32) {
   switch (mode) {
-    case S_TFIRST: return f32 ? nullptr : (slice_fn)slice_kernel<N, S_TFIRST, false>;
+    case S_TFIRST: return f32 ? nullptr : (slice_fn)slice_kernel<N, S_TFIRST, false, 4, false, SliceTFirst<N>::G, SliceTFirst<N>::OCC>;
     case S_TFIRST_LIN: return f32 ? (slice_fn)slice_kernel<N, S_TFIRST_LIN, true> : (slice_fn)slice_kernel<N, S_TFIRST_LIN, false>;
     case S_JFIRST: return f32 ? (slice_fn)slice_kernel<N, S_JFIRST, true> : (slice_fn)slice_kernel<N, S_JFIRST, false>;
     case S_MID: return f32 ? nullptr : (slice_fn)slice_kernel<N, S_MID, false>;
@@ -1524,8 +1542,12 @@ inline line_fn line_variant(int n, int mode, bool persist, bool fullc, bool f32 
   }
 }
 #endif
-inline int slice_tile_slices(int n) { return n == 16 ? SliceGeo<16>::G : n == 20 ? SliceGeo<20>::G : n == 24 ? SliceGeo<24>::G : SliceGeo<32>::G; }
-inline size_t slice_lds_bytes(int n) { return (size_t)slice_tile_slices(n) * n * (n == 20 ? n : n + 2) * 8 * 4; }
+// slices per wave tile / LDS bytes per workgroup of slice_variant(n, mode)
+inline int slice_tile_slices(int n, int mode) {
+  if (mode == S_TFIRST && n == 20) return SliceTFirst<20>::G;
+  return n == 16 ? SliceGeo<16>::G : n == 20 ? SliceGeo<20>::G : n == 24 ? SliceGeo<24>::G : SliceGeo<32>::G;
+}
+inline size_t slice_lds_bytes(int n, int mode) { return (size_t)slice_tile_slices(n, mode) * n * (n == 20 ? n : n + 2) * 8 * 4; }
 inline int line_block(int n) { return n <= 24 ? 256 : 512; }
 inline size_t line_lds_bytes(int n) { return (size_t)n * n * LINE_R * 8; }
 inline int line_blocks_per_cu(int n) { return n <= 16 ? LineGeo<16>::BPC : n == 20 ? LineGeo<20>::BPC : n == 24 ? LineGeo<24>::BPC : LineGeo<32>::BPC; }

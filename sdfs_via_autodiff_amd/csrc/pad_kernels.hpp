@@ -99,12 +99,13 @@ pad_slice_kernel(const PadDesc P, const SliceIO io) {
   wave_lds_fence();
   // ---- x = w^theta (c1 = w^(theta-1)) or v c1 on the registers, then parked -------------------------------------
   if (POWP) {
-    const PowLane PT = pow_lane_init(lane);
+    PowK<true> PT;
+    PT.init(P.theta, lane);
 #pragma unroll
     for (int k = 0; k < PAD_EPL; k += 2) {
       const double xin[2] = {v[k], v[k + 1]};                     // (masked lanes were loaded as 1)
       double xw[2];
-      pow_fast_n<true, 2>(xin, P.theta, PT, xw);
+      PT.template run<2>(xin, xw);
       if (LIN) {
         if (lane + 64 * k < nval) io.aux_out[gbase + lane + 64 * k] = xw[0] / xin[0];
         if (lane + 64 * (k + 1) < nval) io.aux_out[gbase + lane + 64 * (k + 1)] = xw[1] / xin[1];
@@ -240,7 +241,8 @@ pad_line_kernel(const PadDesc P, const LineIO io) {
   double rmax = 0.0, dot_yv = 0.0, dot_yy = 0.0;
   bool rnan = false;
   if (CES) {
-    const PowLane PT = pow_lane_init(lane);
+    PowK<false> PT;
+    PT.init(P.inv_theta, lane);
     const unsigned io0 = (unsigned)P.out_idx[o];
     const unsigned ia = pk0 ? io0 + (unsigned)P.rest_idx[pos] : 0u;
     const unsigned ib = pk1 ? io0 + (unsigned)P.rest_idx[pos + 1] : 0u;
@@ -263,7 +265,7 @@ pad_line_kernel(const PadDesc P, const LineIO io) {
       // whole wave), masked lanes feed it 1
       const double ks[2] = {a ? s2[k].x * sv.x : 1.0, b ? s2[k].y * sv.y : 1.0};
       double uu[2];
-      pow_fast_n<false, 2>(ks, P.inv_theta, PT, uu);
+      PT.template run<2>(ks, uu);
       const double y0 = 1.0 + P.beta * uu[0], y1 = 1.0 + P.beta * uu[1];
       if (a) {
         if (LINE) auxo[off] = P.beta * uu[0] / sv.x;

@@ -89,6 +89,28 @@ struct PassIO {
 };
 
 typedef double v4d __attribute__((ext_vector_type(4)));
+// tile registers as native vectors: a struct double2 moved between address spaces becomes an llvm.memcpy, and a tile
+// array that lives across a loop then stays in scratch
+typedef double v2d __attribute__((ext_vector_type(2)));
+
+// Grid streams of the pair-plan kernels: every point of a pass is read once and written once, nothing is re-read
+// through L2 inside a launch, so the 16-byte accesses carry the non-temporal hint (global_load/store_dwordx4 ... nt).
+// Measured with a plain streaming copy of one 512 MB grid (tools/probes/kernel_bench.hip, profiles/round4_kernel_bench.txt):
+// 5.43-5.54 TB/s with default-policy accesses, 5.85-5.86 TB/s with nt loads and stores.  SDFS_NT: bit 0 loads, bit 1
+// stores (A/B builds of the probe set it to 0).
+#ifndef SDFS_NT
+#define SDFS_NT 3
+#endif
+__device__ __forceinline__ v2d ldg_stream(const void* p) {
+  if (SDFS_NT & 1) return __builtin_nontemporal_load(reinterpret_cast<const v2d*>(p));
+  return *reinterpret_cast<const v2d*>(p);
+}
+__device__ __forceinline__ void stg_stream(void* p, const v2d v) {
+  if (SDFS_NT & 2) __builtin_nontemporal_store(v, reinterpret_cast<v2d*>(p));
+  else *reinterpret_cast<v2d*>(p) = v;
+}
+__device__ __forceinline__ double2 ldg_stream2(const void* p) { const v2d t = ldg_stream(p); return make_double2(t.x, t.y); }
+__device__ __forceinline__ void stg_stream2(void* p, const double2 v) { stg_stream(p, (v2d){v.x, v.y}); }
 
 // ---------------------------------------------------------------------------
 // pow_fast(x, y) for the two powers of the operator (w^theta and (K S)^(1/theta)).
@@ -310,7 +332,155 @@ __device__ __forceinline__ void pow_fast_n(const double (&x)[N], double y, const
     }
   }
 }
+// ---------------------------------------------------------------------------
+// powy: x^y with the exponent y FIXED FOR THE LAUNCH (theta in the first pass of T, 1/theta in its last) -- round 4.
+// Every term of y log2 x = y k + y log2 c + y log2(1 + r) is scaled by y before the per-element work starts:
+//   * lane i keeps  B = high word of y log2 c_i  (21 significant bits, one gather) and  Llo = the rest (a plain double);
+//   * y = yhi + ylo with yhi = y's high word, so  t1 = fma(yhi, k, B)  is EXACT (<= 41 significant bits) and everything
+//     else -- tlo = fma(ylo, k, Llo), the polynomial y log2(1 + r) = r (c1 + c2 r + ...) with c_j = y a_j held in SGPRs
+//     -- stays below ~|y| / 100 in magnitude, where plain double arithmetic is 2^-54 absolute: no double-double
+//     anywhere, no product y * hi with its error term, no two-sum;
+//   * near-minimax polynomials (tools/gen_pow_tables.py): log2(1 + r) to r^6 (DEG = 6: 1.04e-17 absolute, i.e. |y| times
+//     that on x^y -- operator grade: for y = theta the closing 1/theta power divides it out again, 1.2e-17 on T w; for
+//     |y| < 1 it is below every rounding) or to r^7 (DEG = 7: 3.8e-20, any |y| <= 64); 2^f to f^5 (2.4e-18);
+//   * the exponent arrives as k 2^20 = tmph & 0xfff00000, which the mantissa reduction needs anyway (yhi, ylo carry 2^-20).
+// 31 VALU instructions per element against 44 for pow_fast_try (host emulation of both, same operations in the same
+// order, against x87 long double: tools/probes/powy_host_check.cpp -- DEG 7 max 2.6e-16 like pow_fast_try's 2.2e-16,
+// DEG 6 2.0e-16 for |y| < 1 and 4.4e-16 at y = -36).  Inputs outside the straight-line path (x <= 0, NaN, Inf,
+// subnormal, |y log2 x| >= 1020) go through pow_core / pow_fix as before; that branch reloads the general tables.
+template <int DEG> struct PowY {
+  static_assert(DEG == 6 || DEG == 7, "polynomial degrees of tools/gen_pow_tables.py");
+  double invc, B, Llo, e2t;      // per lane (lane = table index)
+  double y, yhi, ylo, c[DEG];    // wave-uniform (SGPRs); c[DEG - 2] stays in a VGPR pair (the first Horner step reads two
+                                 // coefficients and a VOP3 instruction of gfx950 takes one scalar operand)
+};
+// d = a * s + c with the multiplier held in an SGPR pair
+__device__ __forceinline__ double fma_sm(double a, double s, double c) {
+  double d;
+  asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "s"(s), "v"(c));
+  return d;
+}
+// a wave-uniform double into an SGPR pair.  (Opaque to the optimiser on purpose: with the readfirstlane builtin the
+// compiler proves the value uniform, drops the move and then keeps all nine constants of the routine in VGPR pairs --
+// fourteen registers the walking slice kernel does not have.)
+__device__ __forceinline__ double uniform_f64(double v) {
+  // (the hazard recogniser does not look inside inline assembly: without the s_nop in front, a readfirstlane issued
+  // right behind the fp64 instruction that produces its operand read the register's previous contents -- constants off
+  // in their low word, 1e-13 .. 3e-6 relative on the power, caught by kernel_bench's comparison with the general routine)
+  int lo, hi;
+  asm volatile("s_nop 7\n\tv_readfirstlane_b32 %0, %2\n\tv_readfirstlane_b32 %1, %3\n\ts_nop 3"
+               : "=&s"(lo), "=&s"(hi) : "v"(__double2loint(v)), "v"(__double2hiint(v)));
+  return __hiloint2double(hi, lo);
+}
+template <int DEG>
+__device__ __forceinline__ PowY<DEG> powy_init(double y, int lane) {
+#pragma clang fp contract(off)
+  PowY<DEG> T;
+  T.invc = POW_INVC[lane]; T.e2t = POW_EXP2T[lane];
+  const double lchi = POW_LOGC_HI[lane], lclo = POW_LOGC_LO[lane];
+  const double p = y * lchi;
+  const double e = fma(y, lclo, fma(y, lchi, -p));     // y (lchi + lclo) = p + e
+  T.B = __hiloint2double(__double2hiint(p), 0);
+  T.Llo = (p - T.B) + e;                               // p - B is exact
+  T.y = y;
+  const double yh = __hiloint2double(__double2hiint(y), 0);
+  T.yhi = uniform_f64(yh * 0x1p-20);
+  T.ylo = uniform_f64((y - yh) * 0x1p-20);
+  if (DEG == 6) {
+    const double a[6] = {0.0, POW_A6_2, POW_A6_3, POW_A6_4, POW_A6_5, POW_A6_6};
+    T.c[0] = uniform_f64(fma(y, POW_A6_1_LO, y * POW_A6_1_HI));
+#pragma unroll
+    for (int j = 1; j < 6; ++j) T.c[j] = j == DEG - 2 ? y * a[j] : uniform_f64(y * a[j]);
+  } else {
+    const double a[7] = {0.0, POW_A7_2, POW_A7_3, POW_A7_4, POW_A7_5, POW_A7_6, POW_A7_7};
+    T.c[0] = uniform_f64(fma(y, POW_A7_1_LO, y * POW_A7_1_HI));
+#pragma unroll
+    for (int j = 1; j < DEG; ++j) T.c[j] = j == DEG - 2 ? y * a[j] : uniform_f64(y * a[j]);
+  }
+  return T;
+}
+#define SDFS_FORJ _Pragma("unroll") for (int j = 0; j < N; ++j)
+// the straight-line path for N elements (structure of arrays: the chains and gathers of neighbours interleave);
+// returns (per lane) whether any input needs the full routine, ts = y log2 x as this path saw it
+template <int DEG, int N>
+__device__ __forceinline__ bool powy_try(const double (&x)[N], const PowY<DEG>& T, double (&res)[N], double (&ts)[N]) {
+#pragma clang fp contract(off)
+  constexpr int OFFH = (int)(POW_OFF >> 32);
+  constexpr double SHIFT = 0x1.8p46;
+  int i4[N], ji[N];
+  double kd[N], z[N], invc[N], B[N], Llo[N], r[N], t1[N], u[N], q[N], f[N], t[N], p[N];
+  bool rare = false;
+  SDFS_FORJ {
+    const int hx = __double2hiint(x[j]);
+    const int tmph = hx - OFFH;
+    rare |= !__builtin_amdgcn_class(x[j], 0x100);      // anything but a positive normal number
+    i4[j] = tmph >> 12;                                // table index * 4 (ds_bpermute reads address bits [7:2])
+    const int m = tmph & (int)0xfff00000;
+    kd[j] = (double)m;                                 // k 2^20
+    z[j] = __hiloint2double(hx - m, __double2loint(x[j]));
+  }
+  SDFS_FORJ invc[j] = gather_hib(T.invc, i4[j]);
+  SDFS_FORJ B[j] = gather_hib(T.B, i4[j]);
+  SDFS_FORJ Llo[j] = gather64b(T.Llo, i4[j]);
+  SDFS_FORJ r[j] = fma(z[j], invc[j], -1.0);
+  SDFS_FORJ t1[j] = fma_sm(kd[j], T.yhi, B[j]);        // exact
+  SDFS_FORJ u[j] = fma_sm(kd[j], T.ylo, Llo[j]);
+  SDFS_FORJ q[j] = fma_sm(r[j], T.c[DEG - 1], T.c[DEG - 2]);
+#pragma unroll
+  for (int d = DEG - 3; d >= 0; --d) { SDFS_FORJ q[j] = fma_sc(q[j], r[j], T.c[d]); }
+  SDFS_FORJ u[j] = fma(q[j], r[j], u[j]);
+  SDFS_FORJ ts[j] = t1[j] + u[j];
+  SDFS_FORJ rare |= !(fabs(ts[j]) < 1020.0);
+  SDFS_FORJ {
+    double kk = ts[j] + SHIFT;                         // low mantissa bits: round(64 ts)
+    ji[j] = __double2loint(kk);
+    kk -= SHIFT;
+    f[j] = (t1[j] - kk) + u[j];                        // t1 - kk is exact
+  }
+  SDFS_FORJ t[j] = gather64b(T.e2t, ji[j] << 2);
+  SDFS_FORJ p[j] = fma_sc(f[j], POW_X5_5, POW_X5_4);
+  SDFS_FORJ p[j] = fma_sc(p[j], f[j], POW_X5_3);
+  SDFS_FORJ p[j] = fma_sc(p[j], f[j], POW_X5_2);
+  SDFS_FORJ p[j] = fma_sc(p[j], f[j], POW_X5_1);
+  SDFS_FORJ {
+    const double v = fma(t[j], p[j] * f[j], t[j]);
+    res[j] = __hiloint2double(__double2hiint(v) + ((ji[j] & ~63) << 14), __double2loint(v));
+  }
+  return rare;
+}
+template <int DEG, int N>
+__device__ __forceinline__ void powy_n(const double (&x)[N], const PowY<DEG>& T, double (&res)[N]) {
+  double ts[N];
+  const bool rare = powy_try<DEG, N>(x, T, res, ts);
+  if (__builtin_expect(__builtin_amdgcn_ballot_w64(rare) != 0ULL, 0)) {
+    const PowLane PT = pow_lane_init((int)(threadIdx.x & 63));
+    SDFS_FORJ {
+      const double c = pow_fix(x[j], T.y, pow_core<true>(x[j], T.y, PT));
+      const int hx = __double2hiint(x[j]);
+      const bool rj = (unsigned)(hx - 0x00100000) >= 0x7fe00000u || !(fabs(ts[j]) < 1020.0);
+      res[j] = rj ? c : res[j];
+    }
+  }
+}
 #undef SDFS_FORJ
+
+// The power of a kernel whose exponent is fixed for the launch: powy (default) or, with -DSDFS_POWY=0 (A/B builds of
+// tools/probes/kernel_bench.hip), the general routine.  HIPREC only matters to the latter.
+#ifndef SDFS_POWY
+#define SDFS_POWY 1
+#endif
+template <bool HIPREC> struct PowK {
+#if SDFS_POWY
+  PowY<6> T;
+  __device__ __forceinline__ void init(double y, int lane) { T = powy_init<6>(y, lane); }
+  template <int N> __device__ __forceinline__ void run(const double (&x)[N], double (&res)[N]) const { powy_n<6, N>(x, T, res); }
+#else
+  PowLane T;
+  double y;
+  __device__ __forceinline__ void init(double y_, int lane) { T = pow_lane_init(lane); y = y_; }
+  template <int N> __device__ __forceinline__ void run(const double (&x)[N], double (&res)[N]) const { pow_fast_n<HIPREC, N>(x, y, T, res); }
+#endif
+};
 
 // XCD-aware block -> tile map: blocks b, b+8, b+16.. share an XCD (round-robin
 // dispatch), so give each XCD one contiguous chunk of tiles: neighbouring tiles
@@ -825,15 +995,23 @@ pass_kernel(const PassDesc P, const PassIO io) {
   }
 }
 
-// test hook: out[i] = pow_fast(x[i], y) (n padded so that whole waves run)
+// test hook: out[i] = pow_fast(x[i], y) (n padded so that whole waves run); deg = 6 / 7: the pre-scaled routine powy
 __global__ void __launch_bounds__(256) debug_pow_kernel(const double* __restrict__ x, double y,
-                                                        double* __restrict__ out, long long n) {
-  const PowLane PT = pow_lane_init(threadIdx.x & 63);
+                                                        double* __restrict__ out, long long n, int deg) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const double xv = i < n ? x[i] : 1.0;
   const double xin[1] = {xv};
   double r[1];
-  if (fabs(y) < 1.0) pow_fast_n<false, 1>(xin, y, PT, r); else pow_fast_n<true, 1>(xin, y, PT, r);
+  if (deg == 6) {
+    const PowY<6> T = powy_init<6>(y, threadIdx.x & 63);
+    powy_n<6, 1>(xin, T, r);
+  } else if (deg == 7) {
+    const PowY<7> T = powy_init<7>(y, threadIdx.x & 63);
+    powy_n<7, 1>(xin, T, r);
+  } else {
+    const PowLane PT = pow_lane_init(threadIdx.x & 63);
+    if (fabs(y) < 1.0) pow_fast_n<false, 1>(xin, y, PT, r); else pow_fast_n<true, 1>(xin, y, PT, r);
+  }
   if (i < n) out[i] = r[0];
 }
 

@@ -157,6 +157,8 @@ struct sdfs_handle {
   double* and_gram_partial = nullptr; // large grids: partial sums of the whole Gram matrix (k_and_gram_full)
   unsigned* and_flag = nullptr;       // fused form: per pass of a chunk, set by a push that met a non-finite residual
   double* and_err = nullptr; int* and_kind = nullptr; int and_slots = 0;
+  // distributed Anderson (sdfs_anderson_begin / _step): history in caller-owned buffers, control state in and_state
+  struct { bool on = false; long long n = 0; int m = 0, mixing_freq = 1; double tol = 0, max_iter = 0, beta = 0, ridge = 0; AndPtrs hp; } dand;
   double* and_err_host = nullptr; int* and_kind_host = nullptr;
   hipGraphExec_t and_graph = nullptr;
   int and_graph_chunk = 0, and_graph_m = 0, and_graph_freq = 0;
@@ -776,7 +778,7 @@ int build_fast_plan(sdfs_handle* h) {
     for (int c = D - 1; c >= 0; --c) P.sd.ref_off += (long long)(h->shape[c] / 2) * stride[c];
     P.q_bytes = 2 * 8.0 * n * n; P.flops = 2.0 * (double)h->N * 2 * n;
     P.label = std::string("slices[") + h->ax[D - 2].name + "," + h->ax[D - 1].name + "|wave-private " +
-              std::to_string(slice_tile_slices(n)) + "x" + std::to_string(n) + "x" + std::to_string(n) + "]";
+              std::to_string(slice_tile_slices(n, S_TFIRST)) + "x" + std::to_string(n) + "x" + std::to_string(n) + "]";
     passes.push_back(P);
   }
   long long min_tiles = 1LL << 60;
@@ -865,9 +867,9 @@ int build_fast_plan(sdfs_handle* h) {
     if (!P.line) for (int m = 0; m < S_NMODES; ++m) {
       slice_fn f = slice_variant(P.n, m);
       if (!f) return 0;
-      hipFuncSetAttribute((const void*)f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)slice_lds_bytes(P.n));
+      hipFuncSetAttribute((const void*)f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)slice_lds_bytes(P.n, m));
       slice_fn f32 = slice_variant(P.n, m, true);
-      if (f32) hipFuncSetAttribute((const void*)f32, hipFuncAttributeMaxDynamicSharedMemorySize, (int)slice_lds_bytes(P.n));
+      if (f32) hipFuncSetAttribute((const void*)f32, hipFuncAttributeMaxDynamicSharedMemorySize, (int)slice_lds_bytes(P.n, m));
     } else for (int m = 0; m < L_NMODES; ++m) for (int pe = 0; pe < 2; ++pe) {
       line_fn f = line_variant(P.n, m, pe != 0, P.ld.lrest % LINE_R == 0);
       if (!f && m == L_TFUSED && pe != 0) continue;          // one tile per workgroup only
@@ -1203,10 +1205,10 @@ int run_fast_plan(sdfs_handle* h, int mode, const double* in, double* out, const
       if (f32 && mode == MODE_JVP) bytes *= 0.5;
       int cid = -1;
       if (h->profiling) { char nm[48]; snprintf(nm, sizeof nm, "%s:%s", tag, P.label.c_str()); cid = counter_id(h, nm, bytes, P.flops); }
-      const long long ntile = (P.sd.nslices + slice_tile_slices(P.n) - 1) / slice_tile_slices(P.n);
+      const long long ntile = (P.sd.nslices + slice_tile_slices(P.n, sm) - 1) / slice_tile_slices(P.n, sm);
       const unsigned grid = (unsigned)((ntile + 3) / 4);
       ProfScope ps(h, cid);
-      hipLaunchKernelGGL(fn, dim3(grid), dim3(256), slice_lds_bytes(P.n), h->stream, sd, io);
+      hipLaunchKernelGGL(fn, dim3(grid), dim3(256), slice_lds_bytes(P.n, sm), h->stream, sd, io);
     } else {
       LineIO io;
       memset(&io, 0, sizeof io);
@@ -1396,9 +1398,9 @@ int big_sa_iteration(sdfs_handle* h, long long it, const double* w_old, double* 
   {
     int cid = -1;
     if (h->profiling) cid = counter_id(h, ("sa:" + P.label).c_str(), 16.0 * (double)h->N + P.q_bytes, P.flops);
-    const long long ntile = (P.sd.nslices + slice_tile_slices(P.n) - 1) / slice_tile_slices(P.n);
+    const long long ntile = (P.sd.nslices + slice_tile_slices(P.n, S_MID) - 1) / slice_tile_slices(P.n, S_MID);
     ProfScope ps(h, cid);
-    hipLaunchKernelGGL(fn, dim3((unsigned)((ntile + 3) / 4)), dim3(256), slice_lds_bytes(P.n), h->stream, P.sd, io);
+    hipLaunchKernelGGL(fn, dim3((unsigned)((ntile + 3) / 4)), dim3(256), slice_lds_bytes(P.n, S_MID), h->stream, P.sd, io);
     HIPCHK(h, hipGetLastError());
   }
   return big_sa_line(h, 1 + (int)(it & 1), false, h->tmp, w_new, w_old, resid, gate, gate_tol);
@@ -2430,7 +2432,13 @@ int krylov_step_t(sdfs_handle* h, int step, long long n, void* const* v, double*
   T *r = (T*)v[1], *rhat = (T*)v[2], *p = (T*)v[3], *q = (T*)v[4], *t = (T*)v[5], *x = (T*)v[6];
   const int g = vec_grid(n);
   hipStream_t st = h->stream;
-  const unsigned long long* nog = nullptr;
+  // SDFS_KS_GATED: every kernel of the step returns at once while the handle's gate word is closed (INIT_FIN opens it
+  // when there is something to solve, ITER_FIN closes it on convergence, breakdown or a non-finite |r|^2), so the caller
+  // can enqueue several iterations per read of the scalar block; INIT and INIT_FIN themselves always run
+  const bool gated = (step & SDFS_KS_GATED) != 0;
+  step &= ~SDFS_KS_GATED;
+  const unsigned long long* nog = (gated && step != SDFS_KS_INIT) ? h->bicg_gate : nullptr;
+  unsigned long long* const wgate = gated ? h->bicg_gate : nullptr;
   switch (step) {
     case SDFS_KS_INIT:
       hipLaunchKernelGGL(k_bicg_init<T>, dim3(g), dim3(VEC_BLOCK), 0, st, b, r, rhat, p, q, x, n);
@@ -2438,7 +2446,7 @@ int krylov_step_t(sdfs_handle* h, int step, long long n, void* const* v, double*
       hipLaunchKernelGGL(k_presum, dim3(1), dim3(VEC_BLOCK), 0, st, (const double*)h->partial, g, 1, sums, nog);
       break;
     case SDFS_KS_INIT_FIN:
-      hipLaunchKernelGGL(k_bicg_init_finish, dim3(1), dim3(VEC_BLOCK), 0, st, (const double*)sums, 0, h->sc, rtol, atol, (unsigned long long*)nullptr);
+      hipLaunchKernelGGL(k_bicg_init_finish, dim3(1), dim3(VEC_BLOCK), 0, st, (const double*)sums, 0, h->sc, rtol, atol, wgate);
       break;
     case SDFS_KS_UPDATE_P:
       hipLaunchKernelGGL(k_bicg_update_p<T>, dim3(g), dim3(VEC_BLOCK), 0, st, (const T*)r, p, (const T*)q, n, h->sc, nog);
@@ -2465,7 +2473,7 @@ int krylov_step_t(sdfs_handle* h, int step, long long n, void* const* v, double*
       hipLaunchKernelGGL(k_presum, dim3(1), dim3(VEC_BLOCK), 0, st, (const double*)h->partial, g, 2, sums, nog);
       break;
     case SDFS_KS_ITER_FIN:
-      hipLaunchKernelGGL(k_bicg_iter_finish, dim3(1), dim3(VEC_BLOCK), 0, st, (const double*)sums, 0, h->sc, (unsigned long long*)nullptr);
+      hipLaunchKernelGGL(k_bicg_iter_finish, dim3(1), dim3(VEC_BLOCK), 0, st, (const double*)sums, 0, h->sc, wgate);
       break;
     case SDFS_KS_SUB_DOT:        // v[0] = out g (fp64), v[1] = a, v[2] = b (fp64): g = a - b, sums[0] = <g, g> (local)
       hipLaunchKernelGGL(k_sub_dot, dim3(g), dim3(VEC_BLOCK), 0, st, (const double*)v[1], (const double*)v[2], (double*)v[0], n, h->partial);
@@ -2946,10 +2954,185 @@ int sdfs_pack_blocks(sdfs_handle* h, int unpack, const void* src, void* dst, int
   return 0;
 }
 
+int sdfs_stream_copy_dev(sdfs_handle* h, const double* src_dev, double* dst_dev, int64_t n) {
+  int rc = check(h); if (rc) return rc;
+  if (!src_dev || !dst_dev || n < 1) return fail(h, SDFS_ERR_ARG, "bad argument");
+  if (((uintptr_t)src_dev | (uintptr_t)dst_dev) % 16 != 0) return fail(h, SDFS_ERR_ARG, "16-byte aligned buffers");
+  const long long units = n / 2;
+  const long long per = (long long)VEC_BLOCK * COPY_UNITS;
+  const unsigned grid = (unsigned)std::max<long long>(1, (units + per - 1) / per);
+  hipLaunchKernelGGL(k_stream_copy, dim3(grid), dim3(VEC_BLOCK), 0, h->stream, src_dev, dst_dev, units, (long long)n);
+  HIPCHK(h, hipGetLastError());
+  return 0;
+}
+
+int sdfs_unpack_blocks_sub(sdfs_handle* h, const void* packed, void* dst, const void* sub, int64_t outer, int64_t n_axis,
+                           int64_t inner, int nblocks, const int64_t* offs, int elem_bytes) {
+  int rc = check(h); if (rc) return rc;
+  if (!packed || !dst || !sub || !offs) return fail(h, SDFS_ERR_ARG, "NULL argument");
+  if (nblocks < 1) return fail(h, SDFS_ERR_ARG, "at least one block");
+  if (nblocks > PACK_MAX_BLOCKS) return fail(h, SDFS_ERR_UNSUPPORTED, "pack: at most %d blocks", PACK_MAX_BLOCKS);
+  if (elem_bytes != 8 && elem_bytes != 4) return fail(h, SDFS_ERR_ARG, "elements of 4 or 8 bytes");
+  if (outer < 1 || n_axis < 1 || inner < 1 || offs[0] != 0 || offs[nblocks] != n_axis) return fail(h, SDFS_ERR_ARG, "bad block table");
+  PackBlocks B;
+  memset(&B, 0, sizeof B);
+  B.n = nblocks;
+  for (int j = 0; j <= nblocks; ++j) {
+    if (j > 0 && offs[j] <= offs[j - 1]) return fail(h, SDFS_ERR_ARG, "empty or unordered block");
+    B.off[j] = (unsigned)offs[j];
+  }
+  const long long run_bytes = (long long)inner * elem_bytes;
+  const bool wide = run_bytes % 16 == 0 && ((uintptr_t)packed % 16) == 0 && ((uintptr_t)dst % 16) == 0 && ((uintptr_t)sub % 16) == 0;
+  const int ub = wide ? 16 : elem_bytes;
+  const long long innerU = run_bytes / ub;
+  const long long total = outer * n_axis * innerU;
+  if (total >= (1LL << 31)) return fail(h, SDFS_ERR_UNSUPPORTED, "pack: more than 2^31 units");
+  const unsigned grid = (unsigned)std::min<long long>((total + VEC_BLOCK - 1) / VEC_BLOCK, 8192);
+#define SDFS_UNPACK_SUB(U)                                                                                               \
+  hipLaunchKernelGGL((k_pack_blocks<U, true, true>), dim3(grid), dim3(VEC_BLOCK), 0, h->stream, (const U*)packed, (U*)dst,     \
+                     (unsigned)outer, (unsigned)n_axis, (unsigned)innerU, B, (const U*)sub)
+  if (ub == 16 && elem_bytes == 8) SDFS_UNPACK_SUB(double2);
+  else if (ub == 16) SDFS_UNPACK_SUB(float4);
+  else if (ub == 8) SDFS_UNPACK_SUB(double);
+  else SDFS_UNPACK_SUB(float);
+#undef SDFS_UNPACK_SUB
+  HIPCHK(h, hipGetLastError());
+  return 0;
+}
+
+static int ensure_bicg_gate(sdfs_handle* h) {
+  if (!h->bicg_gate) {
+    HIPCHK(h, hipMalloc((void**)&h->bicg_gate, 64));
+    h->misc_allocs.push_back(h->bicg_gate);
+    HIPCHK(h, hipHostMalloc((void**)&h->bicg_gate_host, 64));
+  }
+  return 0;
+}
+
+int sdfs_krylov_gate(sdfs_handle* h, const void** gate_dev) {
+  int rc = check(h); if (rc) return rc;
+  if (!gate_dev) return fail(h, SDFS_ERR_ARG, "NULL pointer");
+  if ((rc = ensure_bicg_gate(h))) return rc;
+  *gate_dev = h->bicg_gate;
+  return 0;
+}
+
+// ---- Anderson acceleration on a sharded grid: the single-GPU loop's batched-Gram kernels on this rank's shard -----------
+constexpr int DAND_SLOTS = 256;       // error ring (one slot per pass, read back by sdfs_anderson_state)
+static_assert(AND_LAZY_PAIRS == SDFS_AND_NPAIRS, "include/sdfs_hip.h states the length of the Gram sums");
+
+int sdfs_anderson_begin(sdfs_handle* h, int64_t n, int history, double* y_hist_dev, double* r_hist_dev, double tol,
+                        int64_t max_iter, double beta, double ridge, int mixing_freq) {
+  int rc = check(h); if (rc) return rc;
+  if (n < 1 || !y_hist_dev || !r_hist_dev) return fail(h, SDFS_ERR_ARG, "bad argument");
+  if (history < 1 || history > AND_LAZY_M) return fail(h, SDFS_ERR_ARG, "Anderson history must be in 1..%d", AND_LAZY_M);
+  if (mixing_freq < 1) return fail(h, SDFS_ERR_ARG, "mixing_freq must be >= 1");
+  if ((n & 1) && history > 0 && ((uintptr_t)r_hist_dev % 16 != 0)) return fail(h, SDFS_ERR_ARG, "history buffers must be 16-byte aligned");
+  if ((rc = ensure_scalars(h))) return rc;
+  if (!h->and_state) {
+    HIPCHK(h, hipMalloc((void**)&h->and_state, 2 * sizeof(AndState)));
+    h->misc_allocs.push_back(h->and_state);
+    HIPCHK(h, hipHostMalloc((void**)&h->and_state_host, sizeof(AndState)));
+  }
+  if (h->and_slots < DAND_SLOTS) {
+    if (h->and_graph) { hipGraphExecDestroy(h->and_graph); h->and_graph = nullptr; }
+    if (h->and_err_host) { hipHostFree(h->and_err_host); hipHostFree(h->and_kind_host); h->and_err_host = nullptr; h->and_kind_host = nullptr; }
+    HIPCHK(h, hipMalloc((void**)&h->and_err, sizeof(double) * DAND_SLOTS));
+    h->misc_allocs.push_back(h->and_err);
+    HIPCHK(h, hipMalloc((void**)&h->and_kind, sizeof(int) * DAND_SLOTS));
+    h->misc_allocs.push_back(h->and_kind);
+    HIPCHK(h, hipMalloc((void**)&h->and_flag, sizeof(unsigned) * DAND_SLOTS));
+    h->misc_allocs.push_back(h->and_flag);
+    HIPCHK(h, hipHostMalloc((void**)&h->and_err_host, sizeof(double) * DAND_SLOTS));
+    HIPCHK(h, hipHostMalloc((void**)&h->and_kind_host, sizeof(int) * DAND_SLOTS));
+    h->and_slots = DAND_SLOTS;
+  }
+  if (!h->and_gram_partial) {
+    HIPCHK(h, hipMalloc((void**)&h->and_gram_partial, sizeof(double) * (size_t)AND_LAZY_PAIRS * AND_LAZY_BLOCKS));
+    h->misc_allocs.push_back(h->and_gram_partial);
+  }
+  auto& D = h->dand;
+  D.on = true; D.n = n; D.m = history; D.mixing_freq = mixing_freq; D.tol = tol; D.max_iter = (double)max_iter; D.beta = beta; D.ridge = ridge;
+  memset(&D.hp, 0, sizeof D.hp);
+  for (int j = 0; j < history; ++j) { D.hp.X[j] = y_hist_dev + (size_t)j * (size_t)n; D.hp.R[j] = r_hist_dev + (size_t)j * (size_t)n; }
+  hipStream_t st = h->stream;
+  HIPCHK(h, hipMemsetAsync(r_hist_dev, 0, sizeof(double) * (size_t)history * (size_t)n, st));
+  HIPCHK(h, hipMemsetAsync(h->and_kind, 0, sizeof(int) * DAND_SLOTS, st));
+  AndState& I = *h->and_state_host;
+  memset(&I, 0, sizeof I);
+  I.err = std::numeric_limits<double>::infinity();
+  I.prev_pos = -1.0; I.mix_rel = -1;
+  I.gate = (max_iter > 0 && I.err > tol) ? ~0ULL : 0ULL;
+  HIPCHK(h, hipMemcpyAsync(h->and_state, &I, sizeof I, hipMemcpyHostToDevice, st));
+  HIPCHK(h, hipStreamSynchronize(st));
+  return 0;
+}
+
+int sdfs_anderson_gate(sdfs_handle* h, const void** gate_dev) {
+  int rc = check(h); if (rc) return rc;
+  if (!gate_dev || !h->dand.on) return fail(h, SDFS_ERR_ARG, "sdfs_anderson_begin first");
+  *gate_dev = &h->and_state->gate;
+  return 0;
+}
+
+int sdfs_anderson_step(sdfs_handle* h, int step, int64_t pass, const double* x_in, double* x_out, double* sums_dev) {
+  int rc = check(h); if (rc) return rc;
+  const auto& D = h->dand;
+  if (!D.on) return fail(h, SDFS_ERR_ARG, "sdfs_anderson_begin first");
+  if (pass < 0 || !sums_dev) return fail(h, SDFS_ERR_ARG, "bad argument");
+  const long long n = D.n;
+  const int m = D.m, g = vec_grid(n), pos = (int)(pass % m), slot = (int)(pass % DAND_SLOTS), rel = (int)(pass & 0x3fffffff);
+  const int gb = (int)std::min<long long>(AND_LAZY_BLOCKS, std::max<long long>(1, (n + 2 * VEC_BLOCK - 1) / (2 * VEC_BLOCK)));
+  AndState* S = h->and_state;
+  hipStream_t st = h->stream;
+  const unsigned long long* gate = &S->gate;
+  switch (step) {
+    case SDFS_AND_PUSH:       // Y[pos] = x + beta r, R[pos] = r = x_out - x_in, sums[0] = this rank's <r, r>
+      if (!x_in || !x_out) return fail(h, SDFS_ERR_ARG, "NULL iterate");
+      hipLaunchKernelGGL(k_and_push_lite, dim3(g), dim3(VEC_BLOCK), 0, st, x_in, (const double*)x_out, D.hp.X[pos], D.hp.R[pos], D.beta, n, h->partial, gate);
+      hipLaunchKernelGGL(k_presum, dim3(1), dim3(VEC_BLOCK), 0, st, (const double*)h->partial, g, 1, sums_dev, gate);
+      break;
+    case SDFS_AND_GRAM:       // sums[1 ..] = this rank's part of the whole Gram matrix (pairs i <= j in k_and_gram_full's order)
+      hipLaunchKernelGGL(k_and_gram_full, dim3(gb), dim3(VEC_BLOCK), 0, st, D.hp, m, D.mixing_freq, n, h->and_gram_partial, (const AndState*)S);
+      hipLaunchKernelGGL(k_presum, dim3(1), dim3(VEC_BLOCK), 0, st, (const double*)h->and_gram_partial, gb, AND_LAZY_PAIRS, sums_dev + 1, gate);
+      break;
+    case SDFS_AND_STEP: {     // the control step from the all-reduced sums (nb = 0: totals, not partials)
+      const int refresh = ((pass + 1) % D.mixing_freq) == 0 ? 1 : 0;
+      hipLaunchKernelGGL(k_and_step_lazy, dim3(1), dim3(VEC_BLOCK), 0, st, (const double*)sums_dev, 0, (const double*)(sums_dev + 1), 1, refresh,
+                         m, pos, rel, S, h->and_err + slot, h->and_kind + slot, D.tol, D.max_iter, D.mixing_freq, D.ridge);
+      break;
+    }
+    case SDFS_AND_MIX:        // the update of x the step decided on, in place in x_out (= T x_in on entry)
+      if (!x_out) return fail(h, SDFS_ERR_ARG, "NULL iterate");
+      hipLaunchKernelGGL(k_and_mix_y, dim3(g), dim3(VEC_BLOCK), 0, st, D.hp, (const AndState*)S, m, D.beta, x_out, (const double*)x_out, pos, rel, n);
+      break;
+    default:
+      return fail(h, SDFS_ERR_ARG, "unknown Anderson step %d", step);
+  }
+  HIPCHK(h, hipGetLastError());
+  return 0;
+}
+
+int sdfs_anderson_state(sdfs_handle* h, double* out8_host, double* errs_host, int64_t first_pass, int64_t count) {
+  int rc = check(h); if (rc) return rc;
+  if (!h->dand.on || !out8_host) return fail(h, SDFS_ERR_ARG, "sdfs_anderson_begin first");
+  if (count < 0 || count > DAND_SLOTS || first_pass < 0 || (count > 0 && !errs_host)) return fail(h, SDFS_ERR_ARG, "bad error window");
+  hipStream_t st = h->stream;
+  HIPCHK(h, hipMemcpyAsync(h->and_state_host, h->and_state, sizeof(AndState), hipMemcpyDeviceToHost, st));
+  if (count > 0) HIPCHK(h, hipMemcpyAsync(h->and_err_host, h->and_err, sizeof(double) * DAND_SLOTS, hipMemcpyDeviceToHost, st));
+  HIPCHK(h, hipStreamSynchronize(st));
+  const AndState& F = *h->and_state_host;
+  out8_host[0] = F.it; out8_host[1] = F.err; out8_host[2] = F.gate != 0ULL ? 1.0 : 0.0; out8_host[3] = F.status;
+  out8_host[4] = F.rejected; out8_host[5] = F.no_mix_until; out8_host[6] = F.last_mixed; out8_host[7] = F.prev_pos;
+  for (int64_t i = 0; i < count; ++i) errs_host[i] = h->and_err_host[(first_pass + i) % DAND_SLOTS];
+  return 0;
+}
+
 int sdfs_krylov_step(sdfs_handle* h, int step, int64_t n, int f32, void* const* v, double* sums_dev, double rtol, double atol) {
   int rc = check(h); if (rc) return rc;
   if (!v || !sums_dev || n < 1) return fail(h, SDFS_ERR_ARG, "bad argument");
   if ((rc = ensure_scalars(h))) return rc;
+  if ((step & SDFS_KS_GATED) && (rc = ensure_bicg_gate(h))) return rc;
   return f32 ? krylov_step_t<float>(h, step, (long long)n, v, sums_dev, rtol, atol)
              : krylov_step_t<double>(h, step, (long long)n, v, sums_dev, rtol, atol);
 }
@@ -3002,13 +3185,17 @@ int sdfs_get_counters(sdfs_handle* h, sdfs_counters* out) {
 }
 
 int sdfs_debug_pow(const double* x_host, double y, double* out_host, int64_t n, int device_id) {
-  if (!x_host || !out_host || n < 1) return SDFS_ERR_ARG;
+  return sdfs_debug_powy(x_host, y, out_host, n, 0, device_id);
+}
+
+int sdfs_debug_powy(const double* x_host, double y, double* out_host, int64_t n, int degree, int device_id) {
+  if (!x_host || !out_host || n < 1 || (degree != 0 && degree != 6 && degree != 7)) return SDFS_ERR_ARG;
   if (hipSetDevice(device_id) != hipSuccess) return fail(nullptr, SDFS_ERR_HIP, "hipSetDevice failed");
   double *dx = nullptr, *dy = nullptr;
   if (hipMalloc((void**)&dx, 8 * (size_t)n) != hipSuccess || hipMalloc((void**)&dy, 8 * (size_t)n) != hipSuccess)
     return fail(nullptr, SDFS_ERR_HIP, "hipMalloc failed");
   hipMemcpy(dx, x_host, 8 * (size_t)n, hipMemcpyHostToDevice);
-  hipLaunchKernelGGL(debug_pow_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, dx, y, dy, (long long)n);
+  hipLaunchKernelGGL(debug_pow_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, dx, y, dy, (long long)n, degree);
   hipError_t e = hipMemcpy(out_host, dy, 8 * (size_t)n, hipMemcpyDeviceToHost);
   hipFree(dx); hipFree(dy);
   return e == hipSuccess ? 0 : fail(nullptr, SDFS_ERR_HIP, "debug_pow: %s", hipGetErrorString(e));
@@ -3041,10 +3228,10 @@ int sdfs_describe_plan(const sdfs_handle* h, char* buf, int64_t cap) {
         snprintf(line, sizeof line, "small-grid plan pass %zu: %s %d wave%s per tile, run %d, tiles %lld, workgroups %u\n", i,
                  P.label.c_str(), P.wpt, P.wpt == 1 ? "" : "s", P.r, P.sm.ntiles, small_grid(P.sm, P.wpt));
       } else if (!P.line) {
-        hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)slice_variant(P.n, S_TFIRST), 256, slice_lds_bytes(P.n));
-        const long long nt = (P.sd.nslices + slice_tile_slices(P.n) - 1) / slice_tile_slices(P.n);
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)slice_variant(P.n, S_TFIRST), 256, slice_lds_bytes(P.n, S_TFIRST));
+        const long long nt = (P.sd.nslices + slice_tile_slices(P.n, S_TFIRST) - 1) / slice_tile_slices(P.n, S_TFIRST);
         snprintf(line, sizeof line, "pair plan pass %zu: %s lds %zu B block 256 (4 wave tiles) wave-tiles %lld blocks/CU %d\n", i,
-                 P.label.c_str(), slice_lds_bytes(P.n), nt, occ);
+                 P.label.c_str(), slice_lds_bytes(P.n, S_TFIRST), nt, occ);
       } else {
         hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)line_variant(P.n, L_MID, P.persist, P.ld.lrest % LINE_R == 0), line_block(P.n), line_lds_bytes(P.n));
         snprintf(line, sizeof line, "pair plan pass %zu: %s lds %zu B block %d tiles %lld (outer %lld x %d chunks of 128 B) %s grid %u blocks/CU %d\n", i,

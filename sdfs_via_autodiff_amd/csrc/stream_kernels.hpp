@@ -25,9 +25,6 @@
 
 namespace sdfs {
 
-// tile registers as native vectors: a struct double2 moved between address spaces becomes an llvm.memcpy, and
-// a tile array that lives across the walk's loop then stays in scratch
-typedef double v2d __attribute__((ext_vector_type(2)));
 
 // Tile scheduler of a persistent launch: tickets, one counter per XCD.  The tiles are cut into eight contiguous
 // ranges; the workgroups (slice form: waves) of XCD x (= blockIdx.x & 7 under round-robin dispatch; only locality
@@ -83,8 +80,142 @@ __device__ __forceinline__ void line_tile_load(v2d (&v)[EPT], const double* base
 #pragma unroll
   for (int k = 0; k < EPT; ++k) {
     const bool rowok = UNITS % B == 0 || tid + k * B < UNITS;
-    v[k] = *reinterpret_cast<const v2d*>(inb + (rowok ? b0 + k * bstep : b0));
+    v[k] = ldg_stream(inb + (rowok ? b0 + k * bstep : b0));
   }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// slice_walk_kernel: slice_kernel's plain first pass of T (S_TFIRST) and its plain contraction (S_MID) with a wave
+// WALKING wave tiles (round 4).  What bounds slice_kernel at GCY 20^6 is neither its instruction count (a power routine
+// 16 % shorter bought 2.7 %), nor occupancy (16 waves per CU instead of 12: nothing), nor its LDS bank conflicts
+// (padded rows: nothing) -- profiles/round4_kernel_bench.txt -- but the bytes it keeps in flight: a wave has loads
+// outstanding only while it waits for its own tile (~45 % of its time), so a CU holds ~70 KB in flight against the
+// ~135 KB that 5.4 TB/s at 6 us per load need.  Here the registers a tile arrives in are free again as soon as the tile
+// is parked in LDS (the power runs on them first), so the NEXT tile's 13 loads are issued right there and travel while
+// the wave runs its two contractions and stores the result -- no second register set (round 3's form issued them before
+// the power, next to the current tile: 168 VGPRs, 2 spills, slower).  Both Q fragment sets stay in registers for the
+// launch (loads return in order: a fragment load behind the prefetch would wait for all of it).  Tiles are drawn from
+// the per-XCD ticket counters, one ticket per wave and tile, the ticket of the tile after next during the power.
+// OCC = waves per SIMD the register budget is set for; QRELOAD: the Q fragments are fetched per tile, in front of the
+// prefetch (their L2 round trip is exposed once per tile, but 40 registers are free during the power).
+// POWLDS: the tile is parked raw, the next tile's loads are issued at once (they travel under the power as well) and the
+// power runs in place in LDS, unit by unit in a rolled loop (one copy of the routine; write + read + write per unit instead
+// of one write, but no unit waits in registers while the routine runs).
+// POW1 (with POWLDS): one element at a time through the routine (half the temporaries; three waves per SIMD interleave).
+template <int N, int MODE, int OCC = 3, bool QRELOAD = false, bool POWLDS = false, bool POW1 = false>
+__global__ void __launch_bounds__(256, OCC)
+slice_walk_kernel(const SliceDesc P, const SliceIO io) {
+  using Geo = SliceGeo<N>;
+  static_assert(MODE == S_TFIRST || MODE == S_MID, "plain first pass of T / plain contraction");
+  constexpr bool POWP = MODE == S_TFIRST;
+  extern __shared__ double lds[];
+  if (io.gate != nullptr) {
+    const unsigned long long g = *io.gate;
+    if (g <= (unsigned long long)__double_as_longlong(io.gate_tol)) return;
+  }
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  if (io.zero != nullptr && blockIdx.x == 0 && threadIdx.x == 0) *io.zero = 0ULL;
+  const long long ntiles = P.nslices / Geo::G;
+  const TicketWalk W(ntiles, blockIdx.x, io.sched);
+  double* const wl = lds + wave * Geo::LTILE;
+  auto lofs = [](const int e) -> int { return Geo::RS == N ? e : (e / N) * Geo::RS + (e % N); };
+  const unsigned lb = (unsigned)lane * 16u;
+  const int li = lane & 15, lk = lane >> 4;
+  auto draw = [&]() -> unsigned {
+    unsigned t = 0u;
+    if (lane == 0) t = W.draw();
+    return (unsigned)__builtin_amdgcn_readfirstlane((int)t);
+  };
+  // whole wave tiles only (the host launches this form when nslices is a multiple of G): every offset is an immediate
+  auto load_tile = [&](v2d (&v)[Geo::EPT], const unsigned t) {
+    const char* const inb = reinterpret_cast<const char*>(io.in + (long long)t * Geo::TILE);
+#pragma unroll
+    for (int k = 0; k < Geo::EPT; ++k) {
+      const bool in_tile = Geo::UNITS % 64 == 0 || lane + 64 * k < Geo::UNITS;      // (compile time except in the last unit)
+      v[k] = ldg_stream(inb + (in_tile ? lb + 1024u * k : lb));    // (a lane past the tile re-reads unit 0's piece: positive, finite)
+    }
+  };
+  unsigned cur = draw();
+  unsigned nxt = cur != NO_TILE ? draw() : NO_TILE;
+  if (cur != NO_TILE) {
+    QFrag<N> qf, qe;
+    if (!QRELOAD) { qf.load(P.Qf, lane); qe.load(P.Qe, lane); }
+    PowK<true> PT;
+    if (POWP) PT.init(P.theta, lane);
+    v2d v[Geo::EPT];
+    load_tile(v, cur);
+    for (;;) {
+      unsigned nn = NO_TILE;
+      if (nxt != NO_TILE) nn = draw();               // the tile after next (returns under the power)
+      // ---- power on the registers, park ------------------------------------------------------------------------
+#pragma unroll
+      for (int k = 0; k < Geo::EPT; ++k) {
+        const int u = lane + 64 * k;
+        if (POWP && !POWLDS) {
+          const double xin[2] = {v[k].x, v[k].y};
+          double xw[2];
+          PT.template run<2>(xin, xw);
+          v[k] = (v2d){xw[0], xw[1]};
+        }
+        if (Geo::UNITS % 64 == 0 || u < Geo::UNITS) *reinterpret_cast<v2d*>(wl + lofs(2 * u)) = v[k];
+      }
+      char* const outb = reinterpret_cast<char*>(io.out + (long long)cur * Geo::TILE);
+      // ---- the next tile's loads: the registers are free, the requests travel under the contractions ----------------
+      if (QRELOAD) { qf.load(P.Qf, lane); qe.load(P.Qe, lane); }
+      if (nxt != NO_TILE) load_tile(v, nxt);
+      if (POWP && POWLDS) {
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll 1
+        for (int k = 0; k < Geo::EPT; ++k) {
+          const int u = lane + 64 * k;
+          const bool in_tile = Geo::UNITS % 64 == 0 || u < Geo::UNITS;
+          const int lo = in_tile ? lofs(2 * u) : 0;
+          const v2d x2 = *reinterpret_cast<const v2d*>(wl + lo);
+          const double xin[2] = {in_tile ? x2.x : 1.0, in_tile ? x2.y : 1.0};
+          double xw[2];
+          if (POW1) {
+            const double xa[1] = {xin[0]}, xb[1] = {xin[1]};
+            double ya[1], yb[1];
+            PT.template run<1>(xa, ya);
+            __builtin_amdgcn_sched_barrier(0);
+            PT.template run<1>(xb, yb);
+            xw[0] = ya[0]; xw[1] = yb[0];
+          } else {
+            PT.template run<2>(xin, xw);
+          }
+          if (in_tile) *reinterpret_cast<v2d*>(wl + lo) = (v2d){xw[0], xw[1]};
+        }
+      }
+      wave_lds_fence();
+      {
+        double* const p0 = wl + li * Geo::RS + lk;
+#pragma unroll
+        for (int ct = 0; ct < Geo::NCT; ++ct) { ctile<N, 1>(p0 + ct * 16 * Geo::RS, qf); __builtin_amdgcn_sched_barrier(0); }
+      }
+      wave_lds_fence();
+      {
+#pragma unroll
+        for (int ct = 0; ct < Geo::NCT; ++ct) {
+          const int c = 16 * ct + li;
+          const int g = c / N, f = c - g * N;
+          ctile<N, Geo::RS>(wl + g * (N * Geo::RS) + f + lk * Geo::RS, qe);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      wave_lds_fence();
+#pragma unroll
+      for (int k = 0; k < Geo::EPT; ++k) {
+        const int u = lane + 64 * k;
+        if (Geo::UNITS % 64 == 0 || u < Geo::UNITS) stg_stream(outb + (lb + 1024u * k), *reinterpret_cast<const v2d*>(wl + lofs(2 * u)));
+        if (k % 4 == 3) __builtin_amdgcn_sched_barrier(0);      // four units on their way out at a time (register budget)
+      }
+      wave_lds_fence();
+      if (nxt == NO_TILE) break;
+      cur = nxt; nxt = nn;
+    }
+  }
+  if (lane == 0) ticket_walk_done(io.sched, gridDim.x * Geo::WAVES);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -145,8 +276,8 @@ line_stream_kernel(const LineDesc P, const LineIO io) {
   qx.load(P.Qx, lane);
   if (PERSIST) qy_.load(P.Qy, lane);
   QFrag<N>& qy = PERSIST ? qy_ : qx;
-  PowLane PT;
-  if (CES) PT = pow_lane_init(lane);
+  PowK<false> PT;
+  if (CES) PT.init(P.inv_theta, lane);
   SDFS_STREAM_STAMP_DECL;
   double rmax = 0.0, dot_yv = 0.0, dot_yy = 0.0;
   bool rnan = false;
@@ -203,7 +334,7 @@ line_stream_kernel(const LineDesc P, const LineIO io) {
 #pragma unroll
         for (int k = 0; k < EPT; ++k) {
           const int u = tid + k * B;
-          if (!PARTIAL || u < Geo::UNITS) *reinterpret_cast<v2d*>(outb + (b0 + (unsigned)k * bstep)) = *reinterpret_cast<const v2d*>(lds + 2 * u);
+          if (!PARTIAL || u < Geo::UNITS) stg_stream(outb + (b0 + (unsigned)k * bstep), *reinterpret_cast<const v2d*>(lds + 2 * u));
           if (k % 4 == 3) __builtin_amdgcn_sched_barrier(0);      // four units on their way out at a time (register budget)
         }
       } else {
@@ -224,7 +355,7 @@ line_stream_kernel(const LineDesc P, const LineIO io) {
           const int u = tid + k * B;
           const bool rowok = k < EPT && (!PARTIAL || u < Geo::UNITS);
           const unsigned offc = rowok ? b0 + (unsigned)k * bstep : b0;
-          if (!OLDPF && need_old) s1 = *reinterpret_cast<const double2*>(oldb + offc);
+          if (!OLDPF && need_old) s1 = ldg_stream2(oldb + offc);
           if (CES && A3F) {
             const int row = rowok ? (u >> 3) : 0;
             const double fx = sF1[32 * par + row / N];
@@ -247,7 +378,7 @@ line_stream_kernel(const LineDesc P, const LineIO io) {
           if (CES) {
             const double ks[2] = {s2.x * sv.x, s2.y * sv.y};
             double uu[2];
-            pow_fast_n<false, 2>(ks, P.inv_theta, PT, uu);
+            PT.template run<2>(ks, uu);
             const double2 y2 = make_double2(1.0 + P.beta * uu[0], 1.0 + P.beta * uu[1]);
             if (rowok) {
               if (LINE) *reinterpret_cast<double2*>(auxo + off) = make_double2(P.beta * uu[0] / sv.x, P.beta * uu[1] / sv.y);
@@ -256,7 +387,7 @@ line_stream_kernel(const LineDesc P, const LineIO io) {
                 rnan |= (r0 != r0) | (r1 != r1);
                 rmax = fmax(rmax, fmax(r0, r1));
               }
-              *reinterpret_cast<double2*>(outb + off) = y2;
+              stg_stream2(outb + off, y2);
             }
           } else if (rowok) {
             double2 y2 = make_double2(sv.x * s2.x, sv.y * s2.y);
@@ -388,6 +519,8 @@ line_tlast32_kernel(const LineDesc P, const LineIO io) {
   }
   const PowLane PT = pow_lane_init(lane);
   const double unscale = t32_scale_of(io.old[P.ref_off], P.theta, PT, true);
+  PowK<false> PK;
+  PK.init(P.inv_theta, lane);
   __syncthreads();
   {
     double* const p0 = lds + li + lk * Geo::LX;
@@ -426,8 +559,8 @@ line_tlast32_kernel(const LineDesc P, const LineIO io) {
     const double ksa[2] = {a3v[0] * (s0.x * unscale), a3v[1] * (s0.y * unscale)};
     const double ksb[2] = {a3v[2] * (s1.x * unscale), a3v[3] * (s1.y * unscale)};
     double ua[2], ub[2];
-    pow_fast_n<false, 2>(ksa, P.inv_theta, PT, ua);
-    pow_fast_n<false, 2>(ksb, P.inv_theta, PT, ub);
+    PK.template run<2>(ksa, ua);
+    PK.template run<2>(ksb, ub);
     const v2d ya = (v2d){1.0 + P.beta * ua[0], 1.0 + P.beta * ua[1]}, yb = (v2d){1.0 + P.beta * ub[0], 1.0 + P.beta * ub[1]};
     if (rowok) {
       if (need_old) {

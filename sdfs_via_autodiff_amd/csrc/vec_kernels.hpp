@@ -708,15 +708,45 @@ k_and_mix_y(AndPtrs h, const AndState* __restrict__ S, int m, double beta, doubl
 #undef BODY
 }
 
+// ---- streaming copy: the ceiling of a 16-byte-per-point pass on this box --------------------------------------------------
+// One chunk of 256 x 8 16-byte units per workgroup, all eight loads of a lane in flight, non-temporal loads and stores --
+// the fastest of the copy forms tools/probes/kernel_bench.hip measured (5.75-5.86 TB/s at 512 MB; grid-stride and
+// default-policy forms 5.1-5.7, hipMemcpyAsync 4.6-5.5).  bench.py prints it as `copy_ceiling_GBps`.
+constexpr int COPY_UNITS = 8;
+__global__ void __launch_bounds__(VEC_BLOCK) k_stream_copy(const double* __restrict__ in, double* __restrict__ out, long long units, long long n) {
+  const long long c0 = (long long)blockIdx.x * (VEC_BLOCK * COPY_UNITS);
+  v2d v[COPY_UNITS];
+#pragma unroll
+  for (int k = 0; k < COPY_UNITS; ++k) {
+    const long long i = c0 + threadIdx.x + (long long)VEC_BLOCK * k;
+    if (i < units) v[k] = __builtin_nontemporal_load(reinterpret_cast<const v2d*>(in) + i);
+  }
+#pragma unroll
+  for (int k = 0; k < COPY_UNITS; ++k) {
+    const long long i = c0 + threadIdx.x + (long long)VEC_BLOCK * k;
+    if (i < units) __builtin_nontemporal_store(v[k], reinterpret_cast<v2d*>(out) + i);
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0 && (n & 1)) out[n - 1] = in[n - 1];
+}
+
 // ---- re-shard pack / unpack (multi-GPU exchange buffers) -----------------------------------------------------------------
 // grid = [outer][n_axis][inner] (C order), packed = concat_j [outer][size_j][inner] with block j = axis indices
 // offs[j] .. offs[j+1].  One launch moves the whole shard (the host side used one strided copy per peer).  U = unit type
 // (16 bytes when the inner run allows it, else one element); innerU = inner run in units.
 constexpr int PACK_MAX_BLOCKS = 16;
 struct PackBlocks { int n; unsigned off[PACK_MAX_BLOCKS + 1]; };
-template <typename U, bool UNPACK>
+// SUB (unpack only): dst = unpacked - sub, `sub` laid out like dst -- the "- v" of a Krylov operator application
+// (J - I) v folded into the pass that scatters the exchanged J v back (distributed.py: HipKrylov; three grid streams
+// instead of the two of the unpack plus the five of a separate subtraction and copy)
+__device__ __forceinline__ double2 unit_sub(const double2 a, const double2 b) { return make_double2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ double unit_sub(const double a, const double b) { return a - b; }
+__device__ __forceinline__ float unit_sub(const float a, const float b) { return a - b; }
+__device__ __forceinline__ float4 unit_sub(const float4 a, const float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
+template <typename U, bool UNPACK, bool SUB = false>
 __global__ void __launch_bounds__(VEC_BLOCK)
-k_pack_blocks(const U* __restrict__ src, U* __restrict__ dst, unsigned outer, unsigned n_axis, unsigned innerU, PackBlocks B) {
+k_pack_blocks(const U* __restrict__ src, U* __restrict__ dst, unsigned outer, unsigned n_axis, unsigned innerU, PackBlocks B,
+              const U* __restrict__ sub = nullptr) {
+  static_assert(!SUB || UNPACK, "the subtraction rides on the unpack");
   const unsigned total = outer * n_axis * innerU;          // < 2^31 (host check)
   for (unsigned e = blockIdx.x * VEC_BLOCK + threadIdx.x; e < total; e += gridDim.x * VEC_BLOCK) {
     const unsigned q = e / innerU, r = e - q * innerU;
@@ -726,7 +756,8 @@ k_pack_blocks(const U* __restrict__ src, U* __restrict__ dst, unsigned outer, un
     for (int t = 1; t < PACK_MAX_BLOCKS; ++t) j += (t < B.n && i >= B.off[t]) ? 1 : 0;
     const unsigned sz = B.off[j + 1] - B.off[j];
     const unsigned p = (outer * B.off[j] + o * sz + (i - B.off[j])) * innerU + r;
-    if (UNPACK) dst[e] = src[p]; else dst[p] = src[e];
+    if (SUB) dst[e] = unit_sub(src[p], sub[e]);
+    else if (UNPACK) dst[e] = src[p]; else dst[p] = src[e];
   }
 }
 

@@ -62,6 +62,16 @@ def block_offsets(sizes):
     return off
 
 
+class _DevWord:
+    """A device address handed to the C ABI where it takes a 1-element tensor (only data_ptr() is used)."""
+
+    def __init__(self, ptr):
+        self._ptr = int(ptr)
+
+    def data_ptr(self):
+        return self._ptr
+
+
 class HipStages:
     """Stage backend on libsdfs_hip (one sharded handle per rank)."""
 
@@ -123,6 +133,29 @@ class HipStages:
             return False                      # more blocks / bigger units than the kernel takes: the caller copies per peer
         check(rc, self._h)
         return True
+
+    def unpack_blocks_sub(self, grid, packed, sub, axis, offs):
+        """grid = unpack(packed) - sub in one launch (sdfs_unpack_blocks_sub): the "- v" of (J - I) v rides on the pass
+        that scatters the exchanged J v back."""
+        shp = list(grid.shape)
+        outer = int(np.prod(shp[:axis], dtype=np.int64)) if axis > 0 else 1
+        inner = int(np.prod(shp[axis + 1:], dtype=np.int64)) if axis + 1 < len(shp) else 1
+        o = (C.c_int64 * len(offs))(*[int(v) for v in offs])
+        rc = lib.sdfs_unpack_blocks_sub(self._h, packed.data_ptr(), grid.data_ptr(), sub.data_ptr(), outer, shp[axis], inner,
+                                        len(offs) - 1, o, grid.element_size())
+        if rc == _lib.SDFS_ERR_UNSUPPORTED:
+            return False
+        check(rc, self._h)
+        return True
+
+    def gate_tensor(self, which):
+        """A 1-element device tensor VIEW of the handle's gate word of the Krylov ("krylov") or the Anderson ("anderson")
+        loop: 0 (as a double: +0.0) once the loop has ended, so stage launches gated on it with gate_tol 0 turn into
+        no-ops exactly when the loop's own kernels do."""
+        p = C.c_void_p()
+        fn = lib.sdfs_krylov_gate if which == "krylov" else lib.sdfs_anderson_gate
+        check(fn(self._h, C.byref(p)), self._h)
+        return _DevWord(p.value)
 
     def describe_plan(self):
         buf = C.create_string_buffer(4096)
@@ -238,7 +271,7 @@ class ShardedKoopmans:
         self._bufs[("flip", role)] = n
         return f"{role}{n}"
 
-    def _reshard(self, x, src_axis, src_sizes, src_off, dst_axis, dst_sizes, dst_off, out=None):
+    def _reshard(self, x, src_axis, src_sizes, src_off, dst_axis, dst_sizes, dst_off, out=None, minus=None):
         """x is sharded on src_axis (this rank's block) with dst_axis full; return the grid sharded
         on dst_axis with src_axis full.  Rank r receives block (all src, its dst block).
         Blocks along axis 0 are contiguous slabs: they are sent / received in place, the other
@@ -292,20 +325,27 @@ class ShardedKoopmans:
             if stage:
                 for t, h_ in zip(recv, hr):
                     t.copy_(h_)
+        offs_src = list(src_off) + [out.shape[src_axis]]
         if src_axis != 0:
-            if rflat is not None and self.backend.pack_blocks(out, rflat, src_axis, list(src_off) + [out.shape[src_axis]], unpack=True):
+            if rflat is not None and minus is not None and self.backend.unpack_blocks_sub(out, rflat, minus, src_axis, offs_src):
+                minus = None                                               # (the subtraction rode on the unpack)
+            elif rflat is not None and self.backend.pack_blocks(out, rflat, src_axis, offs_src, unpack=True):
                 pass
             else:
                 for slot, t in zip(slots, recv):                           # unpack
                     slot.copy_(t)
+        if minus is not None:
+            out.sub_(minus)
         self.n_exchanges += 1
         return out
 
     def a_to_b(self, x, out=None):
         return self._reshard(x, self.axis_a, self.a_sizes, self.a_off, self.axis_b, self.b_sizes, self.b_off, out=out)
 
-    def b_to_a(self, x, out=None):
-        return self._reshard(x, self.axis_b, self.b_sizes, self.b_off, self.axis_a, self.a_sizes, self.a_off, out=out)
+    def b_to_a(self, x, out=None, minus=None):
+        """minus (a grid in the A-sharded layout): the result is (re-sharded x) - minus, the subtraction folded into the
+        unpack launch."""
+        return self._reshard(x, self.axis_b, self.b_sizes, self.b_off, self.axis_a, self.a_sizes, self.a_off, out=out, minus=minus)
 
     @property
     def mirror_ok(self):
@@ -339,11 +379,14 @@ class ShardedKoopmans:
         return t, res
 
     # -- operator -------------------------------------------------------------------
-    def _apply(self, mode, x):
-        y = self._stage(self.backend, 0, mode, x, "s0")
+    def _apply(self, mode, x, out=None, minus=None, gate=None):
+        """gate: a 1-element device tensor; while it holds 0 the stage kernels are no-ops (the exchanges still run, on
+        whatever the buffers hold).  out / minus: as in b_to_a."""
+        kw = {} if gate is None else dict(gate=gate, gate_tol=0.0)
+        y = self._stage(self.backend, 0, mode, x, "s0", **kw)
         z = self.a_to_b(y)
-        t = self._stage(self.backend, 1, mode, z, "s1")
-        return self.b_to_a(t)
+        t = self._stage(self.backend, 1, mode, z, "s1", **kw)
+        return self.b_to_a(t, out=out, minus=minus)
 
     def apply_T(self, w_loc):
         return self._apply(MODE_T, w_loc)
@@ -370,6 +413,11 @@ class ShardedKoopmans:
 
     def jvp(self, v_loc):
         return self._apply(MODE_JVP, v_loc)
+
+    def jvp_minus(self, v_loc, out, gate=None):
+        """out = dT(w)[v] - v, the Krylov operator of the Newton step (code/solvers.py:87): the "- v" rides on the
+        unpack launch of the second exchange."""
+        return self._apply(MODE_JVP, v_loc, out=out, minus=v_loc, gate=gate)
 
     # -- reductions -------------------------------------------------------------------
     def _allreduce(self, t, op):
@@ -478,14 +526,25 @@ def successive_approx_sharded(op, w_loc, tol=1e-7, max_iter=1000000, errors=None
                 slots[0:1].copy_(slots[n:n + 1])                  # gate of the next chunk's first iteration
         if stats is not None:
             stats["mirror_iters"] = it
-        w = A[(it >> 1) & 1] if it & 1 == 0 else B[(it >> 1) & 1]     # w_it
-        w_loc = w if it & 1 == 0 else op.b_to_a(w)                   # back to the A-sharded layout
+        # w_it, back in the A-sharded layout and in a buffer this call owns (never the operator's re-shard buffer, which
+        # the next exchange overwrites, and never the caller's tensor): an odd `it` lands in the A buffer that does not
+        # hold w_(it-1)
+        if it & 1 == 0:
+            w_loc = A[(it >> 1) & 1]
+        else:
+            w_loc = op.b_to_a(B[(it >> 1) & 1], out=A[(((it - 1) >> 1) + 1) & 1])
+        own = True
         if diverged:
+            # (a non-finite error keeps every later gate of its chunk open: the iterate returned is not w_it and holds
+            # non-finite values either way)
             if stats is not None:
                 stats["host_syncs"] = host_syncs
             return w_loc, it
-    # exact phase: fixed layout, one-step error, the same ring and gate
-    W = [w_loc.contiguous(), torch.empty_like(w_loc)]
+    else:
+        own = False
+    # exact phase: fixed layout, one-step error, the same ring and gate.  The caller's tensor is never written: the
+    # second iteration's output lands in W[0].
+    W = [w_loc if own else w_loc.contiguous().clone(), torch.empty_like(w_loc)]
     cur = 0
     w_b = None
     err = tol + 1
@@ -522,8 +581,68 @@ def successive_approx_sharded(op, w_loc, tol=1e-7, max_iter=1000000, errors=None
     return W[cur], it
 
 
+AND_PUSH, AND_GRAM, AND_STEP, AND_MIX = range(4)
+AND_NPAIRS = 78                      # SDFS_AND_NPAIRS: Gram sums of a history of up to 12
+AND_DEVICE_MAX_M = 12
+
+
+def _anderson_sharded_device(op, w_loc, tol, max_iter, m, mixing_frequency, beta, ridge, errors, stats, check_every):
+    """anderson_sharded on the library's own kernels (sdfs_anderson_step: the single-GPU loop's batched-Gram form,
+    csrc/vec_kernels.hpp) with the loop's control in the handle's device state: per pass one sharded application of T
+    (stage kernels gated on the loop's own word), the push, ONE all-reduce of |r|^2, on every mixing_frequency-th pass the
+    Gram sweep and an all-reduce of its 78 sums, the control step (one workgroup: stopping test, solve, safeguard --
+    identical on every rank, it only sees all-reduced values) and the update of x.  The iterate alternates between two
+    buffers (a plain step x = T x is no copy), nothing is cloned, and the host reads the state every `check_every`
+    passes: host_syncs <= n_iter / check_every + 2."""
+    be = op.backend
+    dev = w_loc.device
+    n = w_loc.numel()
+    h = be._h
+    Y = torch.empty((m, n), dtype=torch.float64, device=dev)
+    R = torch.empty((m, n), dtype=torch.float64, device=dev)
+    sums = torch.zeros(1 + AND_NPAIRS, dtype=torch.float64, device=dev)
+    X = [w_loc.contiguous().clone(), torch.empty_like(w_loc)]
+    check(lib.sdfs_anderson_begin(h, n, m, Y.data_ptr(), R.data_ptr(), float(tol), int(max_iter), float(beta), float(ridge),
+                                  int(mixing_frequency)), h)
+    gate = be.gate_tensor("anderson")
+    check_every = max(int(check_every), 1)
+    st = (C.c_double * 8)()
+    errbuf = (C.c_double * 256)()
+
+    def step(which, i, xi=None, xo=None):
+        check(lib.sdfs_anderson_step(h, which, i, xi.data_ptr() if xi is not None else None,
+                                     xo.data_ptr() if xo is not None else None, sums.data_ptr()), h)
+
+    enq, it, host_syncs, open_ = 0, 0, 0, max_iter > 0
+    while open_ and enq < max_iter:
+        cnt = min(check_every, max_iter - enq, 256)
+        for i in range(enq, enq + cnt):
+            xi, xo = X[i & 1], X[(i + 1) & 1]
+            op._apply(MODE_T, xi, out=xo, gate=gate)
+            step(AND_PUSH, i, xi, xo)
+            op.allreduce_sum(sums[:1])
+            if (i + 1) % mixing_frequency == 0:
+                step(AND_GRAM, i)
+                op.allreduce_sum(sums[1:])
+            step(AND_STEP, i)
+            step(AND_MIX, i, None, xo)
+        check(lib.sdfs_anderson_state(h, st, errbuf, enq, cnt), h)      # the one host read of the chunk
+        host_syncs += 1
+        it_new = int(st[0])
+        if errors is not None:
+            errors.extend(errbuf[j] for j in range(it_new - it))
+        it = it_new
+        open_ = st[2] != 0.0
+        enq += cnt
+    if stats is not None:
+        stats["rejected_mixes"] = int(st[4]) if host_syncs else 0
+        stats["host_syncs"] = host_syncs
+        stats["status"] = int(st[3]) if host_syncs else 0
+    return X[it & 1], it          # pass i leaves the iterate in buffer (i + 1) & 1
+
+
 def anderson_sharded(op, w_loc, tol=1e-7, max_iter=10000, history_size=10, mixing_frequency=4, beta=8.0, ridge=1e-6,
-                     errors=None, stats=None):
+                     errors=None, stats=None, check_every=16):
     """Anderson acceleration (code/solvers.py:98-124: jaxopt.AndersonAcceleration with m = 10, mixing every 4th
     iteration, beta = 8, ridge 1e-6; semantics restated in oracle/solvers.py, iterate parity UNPINNED) on a sharded
     grid, fixed layout.  Per iteration: one sharded application of T (two exchanges), the history write and ONE
@@ -534,9 +653,13 @@ def anderson_sharded(op, w_loc, tol=1e-7, max_iter=10000, history_size=10, mixin
     extrapolation is local.  A mixing step that leaves the domain (w <= 0 or not finite; at large grids
     N r^2 dwarfs the absolute ridge) is rejected as in the single-GPU loop: plain step, history restarted.
     Returns (w_loc, n_iter); the error is the reference's: the Euclidean norm of T(w) - w."""
+    if isinstance(op.backend, HipStages) and int(history_size) <= AND_DEVICE_MAX_M:
+        return _anderson_sharded_device(op, w_loc, tol, max_iter, int(history_size), int(mixing_frequency), beta, ridge,
+                                        errors, stats, check_every)
     m = int(history_size)
     dev = w_loc.device
     n = w_loc.numel()
+    # (CPU rehearsal with the numpy-oracle stage backend: the same scheme in torch arithmetic, one read per iteration)
     # history slot j: Y_j = x_j + beta r_j and r_j, so that a mixing step reads m streams (x = sum_j alpha_j Y_j)
     Y = torch.zeros((m, n), dtype=torch.float64, device=dev)
     R = torch.zeros((m, n), dtype=torch.float64, device=dev)
@@ -601,6 +724,7 @@ def anderson_sharded(op, w_loc, tol=1e-7, max_iter=10000, history_size=10, mixin
 
 KS_INIT, KS_INIT_FIN, KS_UPDATE_P, KS_DOT_RQ, KS_ALPHA_S, KS_S_FIN, KS_DOT_TS, KS_OMEGA_XR, KS_ITER_FIN, KS_SUB_DOT, \
     KS_NEWTON_UPDATE = range(11)
+KS_GATED = 0x100
 SC_RR, SC_BB, SC_ATOL2, SC_BREAK, SC_ITERS = 9, 10, 11, 13, 15
 
 
@@ -610,10 +734,11 @@ class HipKrylov:
     is one all-reduce of a two-double device tensor, and the only host-visible step of an iteration is reading the
     scalar block back."""
 
-    def __init__(self, op):
+    def __init__(self, op, chunk=8):
         self.op = op
         self.h = op.backend._h
         self.sums = None
+        self.chunk = chunk           # BiCGSTAB iterations enqueued per read of the scalar block
 
     def _step(self, step, n, vecs, rtol=0.0, atol=0.0, f32=False):
         arr = (C.c_void_p * 7)(*[(v.data_ptr() if v is not None else None) for v in vecs])
@@ -642,33 +767,52 @@ class HipKrylov:
             self._step = _plain
 
     def _bicgstab_loop(self, V, n, tol, atol, maxiter, stats):
+        """Every kernel of an iteration -- the fused BLAS-1 groups, their finishing kernels and the stage kernels of both
+        J.v applications -- is gated on the handle's device word, which the iteration's last kernel clears on convergence,
+        breakdown or a non-finite |r|^2 (the single-GPU loop's gate, csrc/vec_kernels.hpp): `self.chunk` iterations are
+        enqueued per read of the scalar block, the launches behind the last real iteration are no-ops (their exchanges and
+        all-reduces move stale data that nothing reads), and iterates and iteration count are those of the
+        one-iteration-per-read loop.  (J - I) v is the two stage launches of J v with the "- v" folded into the unpack
+        of the second exchange (jvp_minus) -- no subtraction or copy pass over the shard."""
         op = self.op
         b, r, rhat, p, q, t, x = V
-        self._step(KS_INIT, n, V)
+        G = KS_GATED
+        gate = op.backend.gate_tensor("krylov")
+        self._step(KS_INIT | G, n, V)
         op.allreduce_sum(self.sums[:1])
-        self._step(KS_INIT_FIN, n, V, tol, atol)
+        self._step(KS_INIT_FIN | G, n, V, tol, atol)
         sc = self.scalars()
+        host_syncs = 1
         k = 0
+        chunk = max(int(self.chunk), 1)
         while sc[SC_RR] > sc[SC_ATOL2] and k < maxiter:
-            self._step(KS_UPDATE_P, n, V)
-            q.copy_(op.jvp(p).sub_(p))
-            self._step(KS_DOT_RQ, n, V)
-            op.allreduce_sum(self.sums[:1])
-            self._step(KS_ALPHA_S, n, V)                 # alpha, s = r - alpha q (in r), local <s, s>
-            op.allreduce_sum(self.sums[:1])
-            self._step(KS_S_FIN, n, V)
-            t.copy_(op.jvp(r).sub_(r))
-            self._step(KS_DOT_TS, n, V)
-            op.allreduce_sum(self.sums[:2])
-            self._step(KS_OMEGA_XR, n, V)                # omega, x and r updates, local <r, r>, <rhat, r>
-            op.allreduce_sum(self.sums[:2])
-            self._step(KS_ITER_FIN, n, V)
-            sc = self.scalars()                          # the one host-visible step of the iteration
+            nq = min(chunk, maxiter - k)
+            it0 = sc[SC_ITERS]
+            for _ in range(nq):
+                self._step(KS_UPDATE_P | G, n, V)
+                op.jvp_minus(p, q, gate=gate)
+                self._step(KS_DOT_RQ | G, n, V)
+                op.allreduce_sum(self.sums[:1])
+                self._step(KS_ALPHA_S | G, n, V)                 # alpha, s = r - alpha q (in r), local <s, s>
+                op.allreduce_sum(self.sums[:1])
+                self._step(KS_S_FIN | G, n, V)
+                op.jvp_minus(r, t, gate=gate)
+                self._step(KS_DOT_TS | G, n, V)
+                op.allreduce_sum(self.sums[:2])
+                self._step(KS_OMEGA_XR | G, n, V)                # omega, x and r updates, local <r, r>, <rhat, r>
+                op.allreduce_sum(self.sums[:2])
+                self._step(KS_ITER_FIN | G, n, V)
+            sc = self.scalars()                                  # the one host-visible step of the chunk
+            host_syncs += 1
+            done = int(round(sc[SC_ITERS] - it0))                # iterations that really ran
             if stats is not None:
-                stats["matvecs"] = stats.get("matvecs", 0) + 2
-            if sc[SC_BREAK] != 0.0 or not np.isfinite(sc[SC_RR]):
+                stats["matvecs"] = stats.get("matvecs", 0) + 2 * done
+            k += done
+            if done < nq or sc[SC_BREAK] != 0.0 or not np.isfinite(sc[SC_RR]):
                 break
-            k += 1
+        if stats is not None:
+            stats["krylov_host_syncs"] = stats.get("krylov_host_syncs", 0) + host_syncs
+            stats["krylov_iters"] = stats.get("krylov_iters", 0) + k
         return x
 
     def residual(self, Tw, w):

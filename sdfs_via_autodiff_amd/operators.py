@@ -202,6 +202,11 @@ class KoopmansOperator:
         return n_iter.value, self._solve_info(rc, n_apply, err, record_errors)
 
     # -- profiling counters (bench.py) -----------------------------------------
+    def stream_copy_dev(self, src_ptr, dst_ptr, n):
+        """dst[0:n] = src[0:n] (device doubles) by the library's streaming copy, on the handle's stream: the ceiling of a
+        pass that reads and writes every grid point once (bench.py's copy_ceiling_GBps)."""
+        check(lib.sdfs_stream_copy_dev(self._h, src_ptr, dst_ptr, int(n)), self._h)
+
     def set_profiling(self, on):
         check(lib.sdfs_set_profiling(self._h, int(on)), self._h)
 

@@ -159,9 +159,21 @@ def body(rank, model, shapes, use_hip, plain=False):
         if max(out["T"], out["Tlin"], out["jvp"]) > 1e-6:      # wrong operator: do not start the solver loops
             return out
         # distributed Newton (tight inner tolerance) vs the oracle's polished fixed point
+        nst = {}
         x_loc, n = D.newton_sharded(op, op.scatter_from_full(torch.full(shapes, 800.0, dtype=torch.float64)).to(dev),
-                                    tol=1e-10, max_iter=30, inner_rtol=1e-9, inner_atol=0.0)
+                                    tol=1e-10, max_iter=30, inner_rtol=1e-9, inner_atol=0.0, stats=nst)
         x = op.gather_full(x_loc).cpu().numpy()
+        if use_hip:
+            # device-gated BiCGSTAB: one read of the scalar block per chunk of iterations; chunk = 1 gives the same iterates
+            out["newton_krylov_syncs"] = nst.get("krylov_host_syncs", -1)
+            out["newton_krylov_iters"] = nst.get("krylov_iters", -1)
+            op._krylov.chunk = 1
+            nst1 = {}
+            x1_loc, n1 = D.newton_sharded(op, op.scatter_from_full(torch.full(shapes, 800.0, dtype=torch.float64)).to(dev),
+                                          tol=1e-10, max_iter=30, inner_rtol=1e-9, inner_atol=0.0, stats=nst1)
+            op._krylov.chunk = 8
+            out["newton_chunk1_diff"] = float((x1_loc - x_loc).abs().max().item())
+            out["newton_chunk1_iters"] = (n1, nst1.get("krylov_iters", -1))
         xs = osol.newton_polish(T, J, x.copy())
         out["newton_err"] = float(np.max(np.abs(x - xs)))
         out["newton_iters"] = n
@@ -177,9 +189,23 @@ def body(rank, model, shapes, use_hip, plain=False):
         x0 = op.n_exchanges
         sa_tol, sa_max = (2e-2, 4000) if plain else (1e-3, 120)
         ce = 7
-        xa_loc, na = D.successive_approx_sharded(op, op.scatter_from_full(torch.full(shapes, 800.0, dtype=torch.float64)).to(dev),
-                                                 tol=sa_tol, max_iter=sa_max, errors=errs, stats=stats, check_every=ce)
+        w0 = op.scatter_from_full(torch.full(shapes, 800.0, dtype=torch.float64)).to(dev)
+        w0_before = w0.clone()
+        xa_loc, na = D.successive_approx_sharded(op, w0, tol=sa_tol, max_iter=sa_max, errors=errs, stats=stats, check_every=ce)
         out["sa_exchanges"] = op.n_exchanges - x0
+        # ownership: the caller's input is untouched, and the result is no buffer the operator (or a later solve) writes --
+        # it survives an application, a J.v and a solve from another start (with and without the mirror phase)
+        out["sa_input_kept"] = bool(torch.equal(w0, w0_before))
+        xa_snapshot = xa_loc.clone()
+        op.apply_T(w_loc); op.jvp(v_loc)
+        for mir in (True, False):
+            D.successive_approx_sharded(op, op.scatter_from_full(torch.full(shapes, 650.0, dtype=torch.float64)).to(dev),
+                                        tol=sa_tol, max_iter=min(sa_max, 9), check_every=4, mirror=mir)
+        w1 = op.scatter_from_full(torch.full(shapes, 800.0, dtype=torch.float64)).to(dev)
+        w1_before = w1.clone()
+        D.successive_approx_sharded(op, w1, tol=sa_tol, max_iter=5, check_every=2, mirror=False)
+        out["sa_input_kept"] = out["sa_input_kept"] and bool(torch.equal(w1, w1_before))
+        out["sa_result_kept"] = bool(torch.equal(xa_loc, xa_snapshot))
         out["sa_mirror_iters"] = stats.get("mirror_iters", 0)
         out["sa_host_syncs"] = stats.get("host_syncs", -1)
         out["sa_check_every"] = ce
@@ -195,8 +221,15 @@ def body(rank, model, shapes, use_hip, plain=False):
         # same iteration count and iterate on these small, well-conditioned histories
         a_tol = 1e-6
         st = {}
+        a_ce = 5
         xa2, n_and = D.anderson_sharded(op, op.scatter_from_full(torch.full(shapes, 800.0, dtype=torch.float64)).to(dev),
-                                        tol=a_tol, max_iter=3000, stats=st)
+                                        tol=a_tol, max_iter=3000, stats=st, check_every=a_ce)
+        if use_hip:
+            out["anderson_host_syncs"] = st.get("host_syncs", -1)
+            out["anderson_check_every"] = a_ce
+            xa3, n_and1 = D.anderson_sharded(op, op.scatter_from_full(torch.full(shapes, 800.0, dtype=torch.float64)).to(dev),
+                                             tol=a_tol, max_iter=3000, check_every=1)
+            out["anderson_check1"] = (n_and1, float((xa3 - xa2).abs().max().item()))
         xo2, n_ando = osol.anderson_solver(T, np.full(shapes, 800.0), tol=a_tol, max_iter=3000, verbose=False)
         out["anderson_iters"] = (n_and, n_ando)
         out["anderson_err"] = float(np.max(np.abs(op.gather_full(xa2).cpu().numpy() - xo2)))

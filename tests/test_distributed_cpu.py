@@ -53,6 +53,18 @@ def test_sharded_operator_world2_gloo(model, shapes):
     check_sa_gating_and_anderson(out)
 
 
+def check_device_gated_newton_and_anderson(out):
+    """HIP stage backend: BiCGSTAB reads its scalar block once per chunk of iterations (HipKrylov.chunk = 8), not per
+    iteration, with the iterates of the one-iteration-per-read loop; Anderson reads its device state every check_every
+    passes."""
+    ks, ki, ns = out["newton_krylov_syncs"], out["newton_krylov_iters"], out["newton_iters"]
+    assert ki > 0 and ks <= ki // 8 + 2 * ns, out            # per solve: one read behind INIT_FIN + one per chunk
+    assert out["newton_chunk1_diff"] == 0.0 and out["newton_chunk1_iters"] == [ns, ki], out
+    na = out["anderson_iters"][0]
+    assert out["anderson_host_syncs"] <= na // out["anderson_check_every"] + 2, out
+    assert out["anderson_check1"] == [na, 0.0], out          # chunked loop = one-pass-per-read loop, bit for bit
+
+
 def check_sa_gating_and_anderson(out):
     """Device-gated loop: one host read per check_every iterations (+ one per phase), the same iterates as the
     one-read-per-iteration form; Anderson: the oracle's fixed point, and its iteration count within a quarter."""
@@ -60,6 +72,7 @@ def check_sa_gating_and_anderson(out):
     assert out["sa_host_syncs"] <= na // out["sa_check_every"] + 3, out
     assert out["sa_n_errors"] == na, out
     assert out["sa_check1"][0] == na and out["sa_check1"][1] == 0.0, out
+    assert out["sa_input_kept"] and out["sa_result_kept"], out
     n_and, n_ando = out["anderson_iters"]
     assert out["anderson_resid"] < 1e-5, out
     # (the iteration path follows the last bits of the ill-conditioned Gram matrix, which the sharded loop adds in an
@@ -116,6 +129,8 @@ def test_sharded_hip_stages_world2(model, shapes):
     assert out["newton_err"] < 1e-8 and out["newton_iters"] < 20, out
     assert out["newton_f32_err"] < 1e-8 and out["newton_f32_iters"] < 25, out      # fp32 Krylov storage, fp64 fixed point
     assert out["sa_iters"][0] == out["sa_iters"][1] and out["sa_err"] < 1e-8, out
+    check_device_gated_newton_and_anderson(out)
+    check_sa_gating_and_anderson(out)
 
 
 @pytest.mark.gpu
@@ -156,6 +171,7 @@ def test_sharded_layer_on_rccl_world1(model, shapes):
     na, no = out["sa_iters"]
     assert na == no and out["sa_err"] < 1e-8, out
     check_sa_gating_and_anderson(out)
+    check_device_gated_newton_and_anderson(out)
 
 
 @pytest.mark.gpu
@@ -182,4 +198,10 @@ def test_pack_blocks_kernel():
         be.pack_blocks(back, packed, axis, offs, unpack=True)
         torch.cuda.synchronize()
         assert torch.equal(back, x), (shp, axis, world)
+        # unpack with the Krylov operator's "- v" folded in (sdfs_unpack_blocks_sub)
+        sub = torch.rand(shp, generator=gen, dtype=torch.float64).to(dt).cuda()
+        back2 = torch.zeros_like(x)
+        assert be.unpack_blocks_sub(back2, packed, sub, axis, offs)
+        torch.cuda.synchronize()
+        assert torch.equal(back2, x - sub), (shp, axis, world)
     be.close()

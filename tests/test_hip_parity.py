@@ -292,6 +292,56 @@ def test_device_pow_accuracy_vs_long_double(S):
     assert out[0] == np.inf and np.isnan(out[1]) and out[2] == 0.0 and np.isnan(out[3]) and out[4] == np.inf
 
 
+def test_device_powy_accuracy_vs_long_double(S):
+    """The routine the kernels use when the exponent is fixed for a launch (pre-scaled tables, csrc/pass_kernel.hpp powy)
+    against x87 long double: degree 7 as accurate as the general routine for any exponent, degree 6 (the form inside the
+    operator kernels) within |y| * 1.04e-17 of it -- which the closing 1/theta power divides out of T w."""
+    import ctypes
+    from sdfs_via_autodiff_amd import _lib
+    rng = np.random.default_rng(12)
+    xs = np.concatenate([
+        np.exp(rng.uniform(np.log(1e-130), np.log(1e8), 200000)),
+        rng.uniform(100.0, 1000.0, 100000),
+        1.0 + rng.uniform(-1e-3, 1e-3, 20000),
+        np.array([1.0, 2.0, 0.5, 800.0, 0.7055, 1.411, 1e-300, 5e-324, 2.2250738585072014e-308, 1e300]),
+    ])
+    for deg, bound in ((7, lambda y: 4.5e-16), (6, lambda y: 3.0e-16 + 1.6e-17 * abs(y))):
+        for y in (-16.0216, -36.03, 1 / -16.0216, 1 / -36.03, -17.0216, -37.03, 1 / -16.0216 - 1, 2.5, 64.0, 0.999):
+            out = np.empty_like(xs)
+            rc = _lib.lib.sdfs_debug_powy(xs.ctypes.data, ctypes.c_double(y), out.ctypes.data, xs.size, deg, 0)
+            assert rc == 0
+            want = np.power(xs.astype(np.longdouble), np.longdouble(y))
+            fin = np.isfinite(want.astype(np.float64)) & (want.astype(np.float64) > 1e-300)
+            rel = np.abs((out[fin].astype(np.longdouble) - want[fin]) / want[fin]).astype(np.float64)
+            assert rel.max() < bound(y), (deg, y, rel.max(), xs[fin][rel.argmax()])
+            big = ~np.isfinite(want.astype(np.float64))
+            assert np.all(np.isinf(out[big]))
+            zero = want.astype(np.float64) == 0.0
+            assert np.all(out[zero] == 0.0)
+        special = np.array([0.0, -1.0, np.inf, np.nan, -0.0])
+        out = np.empty_like(special)
+        _lib.lib.sdfs_debug_powy(special.ctypes.data, ctypes.c_double(-16.0216), out.ctypes.data, special.size, deg, 0)
+        assert out[0] == np.inf and np.isnan(out[1]) and out[2] == 0.0 and np.isnan(out[3]) and out[4] == np.inf
+    out = np.empty(4)
+    assert _lib.lib.sdfs_debug_powy(xs.ctypes.data, ctypes.c_double(2.0), out.ctypes.data, 4, 5, 0) != 0      # degrees 0, 6, 7 only
+
+
+def test_stream_copy_entry_point(S):
+    """sdfs_stream_copy_dev (bench.py's copy ceiling): an exact copy for even and odd lengths, arguments checked."""
+    import torch
+    from sdfs_via_autodiff_amd import _lib
+    T, _, _ = make_op(S, "ssy", (3, 4, 5, 6))
+    for n in (1, 2, 7, 4096, 2048 * 8 * 3 + 5):
+        a = torch.arange(n, dtype=torch.float64, device="cuda") * 1.25 + 0.5
+        b = torch.full((n + 2,), -1.0, dtype=torch.float64, device="cuda")
+        T.stream_copy_dev(a.data_ptr(), b.data_ptr(), n)
+        T.synchronize()
+        assert torch.equal(b[:n], a) and float(b[n]) == -1.0 and float(b[n + 1]) == -1.0
+    with pytest.raises(_lib.SdfsError):
+        T.stream_copy_dev(a.data_ptr() + 8, b.data_ptr(), 4)          # not 16-byte aligned
+    T.close()
+
+
 def test_in_place_apply_and_two_handles(S):
     """Device-pointer entry points: out may alias the input; handles are independent."""
     import torch

@@ -23,9 +23,48 @@ __device__ int g_stamp_it;
 #define SDFS_STREAM_STAMP_DECL int stamp_it = (blockIdx.x == 8 && __builtin_nontemporal_load(&g_stamp_it) == 0) ? 0 : 1000
 #define SDFS_STREAM_STAMP(i) do { if (threadIdx.x == 0 && stamp_it < 12) g_stamps[stamp_it * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
 #define SDFS_STREAM_STAMP_NEXT do { stamp_it++; } while (0)
+#ifdef KB_OLD_POW
+// A/B of the power routines inside one process: a COPY of csrc/ (tools/probes/kb.sh makes it: #pragma once keys on the
+// file) compiled into namespace sdfs_old with the general routine of rounds 1-3
+#ifndef KB_OLD_POWY
+#define KB_OLD_POWY 0
+#endif
+#ifndef KB_OLD_NT
+#define KB_OLD_NT 3
+#endif
+#define SDFS_POWY KB_OLD_POWY
+#define SDFS_NT KB_OLD_NT
+#define sdfs sdfs_old
+#include "kb_oldpow/stream_kernels.hpp"
+#undef sdfs
+#undef SDFS_POWY
+#undef SDFS_NT
+#endif
 #include "../../sdfs_via_autodiff_amd/csrc/stream_kernels.hpp"
 
 using namespace sdfs;
+
+// streaming copy: every lane keeps U 16-byte loads in flight; a workgroup walks chunks of 256 * U units (grid-stride)
+template <int U, int NT>
+__global__ void __launch_bounds__(256) copy_stream_kernel(const double2* __restrict__ in, double2* __restrict__ out, long long units) {
+  typedef double v2 __attribute__((ext_vector_type(2)));
+  const v2* src = reinterpret_cast<const v2*>(in);
+  v2* dst = reinterpret_cast<v2*>(out);
+  const long long chunk = 256LL * U;
+  for (long long c0 = (long long)blockIdx.x * chunk; c0 < units; c0 += (long long)gridDim.x * chunk) {
+    v2 v[U];
+#pragma unroll
+    for (int k = 0; k < U; ++k) {
+      const long long i = c0 + threadIdx.x + 256LL * k;
+      if (i < units) v[k] = (NT & 1) ? __builtin_nontemporal_load(src + i) : src[i];
+    }
+#pragma unroll
+    for (int k = 0; k < U; ++k) {
+      const long long i = c0 + threadIdx.x + 256LL * k;
+      if (i < units) { if (NT & 2) __builtin_nontemporal_store(v[k], dst + i); else dst[i] = v[k]; }
+    }
+  }
+}
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
 
@@ -133,8 +172,8 @@ int main(int argc, char** argv) {
   // ---- pass 1: slices over the two fastest axes ------------------------------------------------------
   SliceDesc sd; memset(&sd, 0, sizeof sd);
   sd.nslices = N / n2; sd.Qf = Q[0]; sd.Qe = Q[1]; sd.theta = theta;
-  const size_t slds = slice_lds_bytes(n);
-  const long long swt = (sd.nslices + slice_tile_slices(n) - 1) / slice_tile_slices(n);
+  const size_t slds = slice_lds_bytes(n, S_MID);
+  const long long swt = (sd.nslices + slice_tile_slices(n, S_MID) - 1) / slice_tile_slices(n, S_MID);
   const unsigned sgrid0 = (unsigned)((swt + 3) / 4);
   typedef std::function<void()> Launch;
   // registers a candidate; `ref` (if given) is the launch whose output `refbuf` the candidate's `out` is compared with
@@ -187,67 +226,131 @@ int main(int argc, char** argv) {
   if (n != 20) { printf("only n = 20 is wired up\n"); return 0; }
   const LineDesc L2 = mk_line(0), L3 = mk_line(2);
   const unsigned C = (unsigned)ncu;
+  printf("power routine: %s; non-temporal hint on the grid streams: %d (bit 0 loads, bit 1 stores)\n", SDFS_POWY ? "powy (pre-scaled tables, round 4)" : "pow_fast_try (general, rounds 1-3)", SDFS_NT);
+#ifdef KB_OLD_POW
+  printf("sdfs_old:: kernels: power routine %s, non-temporal hint %d\n", KB_OLD_POWY ? "powy" : "general (rounds 1-3)", KB_OLD_NT);
+#endif
+  // ---- round 4 (a): what a streaming copy of one grid reaches on this box (the ceiling of a 16 B/point pass) ----
+  {
+    const double bytes = 16.0 * N;
+    const long long units = N / 2;
+    auto cp = [&](auto kern, unsigned grid, const char* name) {
+      add(name, [=]() { hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, 0, (const double2*)w, (double2*)outA, units); }, bytes, nullptr, nullptr, nullptr);
+    };
+    cp(copy_stream_kernel<4, 0>, 8u * C, "copy: grid-stride, 4 x 16 B per lane in flight, 8 wg/CU");
+    cp(copy_stream_kernel<8, 0>, 4u * C, "copy: grid-stride, 8 x 16 B per lane in flight, 4 wg/CU");
+    cp(copy_stream_kernel<8, 0>, 8u * C, "copy: grid-stride, 8 x 16 B per lane in flight, 8 wg/CU");
+    cp(copy_stream_kernel<13, 0>, 3u * C, "copy: grid-stride, 13 x 16 B per lane (a line tile), 3 wg/CU");
+    cp(copy_stream_kernel<16, 0>, 4u * C, "copy: grid-stride, 16 x 16 B per lane in flight, 4 wg/CU");
+    cp(copy_stream_kernel<8, 3>, 4u * C, "copy: grid-stride, 8 x 16 B, nontemporal, 4 wg/CU");
+    cp(copy_stream_kernel<8, 3>, 8u * C, "copy: grid-stride, 8 x 16 B, nontemporal, 8 wg/CU");
+    cp(copy_stream_kernel<16, 3>, 4u * C, "copy: grid-stride, 16 x 16 B, nontemporal, 4 wg/CU");
+    {
+      const unsigned grid1 = (unsigned)((units + 256 * 8 - 1) / (256 * 8));
+      cp(copy_stream_kernel<8, 0>, grid1, "copy: one chunk per workgroup, 8 x 16 B per lane");
+      cp(copy_stream_kernel<8, 3>, grid1, "copy: one chunk per workgroup, 8 x 16 B, nontemporal");
+    }
+    {
+      const unsigned grid1 = (unsigned)((units + 256 * 8 - 1) / (256 * 8));
+      cp(copy_stream_kernel<8, 1>, grid1, "copy: one chunk per workgroup, 8 x 16 B, nontemporal loads only");
+      cp(copy_stream_kernel<8, 2>, grid1, "copy: one chunk per workgroup, 8 x 16 B, nontemporal stores only");
+    }
+    add("copy: hipMemcpyAsync device to device", [=]() { hipMemcpyAsync(outA, w, (size_t)N * 8, hipMemcpyDeviceToDevice, 0); }, bytes, nullptr, nullptr, nullptr);
+    run_all(rounds);
+  }
   // S = w^theta contracted over (e, f): the input of the later passes
   slice_launch((slice_fn)slice_kernel<20, S_TFIRST, false>, sgrid0, w, tmpA)();
   CK(hipDeviceSynchronize());
   {
+    // ---- pass 1: the library's form, and the LDS-conflict variants (b): padded rows (22 doubles) at 1 / 2 / 4 waves
+    // per workgroup (LDS per wave 12.8 -> 14.08 KB: 11 / 10 / 8 waves per CU against 12) -----------------------------
     Launch base = slice_launch((slice_fn)slice_kernel<20, S_TFIRST, false>, sgrid0, w, outA);
-    add("slice_kernel<20,TFIRST> baseline", base, b2, nullptr, nullptr, nullptr);
-    // (the wave-walking slice_stream_kernel measured here in round 3 lost 5 % and was dropped: profiles/round3_kernel_bench.txt)
-    Launch basem = slice_launch((slice_fn)slice_kernel<20, S_MID, false>, sgrid0, w, outA);
-    add("slice_kernel<20,MID> baseline", basem, b2, nullptr, nullptr, nullptr);
-    run_all(rounds);
-  }
-  {
-    Launch base = line_launch((line_fn)line_kernel<20, L_MID, false, true, false>, L2, (unsigned)L2.ntiles, tmpA, outA, nullptr, false);
-    add("line_kernel<20,MID> pair (a,b) baseline", base, b2, nullptr, nullptr, nullptr);
-    for (unsigned wg : {3u * C, 2u * C})
-      add("line_stream<20,MID,3> pair (a,b) wgs " + std::to_string(wg), line_launch((line_fn)line_stream_kernel<20, L_MID, 3>, L2, wg, tmpA, outB, nullptr, false), b2, outB, base, outA);
-    Launch base3 = line_launch((line_fn)line_kernel<20, L_MID, false, true, false>, L3, (unsigned)L3.ntiles, tmpA, outA, nullptr, false);
-    add("line_kernel<20,MID> pair (c,d) baseline", base3, b2, nullptr, nullptr, nullptr);
-    for (unsigned wg : {3u * C, 2u * C})
-      add("line_stream<20,MID,3> pair (c,d) wgs " + std::to_string(wg), line_launch((line_fn)line_stream_kernel<20, L_MID, 3>, L3, wg, tmpA, outB, nullptr, false), b2, outB, base3, outA);
-    run_all(rounds);
-  }
-  {
-    // row spacing sweep: the same line kernels on synthetic geometries (400 rows per tile, spacing lrest doubles)
-    for (long long lr : {400LL, 1600LL, 8000LL, 32000LL, 160000LL}) {
-      LineDesc L = L2; L.lrest = lr; L.nchunks = (int)(lr / LINE_R); L.nouter = N / (n2 * lr); L.ntiles = L.nouter * L.nchunks;
-      add("line_kernel<20,MID> rows " + std::to_string(lr * 8) + " B apart", line_launch((line_fn)line_kernel<20, L_MID, false, true, false>, L, (unsigned)L.ntiles, tmpA, outA, nullptr, false), b2, nullptr, nullptr, nullptr);
-      add("line_stream<20,MID,3> rows " + std::to_string(lr * 8) + " B apart, wgs 768", line_launch((line_fn)line_stream_kernel<20, L_MID, 3>, L, 3 * C, tmpA, outB, nullptr, false), b2, nullptr, nullptr, nullptr);
-    }
-    run_all(rounds);
-  }
-  {
-    Launch base = line_launch((line_fn)line_kernel<20, L_TLAST, false, true, false>, L3, (unsigned)L3.ntiles, tmpA, outA, w, true);
-    add("line_kernel<20,TLAST> pair (c,d) baseline", base, b3, nullptr, nullptr, nullptr);
-    add("line_stream<20,TLAST,2> pair (c,d) wgs " + std::to_string(2 * C), line_launch((line_fn)line_stream_kernel<20, L_TLAST, 2>, L3, 2 * C, tmpA, outB, w, true), b3, outB, base, outA);
-    add("line_stream<20,TLAST,3,OLDPF,A3F,nonpersist> pair (c,d)", line_launch((line_fn)line_stream_kernel<20, L_TLAST, 3, true, 256, false, true>, L3, (unsigned)L3.ntiles, tmpA, outB, w, true), b3, outB, base, outA);
-    add("line_stream<20,TLAST,2,OLDPF,A3F,persistent> pair (c,d) wgs " + std::to_string(2 * C), line_launch((line_fn)line_stream_kernel<20, L_TLAST, 2, true, 256, true, true>, L3, 2 * C, tmpA, outB, w, true), b3, outB, base, outA);
-    add("line_stream<20,TLAST,2,A3F,persistent (window)> pair (c,d) wgs " + std::to_string(2 * C), line_launch((line_fn)line_stream_kernel<20, L_TLAST, 2, false, 256, true, true>, L3, 2 * C, tmpA, outB, w, true), b3, outB, base, outA);
-    add("line_stream<20,TLAST,3,OLDPF,256,nonpersist> pair (c,d)", line_launch((line_fn)line_stream_kernel<20, L_TLAST, 3, true, 256, false>, L3, (unsigned)L3.ntiles, tmpA, outB, w, true), b3, outB, base, outA);
-    add("line_stream<20,TLAST,2,OLDPF,256,nonpersist> pair (c,d)", line_launch((line_fn)line_stream_kernel<20, L_TLAST, 2, true, 256, false>, L3, (unsigned)L3.ntiles, tmpA, outB, w, true), b3, outB, base, outA);
-    add("line_stream<20,TLAST,1,OLDPF,512,nonpersist> pair (c,d)", line_launch((line_fn)line_stream_kernel<20, L_TLAST, 1, true, 512, false>, L3, (unsigned)L3.ntiles, tmpA, outB, w, true, 512), b3, outB, base, outA);
-    add("line_stream<20,TLAST,2,OLDPF,512,nonpersist> pair (c,d)", line_launch((line_fn)line_stream_kernel<20, L_TLAST, 2, true, 512, false>, L3, (unsigned)L3.ntiles, tmpA, outB, w, true, 512), b3, outB, base, outA);
-    add("line_stream<20,TLAST,1,OLDPF,512thr> pair (c,d) wgs " + std::to_string(C), line_launch((line_fn)line_stream_kernel<20, L_TLAST, 1, true, 512>, L3, C, tmpA, outB, w, true, 512), b3, outB, base, outA);
-    add("line_stream<20,TLAST,1,512thr> pair (c,d) wgs " + std::to_string(C), line_launch((line_fn)line_stream_kernel<20, L_TLAST, 1, false, 512>, L3, C, tmpA, outB, w, true, 512), b3, outB, base, outA);
-    add("line_stream<20,TLAST,2,OLDPF> pair (c,d) wgs " + std::to_string(2 * C), line_launch((line_fn)line_stream_kernel<20, L_TLAST, 2, true>, L3, 2 * C, tmpA, outB, w, true), b3, outB, base, outA);
-    dump_stamps("line_stream<20,TLAST,2,OLDPF> wgs 512", line_launch((line_fn)line_stream_kernel<20, L_TLAST, 2, true>, L3, 2 * C, tmpA, outB, w, true));
-    dump_stamps("line_stream<20,TLAST,1,OLDPF,512thr> wgs 256", line_launch((line_fn)line_stream_kernel<20, L_TLAST, 1, true, 512>, L3, C, tmpA, outB, w, true, 512));
-    dump_stamps("line_stream<20,TLAST,2> wgs 512", line_launch((line_fn)line_stream_kernel<20, L_TLAST, 2>, L3, 2 * C, tmpA, outB, w, true));
-    dump_stamps("line_stream<20,MID,3> (c,d) wgs 512", line_launch((line_fn)line_stream_kernel<20, L_MID, 3>, L3, 2 * C, tmpA, outB, nullptr, false));
-    dump_stamps("line_stream<20,MID,3> (a,b) wgs 512", line_launch((line_fn)line_stream_kernel<20, L_MID, 3>, L2, 2 * C, tmpA, outB, nullptr, false));
+    add("slice_kernel<20,TFIRST> 4 waves/wg, rows of 20 (library)", base, b2, nullptr, nullptr, nullptr);
+    auto sl = [&](slice_fn fn, int wv, bool pad, int g = 4) -> Launch {
+      const size_t lds = (size_t)wv * g * 20 * (pad ? 22 : 20) * 8;
+      hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      SliceIO io; memset(&io, 0, sizeof io); io.in = w; io.out = outB; io.sched = sched;
+      const long long wt = (sd.nslices + g - 1) / g;
+      const unsigned grid = (unsigned)((wt + wv - 1) / wv);
+      return [=]() { hipLaunchKernelGGL(fn, dim3(grid), dim3(64 * wv), lds, 0, sd, io); };
+    };
+#ifdef KB_OLD_POW
     {
-      // the fused end + start kernel of the SA loop (line_kernel<L_TFUSED>).  Its streamed twin (side stream loaded
-      // early, fully unrolled epilogue) was measured here in round 3: 0.75 against 0.57 ms -- the compiler keeps the
-      // loop rolled around the two power routines and parks the prefetched tile in scratch; dropped.
-      hipFuncSetAttribute((const void*)line_kernel<20, L_TFUSED, false, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)llds);
-      LineIO io; memset(&io, 0, sizeof io); io.in = tmpA; io.out = outB; io.old = w; io.resid = resid; io.aux_out = tmpB; io.sched = sched;
-      const unsigned grid = (unsigned)L3.ntiles;
-      add("line_kernel<20,TFUSED> pair (c,d)", [=]() { hipLaunchKernelGGL((line_kernel<20, L_TFUSED, false, true, false>), dim3(grid), dim3(256), llds, 0, L3, io); }, 32.0 * N, nullptr, nullptr, nullptr);
+      typedef void (*oslice_fn)(const sdfs_old::SliceDesc, const sdfs_old::SliceIO);
+      oslice_fn fn = (oslice_fn)sdfs_old::slice_kernel<20, sdfs_old::S_TFIRST, false>;
+      hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)slds);
+      sdfs_old::SliceDesc so; memcpy(&so, &sd, sizeof so);
+      sdfs_old::SliceIO io; memset(&io, 0, sizeof io); io.in = w; io.out = outB; io.sched = sched;
+      add("sdfs_old::slice_kernel<20,TFIRST>", [=]() { hipLaunchKernelGGL(fn, dim3(sgrid0), dim3(256), slds, 0, so, io); }, b2, outB, base, outA);
     }
+#endif
+    // (d) a wave walking tiles, the next tile's loads issued as soon as the current one is parked
+    add("slice_walk<20,TFIRST> (next tile in flight under the contractions) 3 waves/SIMD wgs " + std::to_string(3 * C), slice_launch((slice_fn)slice_walk_kernel<20, S_TFIRST>, 3 * C, w, outB), b2, outB, base, outA);
+    add("slice_walk<20,TFIRST> Q fragments per tile, 3 waves/SIMD wgs " + std::to_string(3 * C), slice_launch((slice_fn)slice_walk_kernel<20, S_TFIRST, 3, true>, 3 * C, w, outB), b2, outB, base, outA);
+    add("slice_walk<20,TFIRST> power in place in LDS, 3 waves/SIMD wgs " + std::to_string(3 * C), slice_launch((slice_fn)slice_walk_kernel<20, S_TFIRST, 3, false, true>, 3 * C, w, outB), b2, outB, base, outA);
+    add("slice_walk<20,TFIRST> power in place in LDS, Q fragments per tile, 3 waves/SIMD wgs " + std::to_string(3 * C), slice_launch((slice_fn)slice_walk_kernel<20, S_TFIRST, 3, true, true>, 3 * C, w, outB), b2, outB, base, outA);
+    add("slice_walk<20,TFIRST> power in place in LDS, one element at a time, 3 waves/SIMD wgs " + std::to_string(3 * C), slice_launch((slice_fn)slice_walk_kernel<20, S_TFIRST, 3, false, true, true>, 3 * C, w, outB), b2, outB, base, outA);
+    add("slice_walk<20,TFIRST> 2 waves/SIMD wgs " + std::to_string(2 * C), slice_launch((slice_fn)slice_walk_kernel<20, S_TFIRST, 2>, 2 * C, w, outB), b2, outB, base, outA);
+    add("slice_walk<20,TFIRST> Q fragments per tile, 2 waves/SIMD wgs " + std::to_string(2 * C), slice_launch((slice_fn)slice_walk_kernel<20, S_TFIRST, 2, true>, 2 * C, w, outB), b2, outB, base, outA);
+    // (c) occupancy: three slices per wave tile (9.6 KB of LDS per wave: 16 waves per CU instead of 12; the last of its four
+    // column tiles repeats four columns: +6.7 % MFMA work)
+    add("slice_kernel<20,TFIRST> 4 waves/wg, 3 slices per wave tile, 4 waves/SIMD", sl((slice_fn)slice_kernel<20, S_TFIRST, false, 4, false, 3, 4>, 4, false, 3), b2, outB, base, outA);
+    add("slice_kernel<20,TFIRST> 2 waves/wg, 3 slices per wave tile, 4 waves/SIMD", sl((slice_fn)slice_kernel<20, S_TFIRST, false, 2, false, 3, 4>, 2, false, 3), b2, outB, base, outA);
+    add("slice_kernel<20,TFIRST> 1 wave/wg, 3 slices per wave tile, 4 waves/SIMD", sl((slice_fn)slice_kernel<20, S_TFIRST, false, 1, false, 3, 4>, 1, false, 3), b2, outB, base, outA);
+    add("slice_kernel<20,TFIRST> 1 wave/wg, 3 slices, rows padded to 22, 4 waves/SIMD", sl((slice_fn)slice_kernel<20, S_TFIRST, false, 1, true, 3, 4>, 1, true, 3), b2, outB, base, outA);
+    add("slice_kernel<20,TFIRST> 4 waves/wg, 2 slices per wave tile, 5 waves/SIMD", sl((slice_fn)slice_kernel<20, S_TFIRST, false, 4, false, 2, 5>, 4, false, 2), b2, outB, base, outA);
+    add("slice_kernel<20,TFIRST> 1 wave/wg, rows of 20", sl((slice_fn)slice_kernel<20, S_TFIRST, false, 1, false>, 1, false), b2, outB, base, outA);
+    add("slice_kernel<20,TFIRST> 2 waves/wg, rows of 20", sl((slice_fn)slice_kernel<20, S_TFIRST, false, 2, false>, 2, false), b2, outB, base, outA);
+    add("slice_kernel<20,TFIRST> 1 wave/wg, rows padded to 22", sl((slice_fn)slice_kernel<20, S_TFIRST, false, 1, true>, 1, true), b2, outB, base, outA);
+    add("slice_kernel<20,TFIRST> 2 waves/wg, rows padded to 22", sl((slice_fn)slice_kernel<20, S_TFIRST, false, 2, true>, 2, true), b2, outB, base, outA);
+    add("slice_kernel<20,TFIRST> 4 waves/wg, rows padded to 22", sl((slice_fn)slice_kernel<20, S_TFIRST, false, 4, true>, 4, true), b2, outB, base, outA);
+    Launch basem = slice_launch((slice_fn)slice_kernel<20, S_MID, false>, sgrid0, w, outA);
+    add("slice_kernel<20,MID> (no power)", basem, b2, nullptr, nullptr, nullptr);
+    add("slice_walk<20,MID> wgs " + std::to_string(3 * C), slice_launch((slice_fn)slice_walk_kernel<20, S_MID>, 3 * C, w, outB), b2, outB, basem, outA);
+    add("slice_kernel<20,MID> 1 wave/wg, rows padded to 22 (no power)", sl((slice_fn)slice_kernel<20, S_MID, false, 1, true>, 1, true), b2, outB, basem, outA);
+    run_all(rounds);
+  }
+  {
+    // ---- pass 2: the persistent middle pass -----------------------------------------------------------------------
+    Launch base = line_launch((line_fn)line_kernel<20, L_MID, false, true, false>, L2, (unsigned)L2.ntiles, tmpA, outA, nullptr, false);
+    add("line_kernel<20,MID> pair (a,b), one tile per workgroup", base, b2, nullptr, nullptr, nullptr);
+#ifdef KB_OLD_POW
+    {
+      typedef void (*oline_fn)(const sdfs_old::LineDesc, const sdfs_old::LineIO);
+      oline_fn fn = (oline_fn)sdfs_old::line_stream_kernel<20, sdfs_old::L_MID, 2>;
+      hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)llds);
+      sdfs_old::LineDesc lo; memcpy(&lo, &L2, sizeof lo);
+      sdfs_old::LineIO io; memset(&io, 0, sizeof io); io.in = tmpA; io.out = outB; io.sched = sched;
+      add("sdfs_old::line_stream<20,MID,2,persistent> pair (a,b) wgs " + std::to_string(2 * C), [=]() { hipLaunchKernelGGL(fn, dim3(2 * C), dim3(256), llds, 0, lo, io); }, b2, outB, base, outA);
+    }
+#endif
+    for (unsigned wg : {3u * C, 2u * C})
+      add("line_stream<20,MID,2,persistent> pair (a,b) wgs " + std::to_string(wg), line_launch((line_fn)line_stream_kernel<20, L_MID, 2>, L2, wg, tmpA, outB, nullptr, false), b2, outB, base, outA);
+    run_all(rounds);
+  }
+  {
+    // ---- pass 3: the last pass (aggregator + residual) ----------------------------------------------------------------
+    Launch base = line_launch((line_fn)line_kernel<20, L_TLAST, false, true, false>, L3, (unsigned)L3.ntiles, tmpA, outA, w, true);
+    add("line_kernel<20,TLAST> pair (c,d) (general power, window of four)", base, b3, nullptr, nullptr, nullptr);
+    add("line_stream<20,TLAST,3,OLDPF,A3F,nonpersist> pair (c,d) (library)", line_launch((line_fn)line_stream_kernel<20, L_TLAST, 3, true, 256, false, true>, L3, (unsigned)L3.ntiles, tmpA, outB, w, true), b3, outB, base, outA);
+#ifdef KB_OLD_POW
+    {
+      typedef void (*oline_fn)(const sdfs_old::LineDesc, const sdfs_old::LineIO);
+      oline_fn fn = (oline_fn)sdfs_old::line_stream_kernel<20, sdfs_old::L_TLAST, 3, true, 256, false, true>;
+      hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)llds);
+      sdfs_old::LineDesc lo; memcpy(&lo, &L3, sizeof lo);
+      sdfs_old::LineIO io; memset(&io, 0, sizeof io); io.in = tmpA; io.out = outB; io.old = w; io.resid = resid; io.sched = sched;
+      const unsigned grid = (unsigned)L3.ntiles;
+      add("sdfs_old::line_stream<20,TLAST,3,OLDPF,A3F,nonpersist>", [=]() { hipLaunchKernelGGL(fn, dim3(grid), dim3(256), llds, 0, lo, io); }, b3, outB, base, outA);
+    }
+#endif
+    add("line_stream<20,TLAST,3,OLDPF,256,nonpersist> pair (c,d) (a3 gathers)", line_launch((line_fn)line_stream_kernel<20, L_TLAST, 3, true, 256, false>, L3, (unsigned)L3.ntiles, tmpA, outB, w, true), b3, outB, base, outA);
+    add("line_stream<20,TLAST,2,OLDPF,A3F,persistent> pair (c,d) wgs " + std::to_string(2 * C), line_launch((line_fn)line_stream_kernel<20, L_TLAST, 2, true, 256, true, true>, L3, 2 * C, tmpA, outB, w, true), b3, outB, base, outA);
+    add("line_stream<20,TLAST,2,OLDPF,A3F,512thr,nonpersist> pair (c,d)", line_launch((line_fn)line_stream_kernel<20, L_TLAST, 2, true, 512, false, true>, L3, (unsigned)L3.ntiles, tmpA, outB, w, true, 512), b3, outB, base, outA);
+    add("line_stream<20,TLAST,3,OLDPF,A3F,512thr,nonpersist> pair (c,d)", line_launch((line_fn)line_stream_kernel<20, L_TLAST, 3, true, 512, false, true>, L3, (unsigned)L3.ntiles, tmpA, outB, w, true, 512), b3, outB, base, outA);
     add("line_kernel<20,TLAST> pair (c,d), no residual", line_launch((line_fn)line_kernel<20, L_TLAST, false, true, false>, L3, (unsigned)L3.ntiles, tmpA, outA, w, false), b2, nullptr, nullptr, nullptr);
     run_all(rounds);
+    dump_stamps("line_stream<20,TLAST,3,OLDPF,A3F,nonpersist>", line_launch((line_fn)line_stream_kernel<20, L_TLAST, 3, true, 256, false, true>, L3, (unsigned)L3.ntiles, tmpA, outB, w, true));
   }
   return 0;
 }
