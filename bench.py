@@ -123,6 +123,48 @@ def cpu_literal_apply():
             "note": "literal = the reference's O(N^2) broadcast formulation, single numpy thread pool"}
 
 
+def newton_roofline(op, w_host, N, krylov_f32, inner=1e-6):
+    """Per-kernel algorithmic bytes / HIP-event time of one more Newton-Krylov solve with events around every launch
+    (code/solvers.py:51-95; configs[3]'s algorithm): the three passes of J.v, the fused BLAS-1 group of BiCGSTAB
+    (144 bytes per point and iteration in fp64, 72 in fp32 storage, over the group's summed kernel time),
+    the linearising applications of T, and one BiCGSTAB iteration as a whole against the HBM peak."""
+    op.set_profiling(True)
+    op.reset_counters()
+    x, n, info = op.solve(w_host, "newton", tol=1e-8, inner_rtol=inner, inner_atol=0.0, krylov_f32=krylov_f32)
+    cs = [c for c in op.counters() if c["launches"]]
+    op.set_profiling(False)
+    del x
+    n_jv = sum(c["launches"] for c in cs if c["name"].startswith(("jvp", "jvp32", "jvpm32")))
+    passes = max(len([c for c in cs if c["name"].startswith(("jvp", "jvp32", "jvpm32"))]), 1)
+    iters = n_jv / passes / 2.0                       # BiCGSTAB iterations: two J.v applications each
+    out = {"kernels": [], "newton_steps": n, "bicgstab_iterations": iters}
+    t_jv = t_b1 = 0.0
+    for c in cs:
+        avg = c["total_ms"] / c["launches"]
+        row = {"name": c["name"], "launches": c["launches"], "avg_ms": avg, "total_ms": c["total_ms"]}
+        if c["alg_bytes"] > 0:
+            row["alg_GB"] = c["alg_bytes"] / 1e9
+            row["GBps"] = c["alg_bytes"] / (avg * 1e-3) / 1e9
+            row["frac_hbm"] = row["GBps"] / HBM_PEAK_GBS
+        if c["name"].startswith(("jvp", "jvp32", "jvpm32")):
+            t_jv += c["total_ms"]
+        if c["name"] == "bicgstab_blas1":
+            t_b1 = c["total_ms"]
+            b1_bytes = (72.0 if krylov_f32 else 144.0) * N
+            row["alg_GB_per_iteration"] = b1_bytes / 1e9
+            row["ms_per_iteration"] = t_b1 / max(iters, 1)
+            row["GBps"] = b1_bytes / (row["ms_per_iteration"] * 1e-3) / 1e9
+            row["frac_hbm"] = row["GBps"] / HBM_PEAK_GBS
+        out["kernels"].append(row)
+    if iters > 0:
+        it_bytes = (144.0 if krylov_f32 else 288.0) * N      # 2 J.v (72 B / point each in fp64) + the BLAS-1 group
+        it_ms = (t_jv + t_b1) / iters
+        out["iteration"] = {"alg_GB": it_bytes / 1e9, "ms": it_ms, "GBps": it_bytes / (it_ms * 1e-3) / 1e9,
+                            "frac_hbm": it_bytes / (it_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                            "bytes_per_point": it_bytes / N}
+    return out
+
+
 def spawn_ranks(n, backend):
     """`python bench.py --gpus N` without a launcher: run torch.distributed.run as a child (one rank per GPU,
     rendezvous on 127.0.0.1) with this command line; rank 0 of the child prints the JSON line."""
@@ -343,6 +385,7 @@ def main():
                                         "applies_per_s": info["n_apply"] / t, "final_err": info["final_err"]}
             if not args.no_cpu:
                 sec["gcy20_newton_1e-8"]["cpu_twin"] = cpu_time_to_converge(model, shapes, params, arrays, n, info["n_apply"], full=False)
+            sec["gcy20_newton_1e-8"]["roofline"] = newton_roofline(op, w800, N, 0)
             # BASELINE config 5: the same solve with fp32 Krylov storage (fp64 arithmetic and outer residual)
             t0 = time.perf_counter()
             x, n, info = op.solve(w800, "newton", tol=1e-8, inner_rtol=1e-6, inner_atol=0.0, krylov_f32=1)
@@ -356,6 +399,13 @@ def main():
             t = time.perf_counter() - t0
             sec["gcy20_newton_1e-8_krylov_f32_inner_1e-4"] = {"iterations": n, "operator_applies": info["n_apply"], "seconds": t,
                                                               "applies_per_s": info["n_apply"] / t, "final_err": info["final_err"]}
+            # config 5 "on MFMA": fp32 storage AND the J.v passes on an fp32 LDS tile with v_mfma_f32 (opts.krylov_f32 = 3)
+            t0 = time.perf_counter()
+            x, n, info = op.solve(w800, "newton", tol=1e-8, inner_rtol=1e-4, inner_atol=0.0, krylov_f32=3)
+            t = time.perf_counter() - t0
+            sec["gcy20_newton_1e-8_f32_mfma_inner_1e-4"] = {"iterations": n, "operator_applies": info["n_apply"], "seconds": t,
+                                                            "applies_per_s": info["n_apply"] / t, "final_err": info["final_err"],
+                                                            "roofline": newton_roofline(op, w800, N, 3, inner=1e-4)}
             del x, w800
             # the device-resident successive-approximation loop on the bench grid (what solver(...) runs): at 20^6 the
             # same three launches per iteration as the headline step (slices, streamed middle lines, streamed last

@@ -55,7 +55,10 @@ typedef struct sdfs_opts {
   int32_t history;       /* Anderson history size m                         */
   int32_t mixing_freq;   /* Anderson mixing frequency                       */
   double beta;           /* Anderson damping                                */
-  double ridge;          /* Anderson ridge                                  */
+  double ridge;          /* Anderson ridge.  >= 0: jaxopt's absolute ridge on the Gram matrix (the reference's 1e-6,
+                          * code/solvers.py:113).  < 0 (opt-in, NOT the reference's semantics): relative,
+                          * |ridge| * trace(G) / history -- on grids of 1e7 .. 1e8 points the Gram entries N r^2 sink
+                          * below an absolute 1e-6 while the residual is still 1e-6 and the acceleration stalls */
   int32_t check_every;   /* host polls the device residual every k iterations (>=1): SA and Anderson enqueue (or replay from
                             a hipGraph) k gated iterations per synchronisation -- rounded up to an even number (SA) or to a
                             multiple of `history` (Anderson); the iterates, counts and error trace do not depend on k */
@@ -65,7 +68,11 @@ typedef struct sdfs_opts {
                           * arithmetic and reductions, fp64 outer residual and iterate -- the mixed-precision
                           * configuration of BASELINE.json (config 5).  2 = the same with every store of those fp32
                           * containers rounded to bfloat16: the NUMERICS of bf16 storage at the bytes of fp32 (evaluation
-                          * mode of the config-5 sweep).  Default 0 (everything fp64).    */
+                          * mode of the config-5 sweep).  3 = fp32 storage as under 1 AND the J.v passes of the pair
+                          * plan on an fp32 LDS tile with v_mfma_f32_16x16x4_f32 (fp32 products and sums inside a
+                          * pass; the BiCGSTAB reductions, the outer residual and the iterate stay fp64) -- config 5's
+                          * "on MFMA" (csrc/f32_kernels.hpp); plans without such kernels run as under 1.
+                          * Default 0 (everything fp64).    */
   int32_t t_f32;         /* Successive approximation on the pair plan (extents 16/20/24/32, whole 16-element chunks): 1 = the
                           * applications of T keep the intermediates between their passes as scaled floats while the step
                           * is above ~64 * 2^-24 * w / |theta| (what that storage can resolve), then the loop finishes in

@@ -134,7 +134,9 @@ def anderson_solver(f, x_init, tol=default_tolerance, max_iter=10000, verbose=Tr
         R[pos] = r
         error = float(np.sqrt(r @ r))
         if it + 1 >= m and (it + 1) % mixing_frequency == 0:
-            G = R @ R.T + ridge * np.eye(m)
+            G = R @ R.T
+            # ridge < 0: the HIP library's opt-in relative ridge |ridge| trace(G) / m (include/sdfs_hip.h; not jaxopt's)
+            G = G + (ridge if ridge >= 0 else -ridge * np.trace(G) / m) * np.eye(m)
             Hm = np.zeros((m + 1, m + 1))
             Hm[0, 1:] = 1.0
             Hm[1:, 0] = 1.0

@@ -1,0 +1,310 @@
+// f32_kernels.hpp -- the Jacobian-vector product of the pair plan with an fp32 LDS tile and fp32 MFMA (round 4).
+//
+// BASELINE config 5 ("fp32/bf16 mixed precision ON MFMA with fp64 residual accumulation").  The reference is fp64 only
+// (code/solvers.py:9-11); what can run at reduced precision without touching the fixed point is the INNER solve of the
+// Newton step, the matrix-free J.v of code/solvers.py:87 inside BiCGSTAB (:91-93): an inexact Newton method only needs
+// its linear system solved to the inner tolerance, while the outer residual T(x) - x, the iterate and every reduction
+// stay fp64.  Rounds 1-3 stored the Krylov vectors, c1, c2 and the J.v intermediates as floats (opts.krylov_f32 = 1)
+// but still widened every tile to fp64 in LDS and contracted it with v_mfma_f64.  Here (opts.krylov_f32 = 3):
+//   * the tile is parked in LDS as floats -- half the LDS bytes, and a line tile of 25.6 KB admits six workgroups per CU
+//     where the fp64 tile (51.2 KB) admits three;
+//   * the contractions run on v_mfma_f32_16x16x4_f32 (32 cycles per 16 x 16 x 4 block against 64 for the fp64 shape;
+//     lane maps probed on hardware, tools/probes/mfma_f32_probe.hip), accumulating in fp32;
+//   * extents that are not a multiple of 16 (n = 20, 24) take a second row tile whose A fragment is zero beyond row n
+//     (20: 2 x 5 MFMAs of 32 cycles = 320 per 16 columns against 5 x 64 + 5 x 20 = 420 in fp64; 16: 160 against 320);
+//   * the dot products of the last pass (<t, s>, <t, t> of BiCGSTAB) are summed in fp64, as everywhere.
+// Rounding: one stored float per stream as before, plus fp32 products and sums inside the three passes: ~1e-6 relative
+// on J.v, against inner tolerances of 1e-4 .. 1e-6 -- tools/mixed_precision_sweep.py measures what that costs.
+#pragma once
+#include "fast_kernels.hpp"
+
+namespace sdfs {
+
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+template <int N> struct MShape32 {
+  static_assert(N == 16 || N == 20 || N == 24 || N == 32, "pair plan extents");
+  static constexpr int NT = (N + 15) / 16;       // row tiles of 16
+  static constexpr int KT = N / 4;               // k-steps of 4
+};
+
+// A operand of v_mfma_f32_16x16x4_f32: lane l holds A[row l & 15][k l >> 4]; rows beyond N are zero
+template <int N> struct QFrag32 {
+  float a[MShape32<N>::NT][MShape32<N>::KT];
+  __device__ __forceinline__ void load(const double* __restrict__ Q, int lane) {
+    using S = MShape32<N>;
+    const int li = lane & 15, lk = lane >> 4;
+#pragma unroll
+    for (int t = 0; t < S::NT; ++t) {
+      const int row = 16 * t + li;
+#pragma unroll
+      for (int kk = 0; kk < S::KT; ++kk) a[t][kk] = row < N ? (float)Q[(row < N ? row : 0) * N + 4 * kk + lk] : 0.f;
+    }
+  }
+};
+
+// One column tile in place in an fp32 LDS tile: y[:, 16 columns] = Q x[:, 16 columns].  `col` points at the tile's
+// element (row 0, this lane's column li); RS = row stride in floats.  B operand: lane l reads row 4 kk + (l >> 4);
+// D: lane l, register i holds row 4 (l >> 4) + i of its column.  Every row is read before any is written.
+template <int N, int RS>
+__device__ __forceinline__ void ctile32(float* __restrict__ col, const int lk, const QFrag32<N>& q) {
+  using S = MShape32<N>;
+  float b[S::KT];
+  const float* const pr = col + lk * RS;
+#pragma unroll
+  for (int kk = 0; kk < S::KT; ++kk) b[kk] = pr[4 * kk * RS];
+  v4f acc[S::NT];
+#pragma unroll
+  for (int t = 0; t < S::NT; ++t) acc[t] = (v4f){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int kk = 0; kk < S::KT; ++kk) {
+#pragma unroll
+    for (int t = 0; t < S::NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(q.a[t][kk], b[kk], acc[t], 0, 0, 0);
+  }
+  float* const pw = col + 4 * lk * RS;
+#pragma unroll
+  for (int t = 0; t < S::NT; ++t) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row0 = 16 * t + i;                       // + 4 lk
+      if (16 * t + 12 + i < N || row0 + 4 * lk < N) pw[row0 * RS] = acc[t][i];      // (first test: compile time, whole tile inside)
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// slice32_kernel: first pass of J.v on the two fastest axes, x = c1 * v in fp32.  A wave owns G consecutive n x n slices
+// in a private LDS region of floats, row stride N + 2 (16 rows read at once then hit 32 different banks).
+template <int N> struct Slice32Geo {
+  static constexpr int G = N == 32 ? 2 : 4;
+  static constexpr int RS = N + 2;
+  static constexpr int LTILE = G * N * RS;               // floats
+  static constexpr int TILE = G * N * N;
+  static constexpr int UNITS4 = TILE / 4;                // float4 units
+  static constexpr int EPT4 = (UNITS4 + 63) / 64;
+  static constexpr int NCT = (G * N + 15) / 16;
+  static constexpr int CPAD = NCT * 16 - G * N;          // repeated columns of the last column tile (see SliceGeo)
+  static constexpr int WAVES = 4;
+  static_assert(CPAD <= 8, "the repeated columns lie inside the last column tile");
+};
+inline size_t slice32_lds_bytes(int n) { return (size_t)(n == 32 ? 2 : 4) * n * (n + 2) * 4 * 4; }
+inline int slice32_tile_slices(int n) { return n == 32 ? 2 : 4; }
+
+template <int N>
+__global__ void __launch_bounds__(256, 4)
+slice32_kernel(const SliceDesc P, const SliceIO io) {
+  using Geo = Slice32Geo<N>;
+  extern __shared__ double lds_[];
+  float* const lds = reinterpret_cast<float*>(lds_);
+  if (io.gate != nullptr) {
+    const unsigned long long g = *io.gate;
+    if (g <= (unsigned long long)__double_as_longlong(io.gate_tol)) return;
+  }
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const long long tile = (long long)blockIdx.x * Geo::WAVES + wave;
+  const long long s0 = tile * Geo::G;
+  if (s0 >= P.nslices) return;
+  const long long rem = (P.nslices - s0) * (N * N / 4);
+  const int nvalid4 = rem < Geo::UNITS4 ? (int)rem : Geo::UNITS4;
+  float* const wl = lds + wave * Geo::LTILE;
+  auto lofs = [](const int e) -> int { return (e / N) * Geo::RS + (e % N); };
+  const long long gbase = s0 * (N * N);
+  const unsigned lb = (unsigned)lane * 16u;
+  const char* const inb = reinterpret_cast<const char*>(reinterpret_cast<const float*>(io.in) + gbase);
+  const char* const auxb = reinterpret_cast<const char*>(reinterpret_cast<const float*>(io.aux_in) + gbase);
+  v4f v[Geo::EPT4], c1v[Geo::EPT4];
+#pragma unroll
+  for (int k = 0; k < Geo::EPT4; ++k) {
+    // (a unit beyond the tile, or in a slice a trailing partial tile does not have, re-reads unit 0's piece: finite
+    // values that stay inside slices which are never stored)
+    const unsigned off = (lane + 64 * k < nvalid4) ? lb + 1024u * k : lb;
+    v[k] = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(inb + off));
+    c1v[k] = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(auxb + off));
+  }
+  QFrag32<N> qf;
+  qf.load(P.Qf, lane);
+#pragma unroll
+  for (int k = 0; k < Geo::EPT4; ++k) {
+    const int u = lane + 64 * k;
+    if (Geo::UNITS4 % 64 == 0 || u < Geo::UNITS4) {
+      const v4f x = v[k] * c1v[k];
+      float* const p = wl + lofs(4 * u);                 // rows are 8-byte aligned (N + 2 is even): two 8-byte stores
+      *reinterpret_cast<v2f*>(p) = (v2f){x.x, x.y};
+      *reinterpret_cast<v2f*>(p + 2) = (v2f){x.z, x.w};
+    }
+  }
+  wave_lds_fence();
+  const int li = lane & 15, lk = lane >> 4;
+  // contraction over the fastest axis: column c = LDS row c (its N elements contiguous: "row stride" 1)
+#pragma unroll
+  for (int ct = 0; ct < Geo::NCT; ++ct) {
+    const bool rep = Geo::CPAD > 0 && ct == Geo::NCT - 1;
+    ctile32<N, 1>(wl + (ct * 16 + li - ((rep && li >= 16 - Geo::CPAD) ? Geo::CPAD : 0)) * Geo::RS, lk, qf);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  wave_lds_fence();
+  {
+    QFrag32<N> qe;
+    qe.load(P.Qe, lane);
+#pragma unroll
+    for (int ct = 0; ct < Geo::NCT; ++ct) {
+      const bool rep = Geo::CPAD > 0 && ct == Geo::NCT - 1;
+      const int c = 16 * ct + li - ((rep && li >= 16 - Geo::CPAD) ? Geo::CPAD : 0);
+      const int g = c / N, f = c - g * N;
+      ctile32<N, Geo::RS>(wl + g * (N * Geo::RS) + f, lk, qe);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  wave_lds_fence();
+  char* const outb = reinterpret_cast<char*>(reinterpret_cast<float*>(io.out) + gbase);
+#pragma unroll
+  for (int k = 0; k < Geo::EPT4; ++k) {
+    const int u = lane + 64 * k;
+    if (u < nvalid4) {
+      const float* const p = wl + lofs(4 * u);
+      const v2f a = *reinterpret_cast<const v2f*>(p), b = *reinterpret_cast<const v2f*>(p + 2);
+      *reinterpret_cast<v4f*>(outb + (lb + 1024u * k)) = (v4f){a.x, a.y, b.x, b.y};      // (default policy: the next pass reads it, pass_kernel.hpp SDFS_NT)
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// line32_kernel: middle / last pass of J.v on a slower pair, whole chunks only (lrest % 16 == 0).  Tile = all n x n
+// (x, y) rows of one 16-float chunk (64 bytes) ... of TWO adjacent chunks would be a 128-byte line, but the pass is then
+// a 51 KB tile again; the 64-byte rows of fp32 streams are what the fp32-storage forms of rounds 2-3 read as well.
+// LDS: row (x, y) at (x * N + y) * 16 floats; unit u = tid + k B is float4 (u & 3) of row u >> 2.
+template <int N> struct Line32Geo {
+  static constexpr int B = 256;
+  static constexpr int W = B / 64;
+  static constexpr int UNITS4 = N * N * LINE_R / 4;
+  static constexpr int EPT4 = (UNITS4 + B - 1) / B;
+  static constexpr int LX = N * LINE_R;                  // floats between two x
+  static constexpr int BPC = N == 16 ? 8 : (N == 20 ? 6 : (N == 24 ? 4 : 2));       // workgroups per CU (LDS: 16 / 25 / 36 / 64 KB)
+  static constexpr int OCC = BPC >= 6 ? 6 : BPC;         // waves per SIMD the register budget is set for
+};
+inline size_t line32_lds_bytes(int n) { return (size_t)n * n * LINE_R * 4; }
+
+template <int N, int MODE>
+__global__ void __launch_bounds__(256, (MODE == L_JLAST && Line32Geo<N>::OCC > 4) ? 4 : Line32Geo<N>::OCC)   // (the last pass holds two side streams)
+line32_kernel(const LineDesc P, const LineIO io) {
+  using Geo = Line32Geo<N>;
+  static_assert(MODE == L_MID || MODE == L_JLAST, "J.v roles");
+  constexpr bool MUL = MODE == L_JLAST;
+  constexpr int B = Geo::B, EPT4 = Geo::EPT4;
+  constexpr bool PART4 = Geo::UNITS4 % B != 0;
+  extern __shared__ double lds_[];
+  float* const lds = reinterpret_cast<float*>(lds_);
+  __shared__ double red4[16];
+  if (io.gate != nullptr) {
+    const unsigned long long g = *io.gate;
+    if (g <= (unsigned long long)__double_as_longlong(io.gate_tol)) return;
+  }
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 15, lk = lane >> 4;
+  const unsigned t = (unsigned)xcd_remap((long long)blockIdx.x, P.ntiles);
+  const unsigned o = t / (unsigned)P.nchunks;
+  const int chunk = (int)(t - o * (unsigned)P.nchunks);
+  const long long tbase = (long long)o * (N * N) * P.lrest + (long long)chunk * LINE_R;
+  const unsigned b0 = ((unsigned)(tid >> 2) * (unsigned)P.lrest + 4u * (tid & 3)) * 4u;
+  const unsigned bstep = (unsigned)(B / 4) * (unsigned)P.lrest * 4u;
+  const char* const inb = reinterpret_cast<const char*>(reinterpret_cast<const float*>(io.in) + tbase);
+  const char* const auxb = reinterpret_cast<const char*>(reinterpret_cast<const float*>(io.aux_in) + tbase);
+  const char* const oldb = reinterpret_cast<const char*>(reinterpret_cast<const float*>(io.old) + tbase);
+  char* const outb = reinterpret_cast<char*>(reinterpret_cast<float*>(io.out) + tbase);
+  const bool need_old = MUL && P.minus_identity;
+  v4f v[EPT4];
+#pragma unroll
+  for (int k = 0; k < EPT4; ++k) {
+    const bool rowok = !PART4 || tid + k * B < Geo::UNITS4;
+    v[k] = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(inb + (rowok ? b0 + k * bstep : b0)));
+  }
+  QFrag32<N> q;
+  q.load(P.Qx, lane);
+#pragma unroll
+  for (int k = 0; k < EPT4; ++k) {
+    const int u = tid + k * B;
+    if (!PART4 || u < Geo::UNITS4) *reinterpret_cast<v4f*>(lds + 4 * u) = v[k];
+  }
+  // side streams of the J.v epilogue: both fit next to the fragments here (an fp32 tile unit is one register quad)
+  v4f c2v[MUL ? EPT4 : 1], oldv[MUL ? EPT4 : 1];
+  if (MUL) {
+#pragma unroll
+    for (int k = 0; k < EPT4; ++k) {
+      const bool rowok = !PART4 || tid + k * B < Geo::UNITS4;
+      c2v[MUL ? k : 0] = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(auxb + (rowok ? b0 + k * bstep : b0)));
+      if (need_old) oldv[MUL ? k : 0] = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(oldb + (rowok ? b0 + k * bstep : b0)));
+    }
+  }
+  __syncthreads();
+  // contraction over X: column (y, r) at y * 16 + r, row stride LX
+#pragma unroll
+  for (int j = 0; j < N / Geo::W; ++j) ctile32<N, Geo::LX>(lds + (wave + j * Geo::W) * 16 + li, lk, q);
+  q.load(P.Qy, lane);
+  __syncthreads();
+  // contraction over Y: column (x, r) at x * LX + r, row stride 16
+#pragma unroll
+  for (int j = 0; j < N / Geo::W; ++j) ctile32<N, LINE_R>(lds + (wave + j * Geo::W) * Geo::LX + li, lk, q);
+  __syncthreads();
+  double dot_yv = 0.0, dot_yy = 0.0;
+#pragma unroll
+  for (int k = 0; k < EPT4; ++k) {
+    const int u = tid + k * B;
+    if (!PART4 || u < Geo::UNITS4) {
+      v4f y = *reinterpret_cast<const v4f*>(lds + 4 * u);
+      if (MUL) {
+        y = y * c2v[MUL ? k : 0];
+        if (need_old) {
+          const v4f ov = oldv[MUL ? k : 0];
+          y = y - ov;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {                   // what is stored is what the dots refer to; sums in fp64
+            dot_yv = fma((double)y[j], (double)ov[j], dot_yv);
+            dot_yy = fma((double)y[j], (double)y[j], dot_yy);
+          }
+        }
+      }
+      *reinterpret_cast<v4f*>(outb + (b0 + k * bstep)) = y;
+    }
+  }
+  if (MUL && io.dotp != nullptr) {
+#pragma unroll
+    for (int s = 32; s > 0; s >>= 1) { dot_yv += __shfl_xor(dot_yv, s); dot_yy += __shfl_xor(dot_yy, s); }
+    if (lane == 0) { red4[wave] = dot_yv; red4[8 + wave] = dot_yy; }
+    __syncthreads();
+    if (tid == 0) {
+      double a = 0.0, b = 0.0;
+      for (int w = 0; w < Geo::W; ++w) { a += red4[w]; b += red4[8 + w]; }
+      io.dotp[blockIdx.x] = a;
+      io.dotp[gridDim.x + blockIdx.x] = b;
+    }
+  }
+}
+
+#ifndef SDFS_NO_VARIANT_TABLES
+inline slice_fn slice32_variant(int n) {
+  switch (n) {
+    case 16: return (slice_fn)slice32_kernel<16>;
+    case 20: return (slice_fn)slice32_kernel<20>;
+    case 24: return (slice_fn)slice32_kernel<24>;
+    case 32: return (slice_fn)slice32_kernel<32>;
+    default: return nullptr;
+  }
+}
+template <int N> inline line_fn line32_variant_n(int mode) {
+  return mode == L_MID ? (line_fn)line32_kernel<N, L_MID> : (mode == L_JLAST ? (line_fn)line32_kernel<N, L_JLAST> : nullptr);
+}
+inline line_fn line32_variant(int n, int mode) {
+  switch (n) {
+    case 16: return line32_variant_n<16>(mode);
+    case 20: return line32_variant_n<20>(mode);
+    case 24: return line32_variant_n<24>(mode);
+    case 32: return line32_variant_n<32>(mode);
+    default: return nullptr;
+  }
+}
+#endif
+
+}  // namespace sdfs

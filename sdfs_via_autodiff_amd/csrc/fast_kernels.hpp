@@ -393,7 +393,7 @@ slice_kernel(const SliceDesc P, const SliceIO io) {
 #pragma unroll
     for (int k = 0; k < Geo::EPT; ++k) {
       const int u = lane + 64 * k;
-      if (u < nvalid) stg_stream2(outb + (lb + 1024u * k), *reinterpret_cast<const double2*>(wl + lofs(2 * u)));
+      if (u < nvalid) stg_stream2<NT_SLICE>(outb + (lb + 1024u * k), *reinterpret_cast<const double2*>(wl + lofs(2 * u)));
     }
   }
 }
@@ -1444,6 +1444,12 @@ __global__ void __launch_bounds__(64) small_sa_finish(const double* part, int n,
   if (threadIdx.x == 0) *slot = (unsigned long long)__double_as_longlong(m);
 }
 
+// The plain first pass of T at N = 20: three slices per wave tile (9.6 KB of LDS per wave, 114 VGPRs: sixteen waves per
+// CU instead of twelve; the last of the four column tiles repeats four columns).  Measured with the power routine and the
+// non-temporal streams of round 4: 0.231-0.233 against 0.240 ms (profiles/round4_kernel_bench.txt); the other roles keep
+// four slices (their streams and register sets differ).
+template <int N> struct SliceTFirst { static constexpr int G = 0, OCC = 3; };
+template <> struct SliceTFirst<20> { static constexpr int G = 3, OCC = 4; };
 typedef void (*small_fn)(const SmallDesc, const SmallIO);
 typedef void (*small_and_fn)(const SmallDesc, const SmallIO, const AndArgs);
 typedef void (*slice_fn)(const SliceDesc, const SliceIO);
@@ -1482,12 +1488,6 @@ inline unsigned small_grid(const SmallDesc& d, int wpt) { return d.cpx != 0u ? 8
 inline unsigned small_cpx(long long ntiles, int wpt) { return (small_grid(ntiles, wpt) + 7u) / 8u; }
 
 
-// The plain first pass of T at N = 20: three slices per wave tile (9.6 KB of LDS per wave, 114 VGPRs: sixteen waves per
-// CU instead of twelve; the last of the four column tiles repeats four columns).  Measured with the power routine and the
-// non-temporal streams of round 4: 0.231-0.233 against 0.240 ms (profiles/round4_kernel_bench.txt); the other roles keep
-// four slices (their streams and register sets differ).
-template <int N> struct SliceTFirst { static constexpr int G = 0, OCC = 3; };
-template <> struct SliceTFirst<20> { static constexpr int G = 3, OCC = 4; };
 template <int N> inline slice_fn slice_variant_n(int mode, bool f32) {
   switch (mode) {
     case S_TFIRST: return f32 ? nullptr : (slice_fn)slice_kernel<N, S_TFIRST, false, 4, false, SliceTFirst<N>::G, SliceTFirst<N>::OCC>;

@@ -93,24 +93,31 @@ typedef double v4d __attribute__((ext_vector_type(4)));
 // array that lives across a loop then stays in scratch
 typedef double v2d __attribute__((ext_vector_type(2)));
 
-// Grid streams of the pair-plan kernels: every point of a pass is read once and written once, nothing is re-read
-// through L2 inside a launch, so the 16-byte accesses carry the non-temporal hint (global_load/store_dwordx4 ... nt).
-// Measured with a plain streaming copy of one 512 MB grid (tools/probes/kernel_bench.hip, profiles/round4_kernel_bench.txt):
-// 5.43-5.54 TB/s with default-policy accesses, 5.85-5.86 TB/s with nt loads and stores.  SDFS_NT: bit 0 loads, bit 1
-// stores (A/B builds of the probe set it to 0).
+// Grid streams of the pair-plan kernels: every point of a pass is read once and written once, so the 16-byte accesses can
+// carry the non-temporal hint (global_load/store_dwordx4 ... nt).  A plain streaming copy of one 512 MB grid gains 6 %
+// from it, all of it from the STORES (tools/probes/kernel_bench.hip, profiles/round4_kernel_bench.txt: 5.43-5.54 TB/s
+// default policy, 5.51 nt loads only, 5.68 nt stores only, 5.77-5.86 both) -- but inside the operator a pass's output
+// is the next pass's input, and what an nt store saves its own kernel the consumer can lose: same-box A/B of whole
+// library builds (tools/ab_step.sh, profiles/round4_ab_step.txt): with every store nt the first pass of GCY 20^6 keeps its
+// time, the last one gains 3 %, the middle one -- 400 rows of 128 bytes from all over the grid per tile -- LOSES 10 %,
+// and 16^6 (134 MB: the intermediates fit the Infinity Cache) loses 4 % overall.  SDFS_NT is a bit mask: 1 loads,
+// 2 stores of the slice kernels, 4 stores of the middle line pass, 8 stores of the last line pass.
 #ifndef SDFS_NT
-#define SDFS_NT 3
+#define SDFS_NT 9
 #endif
+enum { NT_SLICE = 2, NT_MID = 4, NT_LAST = 8 };
 __device__ __forceinline__ v2d ldg_stream(const void* p) {
   if (SDFS_NT & 1) return __builtin_nontemporal_load(reinterpret_cast<const v2d*>(p));
   return *reinterpret_cast<const v2d*>(p);
 }
+template <int WHO>
 __device__ __forceinline__ void stg_stream(void* p, const v2d v) {
-  if (SDFS_NT & 2) __builtin_nontemporal_store(v, reinterpret_cast<v2d*>(p));
+  if (SDFS_NT & WHO) __builtin_nontemporal_store(v, reinterpret_cast<v2d*>(p));
   else *reinterpret_cast<v2d*>(p) = v;
 }
 __device__ __forceinline__ double2 ldg_stream2(const void* p) { const v2d t = ldg_stream(p); return make_double2(t.x, t.y); }
-__device__ __forceinline__ void stg_stream2(void* p, const double2 v) { stg_stream(p, (v2d){v.x, v.y}); }
+template <int WHO>
+__device__ __forceinline__ void stg_stream2(void* p, const double2 v) { stg_stream<WHO>(p, (v2d){v.x, v.y}); }
 
 // ---------------------------------------------------------------------------
 // pow_fast(x, y) for the two powers of the operator (w^theta and (K S)^(1/theta)).

@@ -23,6 +23,7 @@
 #include "pass_kernel.hpp"
 #include "fast_kernels.hpp"
 #include "stream_kernels.hpp"
+#include "f32_kernels.hpp"
 #include "pad_kernels.hpp"
 #include "cont_kernel.hpp"
 #include "dense_kernel.hpp"
@@ -174,6 +175,7 @@ struct sdfs_handle {
   bool krylov_f32 = false;
   std::vector<double> a3_host;       // host copy of the a3 table (the pair plan looks for its two-table form)
   bool t32_active = false;           // successive approximation, opts.t_f32: T applications keep their intermediates as scaled floats
+  bool krylov_mfma32 = false;        // ... with the J.v passes of the pair plan on an fp32 LDS tile and fp32 MFMA (opts.krylov_f32 = 3: f32_kernels.hpp)
   bool krylov_bf16 = false;          // ... with every store of those fp32 containers rounded to bfloat16 (opts.krylov_f32 = 2: bf16r, vec_kernels.hpp)
   double lin_ref = 0.0;              // sharded handles: reference value of the fp32 linearisation scale (sdfs_set_krylov_f32)
 
@@ -870,6 +872,7 @@ int build_fast_plan(sdfs_handle* h) {
       hipFuncSetAttribute((const void*)f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)slice_lds_bytes(P.n, m));
       slice_fn f32 = slice_variant(P.n, m, true);
       if (f32) hipFuncSetAttribute((const void*)f32, hipFuncAttributeMaxDynamicSharedMemorySize, (int)slice_lds_bytes(P.n, m));
+      if (slice_fn m32 = slice32_variant(P.n)) hipFuncSetAttribute((const void*)m32, hipFuncAttributeMaxDynamicSharedMemorySize, (int)slice32_lds_bytes(P.n));
     } else for (int m = 0; m < L_NMODES; ++m) for (int pe = 0; pe < 2; ++pe) {
       line_fn f = line_variant(P.n, m, pe != 0, P.ld.lrest % LINE_R == 0);
       if (!f && m == L_TFUSED && pe != 0) continue;          // one tile per workgroup only
@@ -877,6 +880,7 @@ int build_fast_plan(sdfs_handle* h) {
       hipFuncSetAttribute((const void*)f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)line_lds_bytes(P.n));
       line_fn f32 = line_variant(P.n, m, false, true, true);
       if (f32) hipFuncSetAttribute((const void*)f32, hipFuncAttributeMaxDynamicSharedMemorySize, (int)line_lds_bytes(P.n));
+      if (line_fn m32 = line32_variant(P.n, m)) hipFuncSetAttribute((const void*)m32, hipFuncAttributeMaxDynamicSharedMemorySize, (int)line32_lds_bytes(P.n));
     }
   }
   bool f32_ok = true;
@@ -1201,14 +1205,17 @@ int run_fast_plan(sdfs_handle* h, int mode, const double* in, double* out, const
       else if (mode == MODE_JVP) { sm = S_JFIRST; io.aux_in = vjp ? h->c2 : h->c1; bytes += n8; }
       SliceDesc sd = P.sd;
       if (vjp) { sd.Qf = h->ax[P.ax1].Qt; sd.Qe = h->ax[P.ax0].Qt; }
-      slice_fn fn = slice_variant(P.n, sm, f32);
+      // opts.krylov_f32 = 3: fp32 LDS tile + fp32 MFMA for the J.v passes (f32_kernels.hpp)
+      const bool m32 = f32 && h->krylov_mfma32 && mode == MODE_JVP;
+      slice_fn fn = m32 ? slice32_variant(P.n) : slice_variant(P.n, sm, f32);
       if (f32 && mode == MODE_JVP) bytes *= 0.5;
       int cid = -1;
-      if (h->profiling) { char nm[48]; snprintf(nm, sizeof nm, "%s:%s", tag, P.label.c_str()); cid = counter_id(h, nm, bytes, P.flops); }
-      const long long ntile = (P.sd.nslices + slice_tile_slices(P.n, sm) - 1) / slice_tile_slices(P.n, sm);
+      if (h->profiling) { char nm[48]; snprintf(nm, sizeof nm, "%s:%s", m32 ? "jvpm32" : tag, P.label.c_str()); cid = counter_id(h, nm, bytes, P.flops); }
+      const int gsl = m32 ? slice32_tile_slices(P.n) : slice_tile_slices(P.n, sm);
+      const long long ntile = (P.sd.nslices + gsl - 1) / gsl;
       const unsigned grid = (unsigned)((ntile + 3) / 4);
       ProfScope ps(h, cid);
-      hipLaunchKernelGGL(fn, dim3(grid), dim3(256), slice_lds_bytes(P.n, sm), h->stream, sd, io);
+      hipLaunchKernelGGL(fn, dim3(grid), dim3(256), m32 ? slice32_lds_bytes(P.n) : slice_lds_bytes(P.n, sm), h->stream, sd, io);
     } else {
       LineIO io;
       memset(&io, 0, sizeof io);
@@ -1237,12 +1244,14 @@ int run_fast_plan(sdfs_handle* h, int mode, const double* in, double* out, const
         fn = line_stream_variant(P.n, lm, d.f1 != nullptr);
         grid = lm == L_MID ? stream_mid_grid(h, P) : (unsigned)d.ntiles;
       }
+      const bool m32 = lf32 && h->krylov_mfma32 && mode == MODE_JVP && !t32;
+      if (m32) { fn = line32_variant(P.n, lm); grid = (unsigned)d.ntiles; }
       if (!fn) return fail(h, SDFS_ERR_UNSUPPORTED, "no line kernel variant");
       if (f32 && mode == MODE_JVP) bytes *= 0.5;
       int cid = -1;
-      if (h->profiling) { char nm[48]; snprintf(nm, sizeof nm, "%s:%s", tag, P.label.c_str()); cid = counter_id(h, nm, bytes, P.flops); }
+      if (h->profiling) { char nm[48]; snprintf(nm, sizeof nm, "%s:%s", m32 ? "jvpm32" : tag, P.label.c_str()); cid = counter_id(h, nm, bytes, P.flops); }
       ProfScope ps(h, cid);
-      hipLaunchKernelGGL(fn, dim3(grid), dim3(line_block(P.n)), line_lds_bytes(P.n), h->stream, d, io);
+      hipLaunchKernelGGL(fn, dim3(grid), dim3(m32 ? 256 : line_block(P.n)), m32 ? line32_lds_bytes(P.n) : line_lds_bytes(P.n), h->stream, d, io);
     }
     HIPCHK(h, hipGetLastError());
     if (f32 && h->krylov_bf16) {
@@ -1764,11 +1773,12 @@ int solve_newton(sdfs_handle* h, const sdfs_opts& o, double* w, int64_t* n_iter,
   // opts.krylov_f32: inexact Newton with the inner solve in fp32 storage (Krylov vectors, c1 / c2, the
   // J.v intermediates) and fp64 arithmetic / reductions; the outer residual T(x) - x and the iterate
   // stay fp64, so the fixed point is reached to the same tolerance.  Discretised, unsharded handles only.
-  struct F32Guard { sdfs_handle* h; ~F32Guard() { h->krylov_f32 = false; h->krylov_bf16 = false; } } f32_guard{h};
+  struct F32Guard { sdfs_handle* h; ~F32Guard() { h->krylov_f32 = false; h->krylov_bf16 = false; h->krylov_mfma32 = false; } } f32_guard{h};
   const bool want_f32 = o.krylov_f32 != 0 && !h->cont && !h->dense && !h->sharded;
   int f32_failures = 0;
   h->krylov_f32 = want_f32;
   h->krylov_bf16 = want_f32 && o.krylov_f32 == 2;
+  h->krylov_mfma32 = want_f32 && o.krylov_f32 == 3;
   while (err > o.tol && it < o.max_iter) {
     // g(x) = T(x) - x, linearisation cached for the J.v products
     if ((rc = run_plan(h, h->plan[0], MODE_T_LIN, true, true, x, Tx, x, nullptr, nullptr, 0.0, 0))) return rc;
@@ -1906,8 +1916,10 @@ int solve_anderson_host(sdfs_handle* h, const sdfs_opts& o, double* w, int64_t* 
       const int d = m + 1;
       std::vector<double> A((size_t)d * d, 0.0), b(d, 0.0);
       for (int j = 1; j < d; ++j) { A[j] = 1.0; A[(size_t)j * d] = 1.0; }
+      double rg = o.ridge;                     // (< 0: relative to trace(G) / m, as in and_step_wave)
+      if (rg < 0.0) { double tr = 0.0; for (int j = 0; j < m; ++j) tr += G[(size_t)j * m + j]; rg = -rg * tr / m; }
       for (int i = 0; i < m; ++i)
-        for (int j = 0; j < m; ++j) A[(size_t)(i + 1) * d + j + 1] = G[(size_t)i * m + j] + (i == j ? o.ridge : 0.0);
+        for (int j = 0; j < m; ++j) A[(size_t)(i + 1) * d + j + 1] = G[(size_t)i * m + j] + (i == j ? rg : 0.0);
       b[0] = 1.0;
       if (solve_dense(A, b, d)) {
         AndCoef c;

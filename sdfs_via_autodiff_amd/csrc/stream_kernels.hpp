@@ -207,7 +207,7 @@ slice_walk_kernel(const SliceDesc P, const SliceIO io) {
 #pragma unroll
       for (int k = 0; k < Geo::EPT; ++k) {
         const int u = lane + 64 * k;
-        if (Geo::UNITS % 64 == 0 || u < Geo::UNITS) stg_stream(outb + (lb + 1024u * k), *reinterpret_cast<const v2d*>(wl + lofs(2 * u)));
+        if (Geo::UNITS % 64 == 0 || u < Geo::UNITS) stg_stream<NT_SLICE>(outb + (lb + 1024u * k), *reinterpret_cast<const v2d*>(wl + lofs(2 * u)));
         if (k % 4 == 3) __builtin_amdgcn_sched_barrier(0);      // four units on their way out at a time (register budget)
       }
       wave_lds_fence();
@@ -334,7 +334,7 @@ line_stream_kernel(const LineDesc P, const LineIO io) {
 #pragma unroll
         for (int k = 0; k < EPT; ++k) {
           const int u = tid + k * B;
-          if (!PARTIAL || u < Geo::UNITS) stg_stream(outb + (b0 + (unsigned)k * bstep), *reinterpret_cast<const v2d*>(lds + 2 * u));
+          if (!PARTIAL || u < Geo::UNITS) stg_stream<NT_MID>(outb + (b0 + (unsigned)k * bstep), *reinterpret_cast<const v2d*>(lds + 2 * u));
           if (k % 4 == 3) __builtin_amdgcn_sched_barrier(0);      // four units on their way out at a time (register budget)
         }
       } else {
@@ -387,7 +387,7 @@ line_stream_kernel(const LineDesc P, const LineIO io) {
                 rnan |= (r0 != r0) | (r1 != r1);
                 rmax = fmax(rmax, fmax(r0, r1));
               }
-              stg_stream2(outb + off, y2);
+              stg_stream2<NT_LAST>(outb + off, y2);
             }
           } else if (rowok) {
             double2 y2 = make_double2(sv.x * s2.x, sv.y * s2.y);

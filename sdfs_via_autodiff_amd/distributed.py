@@ -694,7 +694,7 @@ def anderson_sharded(op, w_loc, tol=1e-7, max_iter=10000, history_size=10, mixin
             Hm = np.zeros((m + 1, m + 1))
             Hm[0, 1:] = 1.0
             Hm[1:, 0] = 1.0
-            Hm[1:, 1:] = G + ridge * np.eye(m)
+            Hm[1:, 1:] = G + (ridge if ridge >= 0 else -ridge * np.trace(G) / m) * np.eye(m)
             rhs = np.zeros(m + 1)
             rhs[0] = 1.0
             try:

@@ -2,11 +2,14 @@
 ACHIEVED fixed-point error of every run (the reference is fp64 only, code/solvers.py:9-11: every row below is new
 work measured against the fp64 fixed point).
 
-    python tools/mixed_precision_sweep.py [16|20 ...] > profiles/round3_mixed_precision_sweep.txt
+    python tools/mixed_precision_sweep.py [16|20 ...] > profiles/round4_mixed_precision_sweep.txt
 
 storage  fp64   everything fp64
          fp32   opts.krylov_f32 = 1: Krylov vectors, c1 / c2 and every J.v stream in fp32 storage; arithmetic (fp64
                 MFMA), reductions, outer residual and iterate fp64
+         f32m   opts.krylov_f32 = 3 (round 4): fp32 storage as above AND the J.v passes on an fp32 LDS tile with
+                v_mfma_f32_16x16x4_f32 (fp32 products and sums inside a pass; csrc/f32_kernels.hpp); reductions, outer
+                residual and iterate fp64 -- config 5's "on MFMA"
          bf16r  opts.krylov_f32 = 2: the same fp32 containers with every store rounded to bfloat16 -- the NUMERICS of
                 bf16 storage (iteration counts, achieved error) at the BYTES of fp32.  The "projected" column prices
                 the run as if the containers were 2 bytes: Krylov-path time scaled by the byte ratio of a BiCGSTAB
@@ -28,7 +31,7 @@ import numpy as np
 sys.path.insert(0, ".")
 import sdfs_via_autodiff_amd as S  # noqa: E402
 
-STORAGE = (("fp64", 0), ("fp32", 1), ("bf16r", 2))
+STORAGE = (("fp64", 0), ("fp32", 1), ("f32m", 3), ("bf16r", 2))
 
 
 def main():
@@ -50,7 +53,7 @@ def main():
             for inner in (1e-2, 1e-4, 1e-6):
                 for name, mode in STORAGE:
                     best = None
-                    for rep in range(2 if mode < 2 else 1):
+                    for rep in range(1 if mode == 2 else 2):
                         t0 = time.perf_counter()
                         x, it, info = T.solve(w0, "newton", tol=tol, inner_rtol=inner, inner_atol=0.0, krylov_f32=mode,
                                               max_iter=60, inner_max_iter=400)

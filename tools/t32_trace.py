@@ -1,6 +1,7 @@
 """Where do the extra iterations of SA with fp32 intermediates (opts.t_f32) come from?  Error traces of the t_f32 solve and
 of the fp64 solve on the shapes of tests/test_hip_pair_plan.py::test_sa_with_fp32_intermediates, the iteration of the
 phase switch (step <= 64 * 2^-24 * w / |theta|) and the ratio of consecutive steps around it."""
+import os
 import sys
 import numpy as np
 sys.path.insert(0, ".")
@@ -10,7 +11,11 @@ for shapes in [(32, 32, 16, 16), (16, 16, 24, 24), (16,) * 6]:
     model = "gcy" if len(shapes) == 6 else "ssy"
     m = S.GCY() if model == "gcy" else S.SSY()
     arr = (S.discretize_gcy if model == "gcy" else S.discretize_ssy)(m, shapes)
-    T = S.KoopmansOperator(model, shapes, m.params, arr)
+    os.environ["SDFS_PLAN"] = "pair"          # (4-D grids take the small / padded plans by default: opts.t_f32 lives on the pair plan)
+    try:
+        T = S.KoopmansOperator(model, shapes, m.params, arr)
+    finally:
+        del os.environ["SDFS_PLAN"]
     w0 = np.full(shapes, 800.0)
     tol = 1e-7
     xa, na, ia = T.solve(w0, "successive_approx", tol=tol, t_f32=1, record_errors=True)
@@ -28,4 +33,10 @@ for shapes in [(32, 32, 16, 16), (16, 16, 24, 24), (16,) * 6]:
         rb = eb[k] / eb[k - 1] if 0 < k < len(eb) else float("nan")
         print(f"   it {k:5d}: step t_f32 {a:.4e} (ratio {ra:.5f})   fp64 {b:.4e} (ratio {rb:.5f})")
     print(f"   max|x32 - x64| = {np.max(np.abs(xa - xb)):.3e}")
+    # where the two traces part: first iteration at which the steps differ by more than 1e-3 relative
+    k = next((i for i in range(min(len(ea), len(eb))) if abs(ea[i] - eb[i]) > 1e-3 * eb[i]), None)
+    print(f"   traces agree to 1e-3 relative up to iteration {k}")
+    if k is not None:
+        for i in range(max(k - 2, 0), min(k + 12, len(ea), len(eb))):
+            print(f"      it {i:5d}: t_f32 {ea[i]:.6e}   fp64 {eb[i]:.6e}")
     T.close()
