@@ -171,28 +171,32 @@ slice32_kernel(const SliceDesc P, const SliceIO io) {
 }
 
 // ---------------------------------------------------------------------------------------------------
-// line32_kernel: middle / last pass of J.v on a slower pair, whole chunks only (lrest % 16 == 0).  Tile = all n x n
-// (x, y) rows of one 16-float chunk (64 bytes) ... of TWO adjacent chunks would be a 128-byte line, but the pass is then
-// a 51 KB tile again; the 64-byte rows of fp32 streams are what the fp32-storage forms of rounds 2-3 read as well.
-// LDS: row (x, y) at (x * N + y) * 16 floats; unit u = tid + k B is float4 (u & 3) of row u >> 2.
-template <int N> struct Line32Geo {
+// line32_kernel: middle / last pass of J.v on a slower pair, whole chunks only.  Tile = all n x n (x, y) rows of one chunk
+// of R floats of the contiguous remainder behind the pair: R = 32 (one 128-byte line per row, 51 KB of LDS at n = 20:
+// three workgroups per CU) where the remainder is a multiple of 32 elements, else R = 16 (64-byte rows, 25.6 KB: six
+// workgroups per CU) -- at GCY 20^6 the pair (z, z_pi) takes 32, the pair (h_z, h_c), whose remainder is 400, takes 16.
+// LDS: row (x, y) at (x * N + y) * R floats; unit u = tid + k B is float4 (u % (R / 4)) of row u / (R / 4).
+template <int N, int R> struct Line32Geo {
+  static_assert(R == 16 || R == 32, "row lengths of the fp32 line tiles");
   static constexpr int B = 256;
   static constexpr int W = B / 64;
-  static constexpr int UNITS4 = N * N * LINE_R / 4;
+  static constexpr int Q4 = R / 4;                       // float4 units per row
+  static constexpr int UNITS4 = N * N * Q4;
   static constexpr int EPT4 = (UNITS4 + B - 1) / B;
-  static constexpr int LX = N * LINE_R;                  // floats between two x
-  static constexpr int BPC = N == 16 ? 8 : (N == 20 ? 6 : (N == 24 ? 4 : 2));       // workgroups per CU (LDS: 16 / 25 / 36 / 64 KB)
-  static constexpr int OCC = BPC >= 6 ? 6 : BPC;         // waves per SIMD the register budget is set for
+  static constexpr int LX = N * R;                       // floats between two x
+  static constexpr int LDS_BYTES = N * N * R * 4;
+  static constexpr int BPC = 163840 / LDS_BYTES > 8 ? 8 : 163840 / LDS_BYTES;       // workgroups per CU (LDS)
+  static constexpr int OCC = BPC >= 6 ? 6 : (BPC < 1 ? 1 : BPC);                    // waves per SIMD the register budget is set for
 };
-inline size_t line32_lds_bytes(int n) { return (size_t)n * n * LINE_R * 4; }
+inline size_t line32_lds_bytes(int n, int r) { return (size_t)n * n * r * 4; }
 
-template <int N, int MODE>
-__global__ void __launch_bounds__(256, (MODE == L_JLAST && Line32Geo<N>::OCC > 4) ? 4 : Line32Geo<N>::OCC)   // (the last pass holds two side streams)
+template <int N, int MODE, int R>
+__global__ void __launch_bounds__(256, ((MODE == L_JLAST && Line32Geo<N, R>::OCC > 4) ? 4 : Line32Geo<N, R>::OCC))   // (the last pass holds two side streams)
 line32_kernel(const LineDesc P, const LineIO io) {
-  using Geo = Line32Geo<N>;
+  using Geo = Line32Geo<N, R>;
   static_assert(MODE == L_MID || MODE == L_JLAST, "J.v roles");
   constexpr bool MUL = MODE == L_JLAST;
-  constexpr int B = Geo::B, EPT4 = Geo::EPT4;
+  constexpr int B = Geo::B, EPT4 = Geo::EPT4, Q4 = Geo::Q4;
   constexpr bool PART4 = Geo::UNITS4 % B != 0;
   extern __shared__ double lds_[];
   float* const lds = reinterpret_cast<float*>(lds_);
@@ -204,12 +208,15 @@ line32_kernel(const LineDesc P, const LineIO io) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 15, lk = lane >> 4;
-  const unsigned t = (unsigned)xcd_remap((long long)blockIdx.x, P.ntiles);
-  const unsigned o = t / (unsigned)P.nchunks;
-  const int chunk = (int)(t - o * (unsigned)P.nchunks);
-  const long long tbase = (long long)o * (N * N) * P.lrest + (long long)chunk * LINE_R;
-  const unsigned b0 = ((unsigned)(tid >> 2) * (unsigned)P.lrest + 4u * (tid & 3)) * 4u;
-  const unsigned bstep = (unsigned)(B / 4) * (unsigned)P.lrest * 4u;
+  // tiles: chunks of R elements (LineDesc counts chunks of 16: nchunks * 16 / R of them per outer index)
+  const unsigned cpo = (unsigned)P.nchunks * LINE_R / R;
+  const long long ntiles = P.nouter * (long long)cpo;
+  const unsigned t = (unsigned)xcd_remap((long long)blockIdx.x, ntiles);
+  const unsigned o = t / cpo;
+  const int chunk = (int)(t - o * cpo);
+  const long long tbase = (long long)o * (N * N) * P.lrest + (long long)chunk * R;
+  const unsigned b0 = ((unsigned)(tid / Q4) * (unsigned)P.lrest + 4u * (tid % Q4)) * 4u;
+  const unsigned bstep = (unsigned)(B / Q4) * (unsigned)P.lrest * 4u;
   const char* const inb = reinterpret_cast<const char*>(reinterpret_cast<const float*>(io.in) + tbase);
   const char* const auxb = reinterpret_cast<const char*>(reinterpret_cast<const float*>(io.aux_in) + tbase);
   const char* const oldb = reinterpret_cast<const char*>(reinterpret_cast<const float*>(io.old) + tbase);
@@ -228,26 +235,40 @@ line32_kernel(const LineDesc P, const LineIO io) {
     const int u = tid + k * B;
     if (!PART4 || u < Geo::UNITS4) *reinterpret_cast<v4f*>(lds + 4 * u) = v[k];
   }
-  // side streams of the J.v epilogue: both fit next to the fragments here (an fp32 tile unit is one register quad)
+  // side streams of the J.v epilogue: v (for "- v" and the dots) travels across the contractions, c2 is fetched behind
+  // them where both would not fit the register budget (R = 32: thirteen quads per stream)
+  constexpr bool C2_EARLY = EPT4 <= 8;
   v4f c2v[MUL ? EPT4 : 1], oldv[MUL ? EPT4 : 1];
   if (MUL) {
 #pragma unroll
     for (int k = 0; k < EPT4; ++k) {
       const bool rowok = !PART4 || tid + k * B < Geo::UNITS4;
-      c2v[MUL ? k : 0] = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(auxb + (rowok ? b0 + k * bstep : b0)));
+      if (C2_EARLY) c2v[MUL ? k : 0] = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(auxb + (rowok ? b0 + k * bstep : b0)));
       if (need_old) oldv[MUL ? k : 0] = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(oldb + (rowok ? b0 + k * bstep : b0)));
     }
   }
   __syncthreads();
-  // contraction over X: column (y, r) at y * 16 + r, row stride LX
+  // contraction over X: column (y, r) at y * R + r, row stride LX; N * R / 16 column tiles go round the four waves
+  constexpr int NCT = N * R / 16;
 #pragma unroll
-  for (int j = 0; j < N / Geo::W; ++j) ctile32<N, Geo::LX>(lds + (wave + j * Geo::W) * 16 + li, lk, q);
+  for (int j = 0; j < NCT / Geo::W; ++j) { ctile32<N, Geo::LX>(lds + (wave + j * Geo::W) * 16 + li, lk, q); __builtin_amdgcn_sched_barrier(0); }
   q.load(P.Qy, lane);
   __syncthreads();
-  // contraction over Y: column (x, r) at x * LX + r, row stride 16
+  // contraction over Y: column (x, r) at x * LX + r, row stride R
 #pragma unroll
-  for (int j = 0; j < N / Geo::W; ++j) ctile32<N, LINE_R>(lds + (wave + j * Geo::W) * Geo::LX + li, lk, q);
+  for (int j = 0; j < NCT / Geo::W; ++j) {
+    const int c = (wave + j * Geo::W) * 16;              // first column of the tile: x = c / R, r = c % R (+ li)
+    ctile32<N, R>(lds + (c / R) * Geo::LX + (c % R) + li, lk, q);
+    __builtin_amdgcn_sched_barrier(0);
+  }
   __syncthreads();
+  if (MUL && !C2_EARLY) {
+#pragma unroll
+    for (int k = 0; k < EPT4; ++k) {
+      const bool rowok = !PART4 || tid + k * B < Geo::UNITS4;
+      c2v[MUL ? k : 0] = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(auxb + (rowok ? b0 + k * bstep : b0)));
+    }
+  }
   double dot_yv = 0.0, dot_yy = 0.0;
 #pragma unroll
   for (int k = 0; k < EPT4; ++k) {
@@ -293,18 +314,25 @@ inline slice_fn slice32_variant(int n) {
     default: return nullptr;
   }
 }
-template <int N> inline line_fn line32_variant_n(int mode) {
-  return mode == L_MID ? (line_fn)line32_kernel<N, L_MID> : (mode == L_JLAST ? (line_fn)line32_kernel<N, L_JLAST> : nullptr);
+// r: row length in floats (line32_row_floats)
+template <int N, int R> inline line_fn line32_variant_nr(int mode) {
+  return mode == L_MID ? (line_fn)line32_kernel<N, L_MID, R> : (mode == L_JLAST ? (line_fn)line32_kernel<N, L_JLAST, R> : nullptr);
 }
-inline line_fn line32_variant(int n, int mode) {
+template <int N> inline line_fn line32_variant_n(int mode, int r) {
+  if constexpr (N <= 24) { if (r == 32) return line32_variant_nr<N, 32>(mode); }      // (32 x 32 x 32 floats would be 128 KB)
+  return r == 16 ? line32_variant_nr<N, 16>(mode) : nullptr;
+}
+inline line_fn line32_variant(int n, int mode, int r) {
   switch (n) {
-    case 16: return line32_variant_n<16>(mode);
-    case 20: return line32_variant_n<20>(mode);
-    case 24: return line32_variant_n<24>(mode);
-    case 32: return line32_variant_n<32>(mode);
+    case 16: return line32_variant_n<16>(mode, r);
+    case 20: return line32_variant_n<20>(mode, r);
+    case 24: return line32_variant_n<24>(mode, r);
+    case 32: return line32_variant_n<32>(mode, r);
     default: return nullptr;
   }
 }
 #endif
+// row length of the fp32 line tiles of a pass: one whole 128-byte line where the remainder allows it
+inline int line32_row_floats(int n, long long lrest) { return (n <= 24 && lrest % 32 == 0) ? 32 : 16; }
 
 }  // namespace sdfs

@@ -880,7 +880,8 @@ int build_fast_plan(sdfs_handle* h) {
       hipFuncSetAttribute((const void*)f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)line_lds_bytes(P.n));
       line_fn f32 = line_variant(P.n, m, false, true, true);
       if (f32) hipFuncSetAttribute((const void*)f32, hipFuncAttributeMaxDynamicSharedMemorySize, (int)line_lds_bytes(P.n));
-      if (line_fn m32 = line32_variant(P.n, m)) hipFuncSetAttribute((const void*)m32, hipFuncAttributeMaxDynamicSharedMemorySize, (int)line32_lds_bytes(P.n));
+      for (int r32 = 16; r32 <= 32; r32 += 16)
+        if (line_fn m32 = line32_variant(P.n, m, r32)) hipFuncSetAttribute((const void*)m32, hipFuncAttributeMaxDynamicSharedMemorySize, (int)line32_lds_bytes(P.n, r32));
     }
   }
   bool f32_ok = true;
@@ -1245,13 +1246,14 @@ int run_fast_plan(sdfs_handle* h, int mode, const double* in, double* out, const
         grid = lm == L_MID ? stream_mid_grid(h, P) : (unsigned)d.ntiles;
       }
       const bool m32 = lf32 && h->krylov_mfma32 && mode == MODE_JVP && !t32;
-      if (m32) { fn = line32_variant(P.n, lm); grid = (unsigned)d.ntiles; }
+      const int r32 = line32_row_floats(P.n, P.ld.lrest);
+      if (m32) { fn = line32_variant(P.n, lm, r32); grid = (unsigned)(d.ntiles * LINE_R / r32); }
       if (!fn) return fail(h, SDFS_ERR_UNSUPPORTED, "no line kernel variant");
       if (f32 && mode == MODE_JVP) bytes *= 0.5;
       int cid = -1;
       if (h->profiling) { char nm[48]; snprintf(nm, sizeof nm, "%s:%s", m32 ? "jvpm32" : tag, P.label.c_str()); cid = counter_id(h, nm, bytes, P.flops); }
       ProfScope ps(h, cid);
-      hipLaunchKernelGGL(fn, dim3(grid), dim3(m32 ? 256 : line_block(P.n)), m32 ? line32_lds_bytes(P.n) : line_lds_bytes(P.n), h->stream, d, io);
+      hipLaunchKernelGGL(fn, dim3(grid), dim3(m32 ? 256 : line_block(P.n)), m32 ? line32_lds_bytes(P.n, r32) : line_lds_bytes(P.n), h->stream, d, io);
     }
     HIPCHK(h, hipGetLastError());
     if (f32 && h->krylov_bf16) {
@@ -1268,7 +1270,12 @@ int run_fast_plan(sdfs_handle* h, int mode, const double* in, double* out, const
 long long jvp_last_tiles(sdfs_handle* h) {
   if (h->cont || h->dense) return 0;
   if (h->fast.ok && h->fast.small) return h->krylov_f32 ? h->plan[0].passes.back().d.ntiles : (long long)small_grid(h->fast.passes.back().sm, h->fast.passes.back().wpt);
-  if (h->fast.ok && h->krylov_f32 && h->fast.f32_ok) return h->fast.passes.back().ld.ntiles;
+  if (h->fast.ok && h->krylov_f32 && h->fast.f32_ok) {
+    const FastPass& PL = h->fast.passes.back();
+    // (the fp32-MFMA last pass walks chunks of 32 floats where the remainder allows it: half the workgroups)
+    if (h->krylov_mfma32 && !h->fast.small && PL.line) return PL.ld.ntiles * LINE_R / line32_row_floats(PL.n, PL.ld.lrest);
+    return PL.ld.ntiles;
+  }
   if (h->fast.ok && h->fast.pad) return h->krylov_f32 ? (h->plan[0].passes.empty() ? 0 : h->plan[0].passes.back().d.ntiles) : h->fast.passes.back().pd.ntiles;
   if (h->fast.ok && !h->krylov_f32) return line_grid(h, h->fast.passes.back());
   return h->plan[0].passes.empty() ? 0 : h->plan[0].passes.back().d.ntiles;

@@ -714,19 +714,23 @@ k_and_mix_y(AndPtrs h, const AndState* __restrict__ S, int m, double beta, doubl
 // default-policy forms 5.1-5.7, hipMemcpyAsync 4.6-5.5).  bench.py prints it as `copy_ceiling_GBps`.
 constexpr int COPY_UNITS = 8;
 __global__ void __launch_bounds__(VEC_BLOCK) k_stream_copy(const double* __restrict__ in, double* __restrict__ out, long long units, long long n) {
-  const long long c0 = (long long)blockIdx.x * (VEC_BLOCK * COPY_UNITS);
-  v2d v[COPY_UNITS];
-#pragma unroll
-  for (int k = 0; k < COPY_UNITS; ++k) {
-    const long long i = c0 + threadIdx.x + (long long)VEC_BLOCK * k;
-    if (i < units) v[k] = __builtin_nontemporal_load(reinterpret_cast<const v2d*>(in) + i);
-  }
-#pragma unroll
-  for (int k = 0; k < COPY_UNITS; ++k) {
-    const long long i = c0 + threadIdx.x + (long long)VEC_BLOCK * k;
-    if (i < units) __builtin_nontemporal_store(v[k], reinterpret_cast<v2d*>(out) + i);
-  }
   if (blockIdx.x == 0 && threadIdx.x == 0 && (n & 1)) out[n - 1] = in[n - 1];
+  if (units == 0) return;
+  const long long c0 = (long long)blockIdx.x * (VEC_BLOCK * COPY_UNITS) + threadIdx.x;
+  const v2d* const src = reinterpret_cast<const v2d*>(in);
+  v2d* const dst = reinterpret_cast<v2d*>(out);
+  v2d v[COPY_UNITS];
+  // (unconditional loads from clamped indices: a load inside `if (i < units)` makes the compiler wait for each one)
+#pragma unroll
+  for (int k = 0; k < COPY_UNITS; ++k) {
+    const long long i = c0 + (long long)VEC_BLOCK * k;
+    v[k] = __builtin_nontemporal_load(src + (i < units ? i : units - 1));
+  }
+#pragma unroll
+  for (int k = 0; k < COPY_UNITS; ++k) {
+    const long long i = c0 + (long long)VEC_BLOCK * k;
+    if (i < units) __builtin_nontemporal_store(v[k], dst + i);
+  }
 }
 
 // ---- re-shard pack / unpack (multi-GPU exchange buffers) -----------------------------------------------------------------
