@@ -126,7 +126,7 @@ def cpu_literal_apply():
 def newton_roofline(op, w_host, N, krylov_f32, inner=1e-6):
     """Per-kernel algorithmic bytes / HIP-event time of one more Newton-Krylov solve with events around every launch
     (code/solvers.py:51-95; configs[3]'s algorithm): the three passes of J.v, the fused BLAS-1 group of BiCGSTAB
-    (144 bytes per point and iteration in fp64, 72 in fp32 storage, over the group's summed kernel time),
+    (stream counts below, over the group's summed kernel time),
     the linearising applications of T, and one BiCGSTAB iteration as a whole against the HBM peak."""
     op.set_profiling(True)
     op.reset_counters()
@@ -142,7 +142,16 @@ def newton_roofline(op, w_host, N, krylov_f32, inner=1e-6):
         if tag in ("jvp", "jvp32", "jvpm32"):
             fam.setdefault(tag, c["launches"])
     iters = sum(fam.values()) / 2.0
-    out = {"kernels": [], "newton_steps": n, "bicgstab_iterations": iters}
+    it64 = fam.get("jvp", 0) / 2.0                 # iterations on fp64 vectors (all of them, or the odd steps redone)
+    fused = any(c["name"].startswith("jvp+") for c in cs)
+    # grid streams of one iteration: 2 J.v of 9 (3 + 2 + 4) and 16 of BLAS-1 (p update 4, <rhat, q> 2,
+    # s update 3, x / r update 7; <t, s> and <t, t> come out of J.v's last pass) = 34; with the p and s updates in J.v's
+    # first pass and <rhat, q> in its last (csrc/krylov_kernels.hpp) 6 + 2 + 5, 5 + 2 + 4 and the x / r update's 7 = 31
+    s64, b64 = (31, 7) if fused else (34, 16)
+    it_bytes_sum = (it64 * s64 * 8.0 + (iters - it64) * 34 * 4.0) * N
+    b1_bytes_sum = (it64 * b64 * 8.0 + (iters - it64) * 16 * 4.0) * N
+    out = {"kernels": [], "newton_steps": n, "bicgstab_iterations": iters, "bicgstab_iterations_fp64": it64,
+           "updates_fused_into_jvp": fused}
     t_jv = t_b1 = 0.0
     for c in cs:
         avg = c["total_ms"] / c["launches"]
@@ -155,18 +164,16 @@ def newton_roofline(op, w_host, N, krylov_f32, inner=1e-6):
             t_jv += c["total_ms"]
         if c["name"] == "bicgstab_blas1":
             t_b1 = c["total_ms"]
-            b1_bytes = (72.0 if krylov_f32 else 144.0) * N
-            row["alg_GB_per_iteration"] = b1_bytes / 1e9
+            row["alg_GB_per_iteration"] = b1_bytes_sum / max(iters, 1) / 1e9
             row["ms_per_iteration"] = t_b1 / max(iters, 1)
-            row["GBps"] = b1_bytes / (row["ms_per_iteration"] * 1e-3) / 1e9
+            row["GBps"] = b1_bytes_sum / (t_b1 * 1e-3) / 1e9
             row["frac_hbm"] = row["GBps"] / HBM_PEAK_GBS
         out["kernels"].append(row)
     if iters > 0:
-        it_bytes = (144.0 if krylov_f32 else 288.0) * N      # 2 J.v (72 B / point each in fp64) + the BLAS-1 group
         it_ms = (t_jv + t_b1) / iters
-        out["iteration"] = {"alg_GB": it_bytes / 1e9, "ms": it_ms, "GBps": it_bytes / (it_ms * 1e-3) / 1e9,
-                            "frac_hbm": it_bytes / (it_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                            "bytes_per_point": it_bytes / N}
+        out["iteration"] = {"alg_GB": it_bytes_sum / iters / 1e9, "ms": it_ms, "GBps": it_bytes_sum / ((t_jv + t_b1) * 1e-3) / 1e9,
+                            "frac_hbm": it_bytes_sum / ((t_jv + t_b1) * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                            "bytes_per_point": it_bytes_sum / iters / N}
     return out
 
 
@@ -196,10 +203,16 @@ def main():
     ap.add_argument("--steps", type=int, default=200)     # 0.2 s of timed work; the first ~50 steps after an
     ap.add_argument("--warmup", type=int, default=50)     # idle period run ~5 % slower (clock ramp)
     ap.add_argument("--workload", default="gcy20", choices=sorted(WORKLOADS))
+    ap.add_argument("--allow-knobs", action="store_true", help="run although SDFS_* kernel-plan variables are set")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
     args = ap.parse_args()
 
+    # the library's test knobs change the kernels that run (SDFS_PLAN=classic is the round-1 path): a measurement must not
+    # pick one up by accident
+    knobs = sorted(k for k in os.environ if k.startswith("SDFS_") and k not in ("SDFS_BENCH_BACKEND", "SDFS_BENCH_SHARDED", "SDFS_BENCH_MIRROR"))
+    if knobs and not args.allow_knobs:
+        raise SystemExit(f"bench.py: kernel-plan variables set in the environment ({', '.join(knobs)}); unset them or pass --allow-knobs")
     # SDFS_BENCH_BACKEND=gloo rehearses the N > 1 path on a single GPU (all ranks on one device,
     # exchanges staged through the host); the real run uses RCCL ("nccl"), one rank per GPU.
     backend = os.environ.get("SDFS_BENCH_BACKEND", "nccl")
@@ -348,7 +361,7 @@ def main():
         "dtype": "f64", "data": "synthetic",
         "config": {"workload": f"{model.upper()} {'x'.join(map(str, shapes))} grid, successive-approximation "
                                f"step (T apply + fused sup-norm residual), default calibration, Rouwenhorst",
-                   "grid_points": N, "spinup_steps": SPINUP, "plan": plan_now},
+                   "grid_points": N, "spinup_steps": SPINUP, "plan": plan_now, "env_knobs": knobs},
         "roofline": {"bound": "hbm", "kernel": dom["name"], "achieved": achieved, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "traffic_source": traffic_source,
@@ -437,6 +450,26 @@ def main():
             t = time.perf_counter() - t0
             sec["gcy20_anderson_1e-6_device"] = {"iterations": n_a, "seconds": t, "ms_per_iteration": t / max(n_a, 1) * 1e3,
                                                  "final_err": info["final_err"]}
+            # ... and to the metric's tolerance, 1e-8 (on Anderson's own error, |T x - x|_2 -- stricter than the sup-norm step
+            # of successive approximation): the reference's absolute ridge 1e-6 (code/solvers.py:113) and the opt-in relative
+            # ridge (sdfs_opts.ridge < 0: |ridge| trace(G) / m; profiles/round4_anderson_ridge.txt), successive approximation
+            # to a sup-norm step of 1e-8 beside them
+            for key, kw in (("gcy20_anderson_1e-8_device", dict(ridge=1e-6)), ("gcy20_anderson_1e-8_relative_ridge_1e-6", dict(ridge=-1e-6))):
+                ws.fill_(800.0)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                n_a, info = op.solve_dev(ws.data_ptr(), "anderson", tol=1e-8, max_iter=6000, **kw)
+                torch.cuda.synchronize()
+                t = time.perf_counter() - t0
+                sec[key] = {"iterations": n_a, "seconds": t, "ms_per_iteration": t / max(n_a, 1) * 1e3, "final_err_l2": info["final_err"],
+                            "status": info["status"]}
+            ws.fill_(800.0)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            n_sa, info = op.solve_dev(ws.data_ptr(), "successive_approx", tol=1e-8, max_iter=100000)
+            torch.cuda.synchronize()
+            t = time.perf_counter() - t0
+            sec["gcy20_successive_approx_1e-8_device"] = {"iterations": n_sa, "seconds": t, "final_err_sup": info["final_err"]}
             del ws
             # the conditional-tensor kernels at full size: Rouwenhorst tensors are slice-identical, so the headline
             # runs the merged (unconditional) plan; SDFS_NO_SLICE_MERGE keeps z_Q (25.6 MB) / z_pi_Q conditional

@@ -59,7 +59,8 @@ typedef struct sdfs_opts {
                           * code/solvers.py:113).  < 0 (opt-in, NOT the reference's semantics): relative,
                           * |ridge| * trace(G) / history -- on grids of 1e7 .. 1e8 points the Gram entries N r^2 sink
                           * below an absolute 1e-6 while the residual is still 1e-6 and the acceleration stalls */
-  int32_t check_every;   /* host polls the device residual every k iterations (>=1): SA and Anderson enqueue (or replay from
+  int32_t check_every;   /* 0 (default): the library's choice -- 32, or 120 where the fused small-grid Anderson loop runs.
+                            k >= 1: the host polls the device residual every k iterations: SA and Anderson enqueue (or replay from
                             a hipGraph) k gated iterations per synchronisation -- rounded up to an even number (SA) or to a
                             multiple of `history` (Anderson); the iterates, counts and error trace do not depend on k */
   int32_t use_graph;     /* 1: replay the iteration chunk from a hipGraph   */

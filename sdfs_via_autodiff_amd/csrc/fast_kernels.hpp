@@ -437,6 +437,8 @@ struct LineIO {
   double gate_tol;
   double* dotp;             // J.v with minus_identity: per-workgroup partial sums <out, v>, <out, out>: [2][gridDim.x]
   unsigned* sched;          // persistent form: {next tile ticket, finished workgroups}, both zero between launches
+  const double* dot_with;   // streamed last pass of J.v (stream_kernels.hpp): also <out, dot_with> into dotp[2][gridDim.x]
+                            // (BiCGSTAB's <rhat, q>, krylov_kernels.hpp)
 };
 
 template <int N> struct LineGeo {
@@ -1528,7 +1530,13 @@ template <int N> inline line_fn line_variant_f32(int mode) {
 }
 template <int N> inline line_fn line_variant_pf(int mode, bool persist, bool fullc, bool f32) {
   if (f32) return (fullc && !persist) ? line_variant_f32<N>(mode) : nullptr;
+#ifdef SDFS_DIAG
+  // round 2's persistent form (SDFS_LINE_PERSIST; superseded by stream_kernels.hpp): diagnostic builds only -- the shipped
+  // library neither reads the knob nor carries these forty instantiations
   if (persist) return fullc ? line_variant_n<N, true, true>(mode) : line_variant_n<N, true, false>(mode);
+#else
+  if (persist) return nullptr;
+#endif
   return fullc ? line_variant_n<N, false, true>(mode) : line_variant_n<N, false, false>(mode);
 }
 // fullc: lrest % 16 == 0 (no partial chunk anywhere in the pass); f32: fp32 storage of the J.v streams / of c2

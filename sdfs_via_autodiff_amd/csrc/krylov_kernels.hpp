@@ -1,0 +1,155 @@
+// krylov_kernels.hpp -- BiCGSTAB vector updates folded into the first pass of J.v (round 4).
+//
+// The inner solve of the Newton step (jax.scipy.sparse.linalg.bicgstab at code/solvers.py:91-93 on the matrix-free
+// J.v of :87) is HBM-bound on large grids: at GCY 20^6 an iteration moves 34 grid streams -- two J.v applications of nine
+// each and sixteen of fused BLAS-1 -- at 0.71 of the HBM peak (bench.py, secondary.gcy20_newton_1e-8.roofline).  What is
+// left is the stream count.  Two of the BLAS-1 kernels produce exactly the vector the next J.v application starts from:
+//     p = r + beta (p - omega q)     then  q = (J - I) p        (k_bicg_update_p, 4 streams + J.v's 3 in its first pass)
+//     s = r - alpha q (in r), <s,s>  then  t = (J - I) s        (k_bicg_s, 3 streams + 3)
+// slice_jfused_kernel does either update on the registers of J.v's first pass -- the slice pass over the two fastest axes
+// (fast_kernels.hpp), x = c1 * v -- and writes the updated vector back beside the pass's own output: 6 and 5 streams
+// instead of 7 and 6.  The third stream saved is <rhat, q>, summed by the last pass of the first J.v application (which
+// holds q and reads p for its "- v" anyway: line_stream_kernel, LineIO::dot_with) instead of a kernel of its own:
+// 31 streams per iteration instead of 34, the same arithmetic (the sums are added in another order).
+// fp64 Krylov storage on the compile-time pair plan; the other plans and the fp32 forms keep the separate kernels.
+#pragma once
+#include "stream_kernels.hpp"
+#include "vec_kernels.hpp"
+
+namespace sdfs {
+
+enum { JF_P = 0, JF_S = 1 };
+
+struct JFusedIO {
+  double* upd;              // JF_P: p;  JF_S: r (becomes s) -- read, updated in place, and the vector J.v is applied to
+  const double* a;          // JF_P: r
+  const double* q;
+  const double* c1;
+  double* out;              // the pass's output (the intermediate of the J.v application)
+  const double* sc;         // scalar block of the recurrence (vec_kernels.hpp): beta, omega / alpha
+  double* dot;              // JF_S: per-wave-tile partial sums of <s, s>
+  const unsigned long long* gate;
+};
+
+template <int N, int KIND>
+__global__ void __launch_bounds__(256, 3)
+slice_jfused_kernel(const SliceDesc P, const JFusedIO io) {
+  using Geo = SliceGeo<N>;
+  constexpr int BU = 2;                                            // units per batch (two batches in flight)
+  constexpr int NB = (Geo::EPT + BU - 1) / BU;
+  extern __shared__ double lds[];
+  SDFS_GATED(io.gate);
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const long long tile = (long long)blockIdx.x * Geo::WAVES + wave;
+  const long long s0 = tile * Geo::G;
+  if (s0 >= P.nslices) return;                                     // no workgroup barrier below
+  const long long rem = (P.nslices - s0) * (N * N / 2);
+  const int nvalid = rem < Geo::UNITS ? (int)rem : Geo::UNITS;
+  double* const wl = lds + wave * Geo::LTILE;
+  auto lofs = [](const int e) -> int { return Geo::RS == N ? e : (e / N) * Geo::RS + (e % N); };
+  const long long gbase = s0 * (N * N);
+  const unsigned lb = (unsigned)lane * 16u;
+  char* const updb = reinterpret_cast<char*>(io.upd + gbase);
+  const char* const ab = reinterpret_cast<const char*>(io.a + gbase);
+  const char* const qb = reinterpret_cast<const char*>(io.q + gbase);
+  const char* const cb = reinterpret_cast<const char*>(io.c1 + gbase);
+  const double c_a = KIND == JF_P ? io.sc[SC_BETA] : io.sc[SC_ALPHA];
+  const double c_b = KIND == JF_P ? io.sc[SC_OMEGA] : 0.0;
+  struct Unit { v2d u, a, q, c; };
+  auto load = [&](Unit (&B)[BU], const int b) {
+#pragma unroll
+    for (int j = 0; j < BU; ++j) {
+      const int k = b * BU + j;
+      // (a unit beyond the tile, or in a slice a trailing tile does not have, re-reads unit 0's piece: finite values
+      // that are neither stored nor parked into a slice that is)
+      const unsigned off = (k < Geo::EPT && lane + 64 * k < nvalid) ? lb + 1024u * k : lb;
+      B[j].u = *reinterpret_cast<const v2d*>(updb + off);
+      if (KIND == JF_P) B[j].a = ldg_stream(ab + off);
+      B[j].q = *reinterpret_cast<const v2d*>(qb + off);
+      B[j].c = *reinterpret_cast<const v2d*>(cb + off);
+    }
+  };
+  double ss = 0.0;
+  auto work = [&](const Unit (&B)[BU], const int b) {
+#pragma unroll
+    for (int j = 0; j < BU; ++j) {
+      const int k = b * BU + j;
+      if (k >= Geo::EPT) continue;
+      const int u = lane + 64 * k;
+      v2d nv;
+      if (KIND == JF_P) {                                          // p = r + beta (p - omega q)          (k_bicg_update_p)
+        nv.x = B[j].a.x + c_a * (B[j].u.x - c_b * B[j].q.x);
+        nv.y = B[j].a.y + c_a * (B[j].u.y - c_b * B[j].q.y);
+      } else {                                                     // s = r - alpha q, <s, s>             (k_bicg_s)
+        nv.x = B[j].u.x - c_a * B[j].q.x;
+        nv.y = B[j].u.y - c_a * B[j].q.y;
+      }
+      if (u < nvalid) {
+        *reinterpret_cast<v2d*>(updb + (lb + 1024u * k)) = nv;
+        if (KIND == JF_S) { ss += nv.x * nv.x; ss += nv.y * nv.y; }
+      }
+      if (Geo::UNITS % 64 == 0 || u < Geo::UNITS) *reinterpret_cast<v2d*>(wl + lofs(2 * u)) = (v2d){nv.x * B[j].c.x, nv.y * B[j].c.y};
+    }
+  };
+  {
+    Unit B0[BU], B1[BU];
+    load(B0, 0);
+#pragma unroll
+    for (int b = 0; b < NB; b += 2) {
+      if (b + 1 < NB) load(B1, b + 1);
+      work(B0, b);
+      if (b + 2 < NB) load(B0, b + 2);
+      if (b + 1 < NB) work(B1, b + 1);
+    }
+  }
+  if (KIND == JF_S) {
+    ss = wave_sum(ss);
+    if (lane == 0) io.dot[tile] = ss;
+  }
+  QFrag<N> qf;
+  qf.load(P.Qf, lane);
+  wave_lds_fence();
+  const int li = lane & 15, lk = lane >> 4;
+  {
+    double* const p0 = wl + li * Geo::RS + lk;
+#pragma unroll
+    for (int ct = 0; ct < Geo::NCT; ++ct) ctile<N, 1>(p0 + ct * 16 * Geo::RS, qf);
+  }
+  wave_lds_fence();
+  {
+    QFrag<N> qe;
+    qe.load(P.Qe, lane);
+#pragma unroll
+    for (int ct = 0; ct < Geo::NCT; ++ct) {
+      const int c = 16 * ct + li;
+      const int g = c / N, f = c - g * N;
+      ctile<N, Geo::RS>(wl + g * (N * Geo::RS) + f + lk * Geo::RS, qe);
+    }
+  }
+  wave_lds_fence();
+  char* const outb = reinterpret_cast<char*>(io.out + gbase);
+#pragma unroll
+  for (int k = 0; k < Geo::EPT; ++k) {
+    const int u = lane + 64 * k;
+    if (u < nvalid) *reinterpret_cast<v2d*>(outb + (lb + 1024u * k)) = *reinterpret_cast<const v2d*>(wl + lofs(2 * u));
+  }
+}
+
+typedef void (*jfused_fn)(const SliceDesc, const JFusedIO);
+#ifndef SDFS_NO_VARIANT_TABLES
+template <int N> inline jfused_fn slice_jfused_variant_n(int kind) {
+  return kind == JF_P ? (jfused_fn)slice_jfused_kernel<N, JF_P> : (jfused_fn)slice_jfused_kernel<N, JF_S>;
+}
+inline jfused_fn slice_jfused_variant(int n, int kind) {
+  switch (n) {
+    case 16: return slice_jfused_variant_n<16>(kind);
+    case 20: return slice_jfused_variant_n<20>(kind);
+    case 24: return slice_jfused_variant_n<24>(kind);
+    case 32: return slice_jfused_variant_n<32>(kind);
+    default: return nullptr;
+  }
+}
+#endif
+
+}  // namespace sdfs

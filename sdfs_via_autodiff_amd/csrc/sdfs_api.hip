@@ -28,6 +28,7 @@
 #include "cont_kernel.hpp"
 #include "dense_kernel.hpp"
 #include "vec_kernels.hpp"
+#include "krylov_kernels.hpp"
 
 using namespace sdfs;
 
@@ -152,6 +153,7 @@ struct sdfs_handle {
   // plans: [0] full grid (or stage 0 of a sharded run), [1] stage 1 of a sharded run
   Plan plan[2];
   FastPlan fast;                      // pair plan of the full grid, when the model admits it
+  FastPlan sfast[2];                  // sharded handle: the two stages on the pair plan's kernels (build_stage_fast_plans)
   unsigned* sched = nullptr;          // tile tickets of the persistent line passes (SCHED_WORDS per pass, zero between launches)
   AndState* and_state = nullptr;      // device-resident Anderson loop: state (two buffers: the fused small-grid form alternates), per-chunk record of its passes
   AndState* and_state_host = nullptr;
@@ -175,6 +177,7 @@ struct sdfs_handle {
   bool krylov_f32 = false;
   std::vector<double> a3_host;       // host copy of the a3 table (the pair plan looks for its two-table form)
   bool t32_active = false;           // successive approximation, opts.t_f32: T applications keep their intermediates as scaled floats
+  bool check_every_default = false;  // the running solve was given check_every <= 0 (sdfs_solve_dev)
   bool krylov_mfma32 = false;        // ... with the J.v passes of the pair plan on an fp32 LDS tile and fp32 MFMA (opts.krylov_f32 = 3: f32_kernels.hpp)
   bool krylov_bf16 = false;          // ... with every store of those fp32 containers rounded to bfloat16 (opts.krylov_f32 = 2: bf16r, vec_kernels.hpp)
   double lin_ref = 0.0;              // sharded handles: reference value of the fp32 linearisation scale (sdfs_set_krylov_f32)
@@ -215,6 +218,12 @@ struct sdfs_handle {
 
   // graph cache for the SA chunk
   const double* jvp_dot_with = nullptr;                // set around a J.v call: the last pass also sums <out, this> (small-grid plan)
+  // set around the J.v calls of a fused BiCGSTAB iteration on the compile-time pair plan (krylov_kernels.hpp): the first
+  // pass forms p or s on its registers (kind JF_P / JF_S, -1: plain first pass), the last pass is the streamed form with
+  // one workgroup per tile and, where dot_with is set, a third sum
+  struct { bool active = false; int kind = -1; double* upd = nullptr; const double* a = nullptr; const double* q = nullptr;
+           double* dot = nullptr; const double* dot_with = nullptr; } jf;
+  double* jf_ss = nullptr; long long jf_ss_n = 0;     // per-wave-tile partial sums of <s, s>
   int bicg_graph_chunk[2] = {0, 0};                    // iterations in the captured graph
   hipGraphExec_t bicg_graph[2] = {nullptr, nullptr};   // one BiCGSTAB iteration (fp64 / fp32 Krylov storage)
   unsigned long long* bicg_gate = nullptr;             // device flag the iteration's kernels are gated on
@@ -279,12 +288,13 @@ Knobs read_knobs() {
   k.cont_lds_cap = env_int("SDFS_CONT_LDS_CAP", 4000);
   k.no_bicg_merge = env_int("SDFS_NO_BICG_MERGE", 0);
   k.small_xcd = env_int("SDFS_SMALL_XCD", 1);
-#endif
-  k.no_slice_merge = env_int("SDFS_NO_SLICE_MERGE", 0);
+  // round 4: measured and settled in rounds 2-3, no test sets them any more
   k.pair_order = env_int("SDFS_PAIR_ORDER", 1);
   k.line_persist = env_int("SDFS_LINE_PERSIST", 0);
-  k.line_stream = env_int("SDFS_LINE_STREAM", 3);
   k.a3_tables = env_int("SDFS_A3_TABLES", 1);
+#endif
+  k.no_slice_merge = env_int("SDFS_NO_SLICE_MERGE", 0);
+  k.line_stream = env_int("SDFS_LINE_STREAM", 3);
   k.small_plan = env_int("SDFS_SMALL_PLAN", 1);
   k.small_r = env_int("SDFS_SMALL_R", 0);
   k.sa_fused = env_int("SDFS_SA_FUSED", -1);
@@ -750,133 +760,112 @@ int upload_ints(sdfs_handle* h, const std::vector<int>& v, int** out) {
   return 0;
 }
 
-int build_fast_plan(sdfs_handle* h) {
-  h->fast.ok = false;
-  h->fast.small = false;
-  h->fast.pad = false;
-  h->fast.passes.clear();
+// One pass of the pair plan over a block of the grid: shp = local extents (a sharded stage holds a block of one axis,
+// the whole-grid plan all of every axis), off = global index of local index 0 on every axis.
+void make_slice_pass(sdfs_handle* h, const int* shp, FastPass& P) {
   const int D = h->ndim;
-  if (h->knobs.plan == 1 || h->sharded || h->cont || h->dense || (D != 4 && D != 6) || h->a3 == nullptr) return 0;
-  if (h->N >= (1LL << 29)) return 0;                       // 32-bit byte offsets inside a tile
-  for (int a = 0; a < D; ++a) {
-    if (h->ax[a].qcount != 1) return 0;
-    for (int c = 0; c < D; ++c) if (h->ax[a].qs[c] != 0) return 0;
-    if (h->ax[a].a3s < 0 || h->ax[a].a3s >= (1 << 24)) return 0;
+  long long stride[MAXD], nloc = 1;
+  for (int a = D - 1; a >= 0; --a) { stride[a] = nloc; nloc *= shp[a]; }
+  const int n = shp[D - 1];
+  P.line = false; P.n = n; P.ax0 = D - 2; P.ax1 = D - 1;
+  memset(&P.sd, 0, sizeof P.sd);
+  P.sd.nslices = nloc / ((long long)n * n);
+  P.sd.Qf = h->ax[D - 1].Q; P.sd.Qe = h->ax[D - 2].Q; P.sd.theta = h->theta;
+  for (int c = D - 1; c >= 0; --c) P.sd.ref_off += (long long)(shp[c] / 2) * stride[c];
+  P.q_bytes = 2 * 8.0 * n * n; P.flops = 2.0 * (double)nloc * 2 * n;
+  P.label = std::string("slices[") + h->ax[D - 2].name + "," + h->ax[D - 1].name + "|wave-private " +
+            std::to_string(slice_tile_slices(n, S_TFIRST)) + "x" + std::to_string(n) + "x" + std::to_string(n) + "]";
+}
+
+// line pass over the pair (a, a + 1), with the index tables of the aggregator's a3 gather when `tables`; returns 1
+// when the block does not fit the kernels' index ranges (the caller then keeps the generic tiles)
+int make_line_pass(sdfs_handle* h, const int* shp, const int* off, int a, bool tables, FastPass& P) {
+  const int D = h->ndim;
+  long long stride[MAXD], nloc = 1;
+  for (int c = D - 1; c >= 0; --c) { stride[c] = nloc; nloc *= shp[c]; }
+  const int n = shp[a];
+  P.line = true; P.n = n; P.ax0 = a; P.ax1 = a + 1;
+  memset(&P.ld, 0, sizeof P.ld);
+  LineDesc& L = P.ld;
+  L.lrest = stride[a + 1];
+  if (L.lrest % 2 != 0) return 1;
+  L.nchunks = (int)((L.lrest + LINE_R - 1) / LINE_R);
+  L.nouter = nloc / ((long long)n * n * L.lrest);
+  L.ntiles = L.nouter * L.nchunks;
+  if (L.ntiles >= (1LL << 31) || (long long)n * n * L.lrest * 8 >= (1LL << 32)) return 1;
+  L.Qx = h->ax[a].Q; L.Qy = h->ax[a + 1].Q;
+  L.inv_theta = 1.0 / h->theta; L.beta = h->beta; L.theta = h->theta;
+  L.cbt = (double)powl((long double)h->beta, (long double)h->theta);
+  L.a3x = h->ax[a].a3s; L.a3y = h->ax[a + 1].a3s;
+  for (int c = D - 1; c >= 0; --c) L.ref_off += (long long)(shp[c] / 2) * stride[c];
+  P.q_bytes = 2 * 8.0 * n * n; P.flops = 2.0 * (double)nloc * 2 * n;
+  P.label = std::string("lines[") + h->ax[a].name + "," + h->ax[a + 1].name + "|" + std::to_string(n) + "x" +
+            std::to_string(n) + "x16 tile]";
+  if (!tables) return 0;
+  // index tables of the aggregator's a3 gather: a3 index = out_idx[outer] + x a3s[X] + y a3s[Y] + rest_idx[position behind Y]
+  std::vector<int> outv((size_t)L.nouter, 0), restv((size_t)L.lrest, 0);
+  for (long long o = 0; o < L.nouter; ++o) {
+    long long r = o; int idx = 0;
+    for (int c = a - 1; c >= 0; --c) { idx += (off[c] + (int)(r % shp[c])) * h->ax[c].a3s; r /= shp[c]; }
+    outv[(size_t)o] = idx;
   }
-  for (int a = 0; a < D; a += 2) {
-    const int n = h->shape[a];
-    if (n != h->shape[a + 1] || !(n == 16 || n == 20 || n == 24 || n == 32)) return 0;
+  for (long long q = 0; q < L.lrest; ++q) {
+    long long r = q; int idx = 0;
+    for (int c = D - 1; c > a + 1; --c) { idx += (off[c] + (int)(r % shp[c])) * h->ax[c].a3s; r /= shp[c]; }
+    restv[(size_t)q] = idx;
   }
-  long long stride[MAXD];
-  { long long st = 1; for (int a = D - 1; a >= 0; --a) { stride[a] = st; st *= h->shape[a]; } }
-  std::vector<FastPass> passes;
-  {
-    FastPass P;
-    const int n = h->shape[D - 1];
-    P.line = false; P.n = n; P.ax0 = D - 2; P.ax1 = D - 1;
-    memset(&P.sd, 0, sizeof P.sd);
-    P.sd.nslices = h->N / ((long long)n * n);
-    P.sd.Qf = h->ax[D - 1].Q; P.sd.Qe = h->ax[D - 2].Q; P.sd.theta = h->theta;
-    for (int c = D - 1; c >= 0; --c) P.sd.ref_off += (long long)(h->shape[c] / 2) * stride[c];
-    P.q_bytes = 2 * 8.0 * n * n; P.flops = 2.0 * (double)h->N * 2 * n;
-    P.label = std::string("slices[") + h->ax[D - 2].name + "," + h->ax[D - 1].name + "|wave-private " +
-              std::to_string(slice_tile_slices(n, S_TFIRST)) + "x" + std::to_string(n) + "x" + std::to_string(n) + "]";
-    passes.push_back(P);
-  }
-  long long min_tiles = 1LL << 60;
-  std::vector<int> line_axes;
-  for (int a = D - 4; a >= 0; a -= 2) line_axes.push_back(a);
-  if (h->knobs.pair_order == 1) std::reverse(line_axes.begin(), line_axes.end());
-  for (int a : line_axes) {
-    FastPass P;
-    const int n = h->shape[a];
-    P.line = true; P.n = n; P.ax0 = a; P.ax1 = a + 1;
-    memset(&P.ld, 0, sizeof P.ld);
-    LineDesc& L = P.ld;
-    L.lrest = stride[a + 1];
-    if (L.lrest % 2 != 0) return 0;
-    L.nchunks = (int)((L.lrest + LINE_R - 1) / LINE_R);
-    L.nouter = h->N / ((long long)n * n * L.lrest);
-    L.ntiles = L.nouter * L.nchunks;
-    if (L.ntiles >= (1LL << 31) || (long long)n * n * L.lrest * 8 >= (1LL << 32)) return 0;
-    L.Qx = h->ax[a].Q; L.Qy = h->ax[a + 1].Q;
-    L.inv_theta = 1.0 / h->theta; L.beta = h->beta; L.theta = h->theta;
-    L.cbt = (double)powl((long double)h->beta, (long double)h->theta);
-    L.a3x = h->ax[a].a3s; L.a3y = h->ax[a + 1].a3s;
-    for (int c = D - 1; c >= 0; --c) L.ref_off += (long long)(h->shape[c] / 2) * stride[c];
-    min_tiles = std::min(min_tiles, L.ntiles);
-    P.q_bytes = 2 * 8.0 * n * n; P.flops = 2.0 * (double)h->N * 2 * n;
-    P.label = std::string("lines[") + h->ax[a].name + "," + h->ax[a + 1].name + "|" + std::to_string(n) + "x" +
-              std::to_string(n) + "x16 tile]";
-    passes.push_back(P);
-  }
-  if (h->knobs.plan != 2 && min_tiles < 2LL * h->num_cus) return 0;      // too few tiles to fill the chip
-  // index tables of the aggregator's a3 gather (last pass = the slowest pair): a3 index =
-  // out_idx[outer] + x a3s[X] + y a3s[Y] + rest_idx[position behind Y]
-  // (successive approximation ends its applications on either line pair in turn: tables for every line pass)
-  for (size_t pi = 1; pi < passes.size(); ++pi) {
-    FastPass& P = passes[pi];
-    const int a = P.ax0;
-    std::vector<int> outv((size_t)P.ld.nouter, 0), restv((size_t)P.ld.lrest, 0);
-    for (long long o = 0; o < P.ld.nouter; ++o) {
-      long long r = o; int idx = 0;
-      for (int c = a - 1; c >= 0; --c) { idx += (int)(r % h->shape[c]) * h->ax[c].a3s; r /= h->shape[c]; }
-      outv[(size_t)o] = idx;
+  int *od = nullptr, *rd = nullptr;
+  int rc;
+  if ((rc = upload_ints(h, outv, &od)) || (rc = upload_ints(h, restv, &rd))) return rc;
+  L.a3 = h->a3; L.out_idx = od; L.rest_idx = rd;
+  // The aggregator's scale as two small tables (lever iii): for Rouwenhorst / Tauchen grids of the
+  // GCY model z_states = sigma_z[h_z] g[z] + m[h_zpi, z_pi], so a3 = exp((1 - gamma)(mu_c + z_states)) is, for every
+  // outer index o of this pass, a product F1[o][x] * F2[o][position behind Y] (and does not depend on Y).  Checked
+  // entry by entry; where it holds the last pass reads 20 doubles and one 16-byte piece per tile instead of two
+  // gathers and their index arithmetic per unit (stream_kernels.hpp, A3F).  The product differs from the table by
+  // its own rounding (tolerance 64 ulp here; |theta| times less on T w).
+  if (!h->a3_host.empty() && h->ax[a + 1].a3s == 0 && L.lrest % LINE_R == 0) {
+    const long long no_ = L.nouter, lr = L.lrest;
+    const int a3x = h->ax[a].a3s;
+    std::vector<double> f1((size_t)(no_ * n)), f2((size_t)(no_ * lr));
+    bool ok = true;
+    const double tol = 64.0 * 2.220446049250313e-16;
+    for (long long o = 0; o < no_ && ok; ++o) {
+      const double* M = h->a3_host.data() + outv[(size_t)o];
+      const double piv = M[restv[0]];
+      if (!(piv > 0.0) || !std::isfinite(piv)) { ok = false; break; }
+      for (int x = 0; x < n; ++x) f1[(size_t)(o * n + x)] = M[(long long)x * a3x + restv[0]];
+      for (long long q = 0; q < lr; ++q) f2[(size_t)(o * lr + q)] = M[restv[(size_t)q]] / piv;
+      for (int x = 0; x < n && ok; ++x)
+        for (long long q = 0; q < lr; ++q) {
+          const double want = M[(long long)x * a3x + restv[(size_t)q]];
+          const double got = f1[(size_t)(o * n + x)] * f2[(size_t)(o * lr + q)];
+          if (!(std::fabs(got - want) <= tol * std::fabs(want))) { ok = false; break; }
+        }
     }
-    for (long long q = 0; q < P.ld.lrest; ++q) {
-      long long r = q; int idx = 0;
-      for (int c = D - 1; c > a + 1; --c) { idx += (int)(r % h->shape[c]) * h->ax[c].a3s; r /= h->shape[c]; }
-      restv[(size_t)q] = idx;
-    }
-    int *od = nullptr, *rd = nullptr;
-    int rc;
-    if ((rc = upload_ints(h, outv, &od)) || (rc = upload_ints(h, restv, &rd))) return rc;
-    P.ld.a3 = h->a3; P.ld.out_idx = od; P.ld.rest_idx = rd;
-    // The aggregator's scale as two small tables (lever iii): for Rouwenhorst / Tauchen grids of the
-    // GCY model z_states = sigma_z[h_z] g[z] + m[h_zpi, z_pi], so a3 = exp((1 - gamma)(mu_c + z_states)) is, for every
-    // outer index o of this pass, a product F1[o][x] * F2[o][position behind Y] (and does not depend on Y).  Checked
-    // entry by entry; where it holds the last pass reads 20 doubles and one 16-byte piece per tile instead of two
-    // gathers and their index arithmetic per unit (stream_kernels.hpp, A3F).  The product differs from the table by
-    // its own rounding (tolerance 64 ulp here; |theta| times less on T w).
-    if (!h->a3_host.empty() && h->ax[a + 1].a3s == 0 && P.ld.lrest % LINE_R == 0) {
-      const long long no_ = P.ld.nouter, lr = P.ld.lrest;
-      const int n = P.n, a3x = h->ax[a].a3s;
-      std::vector<double> f1((size_t)(no_ * n)), f2((size_t)(no_ * lr));
-      bool ok = true;
-      const double tol = 64.0 * 2.220446049250313e-16;
-      for (long long o = 0; o < no_ && ok; ++o) {
-        const double* M = h->a3_host.data() + outv[(size_t)o];
-        const double piv = M[restv[0]];
-        if (!(piv > 0.0) || !std::isfinite(piv)) { ok = false; break; }
-        for (int x = 0; x < n; ++x) f1[(size_t)(o * n + x)] = M[(long long)x * a3x + restv[0]];
-        for (long long q = 0; q < lr; ++q) f2[(size_t)(o * lr + q)] = M[restv[(size_t)q]] / piv;
-        for (int x = 0; x < n && ok; ++x)
-          for (long long q = 0; q < lr; ++q) {
-            const double want = M[(long long)x * a3x + restv[(size_t)q]];
-            const double got = f1[(size_t)(o * n + x)] * f2[(size_t)(o * lr + q)];
-            if (!(std::fabs(got - want) <= tol * std::fabs(want))) { ok = false; break; }
-          }
-      }
-      if (ok) {
-        double *d1 = nullptr, *d2 = nullptr;
-        if ((rc = upload(h, &d1, f1.data(), f1.size())) || (rc = upload(h, &d2, f2.data(), f2.size()))) return rc;
-        P.ld.f1 = d1; P.ld.f2 = d2;
-      }
+    if (ok) {
+      double *d1 = nullptr, *d2 = nullptr;
+      if ((rc = upload(h, &d1, f1.data(), f1.size())) || (rc = upload(h, &d2, f2.data(), f2.size()))) return rc;
+      L.f1 = d1; L.f2 = d2;
     }
   }
-  // dynamic LDS above 64 KB has to be allowed per kernel variant
+  return 0;
+}
+
+// dynamic LDS above 64 KB has to be allowed per kernel variant; which line passes run stream_kernels.hpp's forms
+int prepare_fast_passes(sdfs_handle* h, std::vector<FastPass>& passes) {
   for (const FastPass& P : passes) {
     if (!P.line) for (int m = 0; m < S_NMODES; ++m) {
       slice_fn f = slice_variant(P.n, m);
-      if (!f) return 0;
+      if (!f) return 1;
       hipFuncSetAttribute((const void*)f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)slice_lds_bytes(P.n, m));
       slice_fn f32 = slice_variant(P.n, m, true);
       if (f32) hipFuncSetAttribute((const void*)f32, hipFuncAttributeMaxDynamicSharedMemorySize, (int)slice_lds_bytes(P.n, m));
       if (slice_fn m32 = slice32_variant(P.n)) hipFuncSetAttribute((const void*)m32, hipFuncAttributeMaxDynamicSharedMemorySize, (int)slice32_lds_bytes(P.n));
     } else for (int m = 0; m < L_NMODES; ++m) for (int pe = 0; pe < 2; ++pe) {
       line_fn f = line_variant(P.n, m, pe != 0, P.ld.lrest % LINE_R == 0);
-      if (!f && m == L_TFUSED && pe != 0) continue;          // one tile per workgroup only
-      if (!f) return 0;
+      if (!f && pe != 0) continue;                           // (the persistent form exists in diagnostic builds only)
+      if (!f) return 1;
       hipFuncSetAttribute((const void*)f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)line_lds_bytes(P.n));
       line_fn f32 = line_variant(P.n, m, false, true, true);
       if (f32) hipFuncSetAttribute((const void*)f32, hipFuncAttributeMaxDynamicSharedMemorySize, (int)line_lds_bytes(P.n));
@@ -884,11 +873,6 @@ int build_fast_plan(sdfs_handle* h) {
         if (line_fn m32 = line32_variant(P.n, m, r32)) hipFuncSetAttribute((const void*)m32, hipFuncAttributeMaxDynamicSharedMemorySize, (int)line32_lds_bytes(P.n, r32));
     }
   }
-  bool f32_ok = true;
-  for (const FastPass& P : passes) if (P.line && P.ld.lrest % LINE_R != 0) f32_ok = false;
-  h->fast.f32_ok = f32_ok;
-  for (size_t i = 0; i < passes.size(); ++i)
-    if (passes[i].line) passes[i].persist = (h->knobs.line_persist >> (i + 1 == passes.size() ? 1 : 0)) & 1;
   if (!h->sched) {
     HIPCHK(h, hipMalloc((void**)&h->sched, sizeof(unsigned) * SCHED_WORDS * 4));
     h->misc_allocs.push_back(h->sched);
@@ -903,12 +887,98 @@ int build_fast_plan(sdfs_handle* h) {
     if (!P.stream) continue;
     for (int m : {(int)L_MID, (int)L_TLAST, (int)L_TLAST_LIN}) for (int a3f = 0; a3f < 2; ++a3f) {
       line_fn f = line_stream_variant(P.n, m, a3f != 0);
-      if (!f) return 0;
+      if (!f) return 1;
       hipFuncSetAttribute((const void*)f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)line_lds_bytes(P.n));
     }
   }
+  return 0;
+}
+
+// every axis with one unconditional transition matrix, extents in pairs the compile-time kernels exist for
+bool pair_plan_legal(const sdfs_handle* h) {
+  const int D = h->ndim;
+  if (h->cont || h->dense || (D != 4 && D != 6) || h->a3 == nullptr) return false;
+  if (h->N >= (1LL << 29)) return false;                   // 32-bit byte offsets inside a tile
+  for (int a = 0; a < D; ++a) {
+    if (h->ax[a].qcount != 1) return false;
+    for (int c = 0; c < D; ++c) if (h->ax[a].qs[c] != 0) return false;
+    if (h->ax[a].a3s < 0 || h->ax[a].a3s >= (1 << 24)) return false;
+  }
+  for (int a = 0; a < D; a += 2) {
+    const int n = h->shape[a];
+    if (n != h->shape[a + 1] || !(n == 16 || n == 20 || n == 24 || n == 32)) return false;
+  }
+  return true;
+}
+
+int build_fast_plan(sdfs_handle* h) {
+  h->fast.ok = false;
+  h->fast.small = false;
+  h->fast.pad = false;
+  h->fast.passes.clear();
+  const int D = h->ndim;
+  if (h->knobs.plan == 1 || h->sharded || !pair_plan_legal(h)) return 0;
+  const int zero[MAXD] = {0, 0, 0, 0, 0, 0};
+  std::vector<FastPass> passes(1);
+  make_slice_pass(h, h->shape, passes[0]);
+  long long min_tiles = 1LL << 60;
+  std::vector<int> line_axes;
+  for (int a = D - 4; a >= 0; a -= 2) line_axes.push_back(a);
+  if (h->knobs.pair_order == 1) std::reverse(line_axes.begin(), line_axes.end());
+  // (successive approximation ends its applications on either line pair in turn: a3 tables for every line pass)
+  for (int a : line_axes) {
+    FastPass P;
+    const int rc = make_line_pass(h, h->shape, zero, a, true, P);
+    if (rc == 1) return 0;
+    if (rc) return rc;
+    min_tiles = std::min(min_tiles, P.ld.ntiles);
+    passes.push_back(P);
+  }
+  if (h->knobs.plan != 2 && min_tiles < 2LL * h->num_cus) return 0;      // too few tiles to fill the chip
+  {
+    const int rc = prepare_fast_passes(h, passes);
+    if (rc == 1) return 0;
+    if (rc) return rc;
+  }
+  bool f32_ok = true;
+  for (const FastPass& P : passes) if (P.line && P.ld.lrest % LINE_R != 0) f32_ok = false;
+  h->fast.f32_ok = f32_ok;
+  for (size_t i = 0; i < passes.size(); ++i)
+    if (passes[i].line) passes[i].persist = (h->knobs.line_persist >> (i + 1 == passes.size() ? 1 : 0)) & 1;
   h->fast.passes = passes;
   h->fast.ok = true;
+  return 0;
+}
+
+// Sharded stages on the pair plan's kernels (6-D grids whose shard axes lie in the two line pairs, one in each): with
+// Kronecker-factorised expectations the order of the contractions is free, so
+//   stage 0 (axis A blocked)  = the slice pass over the two fastest axes + the middle line pass over B's pair,
+//   stage 1 (axis B blocked)  = the last line pass, with the aggregator, over A's pair --
+// the same three kernels as on one GPU, on a block of the grid each, instead of the generic 80 KB tiles (1200 tiles
+// over 512 slots at GCY 20^6 over eight ranks: tools/stage_kernel_times.py).  fp64 streams; fp32 Krylov storage keeps
+// the generic stage plans.
+int build_stage_fast_plans(sdfs_handle* h, int a_lo, int a_len, int b_lo, int b_len) {
+  h->sfast[0].ok = h->sfast[1].ok = false;
+  const int D = h->ndim;
+  if (h->knobs.plan == 1 || !h->sharded || D != 6 || !pair_plan_legal(h)) return 0;
+  const int pa = h->axis_a & ~1, pb = h->axis_b & ~1;
+  if (pa == pb || pa == D - 2 || pb == D - 2) return 0;
+  int shp[MAXD], off[MAXD] = {0, 0, 0, 0, 0, 0};
+  for (int a = 0; a < D; ++a) shp[a] = h->shape[a];
+  std::vector<FastPass> s0(2), s1(1);
+  shp[h->axis_a] = a_len; off[h->axis_a] = a_lo;
+  make_slice_pass(h, shp, s0[0]);
+  int rc = make_line_pass(h, shp, off, pb, false, s0[1]);
+  shp[h->axis_a] = h->shape[h->axis_a]; off[h->axis_a] = 0;
+  if (rc == 1) return 0;
+  if (rc) return rc;
+  shp[h->axis_b] = b_len; off[h->axis_b] = b_lo;
+  rc = make_line_pass(h, shp, off, pa, true, s1[0]);
+  if (rc == 1) return 0;
+  if (rc) return rc;
+  if ((rc = prepare_fast_passes(h, s0)) || (rc = prepare_fast_passes(h, s1))) return rc == 1 ? 0 : rc;
+  h->sfast[0].passes = s0; h->sfast[1].passes = s1;
+  h->sfast[0].ok = h->sfast[1].ok = true;
   return 0;
 }
 
@@ -1113,28 +1183,30 @@ int round_stream_bf16_n(sdfs_handle* h, void* p, long long n, const unsigned lon
 }
 int round_stream_bf16(sdfs_handle* h, void* p, const unsigned long long* gate) { return round_stream_bf16_n(h, p, (long long)h->N, gate); }
 
-int run_fast_plan(sdfs_handle* h, int mode, const double* in, double* out, const double* old,
-                  unsigned long long* resid, const unsigned long long* gate, double gate_tol, int minus_identity,
+// fp = the whole-grid pair plan (has_first and has_last), or one stage of a sharded handle (build_stage_fast_plans:
+// stage 0 holds the first pass, stage 1 the last); nloc = grid points of the block
+int run_fast_plan(sdfs_handle* h, FastPlan& fp, long long nloc, bool has_first, bool has_last, int mode, const double* in, double* out,
+                  const double* old, unsigned long long* resid, const unsigned long long* gate, double gate_tol, int minus_identity,
                   double* dotp) {
   const bool vjp = mode == MODE_VJP;       // the J.v launches with transposed matrices and c1 / c2 swapped (fp64)
   if (vjp) mode = MODE_JVP;
   int rc = ensure_tmp(h);
   if (rc) return rc;
   if (mode != MODE_T) { rc = ensure_lin(h); if (rc) return rc; }
-  const int np = (int)h->fast.passes.size();
-  const double n8 = 8.0 * (double)h->N;
+  const int np = (int)fp.passes.size();
+  const double n8 = 8.0 * (double)nloc;
   // fp32 Krylov storage: every stream of a J.v application holds floats; a linearising T keeps fp64 streams
   // and writes only c1 (first pass) and c2 (last pass) as scaled floats
   const bool f32 = !vjp && h->krylov_f32 && mode != MODE_T;
   // opts.t_f32: the intermediates between the passes of a plain T application as scaled floats (whole chunks everywhere)
-  const bool t32 = mode == MODE_T && h->t32_active && h->fast.f32_ok && !h->fast.small;
+  const bool t32 = mode == MODE_T && h->t32_active && fp.f32_ok && !fp.small && has_first && has_last;
   const char* tag = t32 ? "T32" : vjp ? "vjp" : (mode == MODE_JVP) ? (f32 ? "jvp32" : "jvp") : (mode == MODE_T_LIN ? "Tlin" : "T");
   for (int i = 0; i < np; ++i) {
-    FastPass& P = h->fast.passes[i];
-    const bool last = i == np - 1;
+    FastPass& P = fp.passes[i];
+    const bool last = has_last && i == np - 1;
     double bytes = 2 * n8 + P.q_bytes;
     const double* pin = (i == 0) ? in : h->tmp;
-    double* pout = last ? out : h->tmp;
+    double* pout = (i == np - 1) ? out : h->tmp;
     if (P.pad) {
       PadDesc d = P.pd;
       d.minus_identity = minus_identity;
@@ -1206,6 +1278,23 @@ int run_fast_plan(sdfs_handle* h, int mode, const double* in, double* out, const
       else if (mode == MODE_JVP) { sm = S_JFIRST; io.aux_in = vjp ? h->c2 : h->c1; bytes += n8; }
       SliceDesc sd = P.sd;
       if (vjp) { sd.Qf = h->ax[P.ax1].Qt; sd.Qe = h->ax[P.ax0].Qt; }
+      if (mode == MODE_JVP && !vjp && !f32 && h->jf.active && h->jf.kind >= 0) {
+        // BiCGSTAB's p / s update on the registers of this pass (krylov_kernels.hpp)
+        jfused_fn jfn = slice_jfused_variant(P.n, h->jf.kind);
+        if (!jfn) return fail(h, SDFS_ERR_UNSUPPORTED, "no fused first pass for this extent");
+        JFusedIO jio;
+        memset(&jio, 0, sizeof jio);
+        jio.upd = h->jf.upd; jio.a = h->jf.a; jio.q = h->jf.q; jio.c1 = h->c1; jio.out = pout; jio.sc = h->sc; jio.dot = h->jf.dot; jio.gate = gate;
+        bytes = (h->jf.kind == JF_P ? 6.0 : 5.0) * n8 + P.q_bytes;
+        int cid = -1;
+        if (h->profiling) { char nm[48]; snprintf(nm, sizeof nm, "jvp+%s:%s", h->jf.kind == JF_P ? "p" : "s", P.label.c_str()); cid = counter_id(h, nm, bytes, P.flops); }
+        const int gsl = slice_tile_slices(P.n, S_JFIRST);
+        const long long ntile = (P.sd.nslices + gsl - 1) / gsl;
+        ProfScope ps(h, cid);
+        hipLaunchKernelGGL(jfn, dim3((unsigned)((ntile + 3) / 4)), dim3(256), slice_lds_bytes(P.n, S_JFIRST), h->stream, P.sd, jio);
+        HIPCHK(h, hipGetLastError());
+        continue;
+      }
       // opts.krylov_f32 = 3: fp32 LDS tile + fp32 MFMA for the J.v passes (f32_kernels.hpp)
       const bool m32 = f32 && h->krylov_mfma32 && mode == MODE_JVP;
       slice_fn fn = m32 ? slice32_variant(P.n) : slice_variant(P.n, sm, f32);
@@ -1244,6 +1333,13 @@ int run_fast_plan(sdfs_handle* h, int mode, const double* in, double* out, const
         // stream_kernels.hpp: persistent middle pass with the next tile in flight; last pass with its side stream loaded early
         fn = line_stream_variant(P.n, lm, d.f1 != nullptr);
         grid = lm == L_MID ? stream_mid_grid(h, P) : (unsigned)d.ntiles;
+      }
+      if (lm == L_JLAST && !lf32 && !vjp && h->jf.active) {
+        // fused BiCGSTAB iteration: the streamed last pass, one workgroup per tile (the partial sums are counted per tile)
+        fn = line_stream_variant(P.n, L_JLAST);
+        grid = (unsigned)d.ntiles;
+        io.dot_with = h->jf.dot_with;
+        bytes += 0.5 * n8;       // (rhat is read by the first of an iteration's two applications: one counter, their mean)
       }
       const bool m32 = lf32 && h->krylov_mfma32 && mode == MODE_JVP && !t32;
       const int r32 = line32_row_floats(P.n, P.ld.lrest);
@@ -1295,7 +1391,11 @@ int run_plan(sdfs_handle* h, Plan& plan, int mode, bool has_first, bool has_last
   // the pair plan serves the whole-grid operator; its fp32-storage forms need whole 16-element chunks in
   // every line pass, otherwise fp32 Krylov storage (and its linearisation) stays on the generic kernels
   if (h->fast.ok && &plan == &h->plan[0] && has_first && has_last && !(h->krylov_f32 && mode != MODE_T && !h->fast.f32_ok))
-    return run_fast_plan(h, mode, in, out, old, resid, gate, gate_tol, minus_identity, dotp);
+    return run_fast_plan(h, h->fast, h->N, true, true, mode, in, out, old, resid, gate, gate_tol, minus_identity, dotp);
+  // sharded stages on the pair plan's kernels (fp64 streams)
+  if (h->sharded && (&plan == &h->plan[0] || &plan == &h->plan[1]) && h->sfast[&plan - h->plan].ok && mode != MODE_VJP &&
+      !(h->krylov_f32 && mode != MODE_T) && has_first == (&plan == &h->plan[0]) && has_last == (&plan == &h->plan[1]))
+    return run_fast_plan(h, h->sfast[&plan - h->plan], plan.nloc, has_first, has_last, mode, in, out, old, resid, gate, gate_tol, minus_identity, dotp);
   const bool vjp = mode == MODE_VJP;       // the J.v launches with transposed matrices and c1 / c2 swapped
   if (vjp) mode = MODE_JVP;
   int rc = ensure_tmp(h);
@@ -1493,7 +1593,10 @@ int solve_sa(sdfs_handle* h, const sdfs_opts& o, double* w, int64_t* n_iter, int
     // A lingered: 551 against 499 iterations at SSY 32x32x16x16), so the switch is at 64.  (The iterate path differs
     // from the all-fp64 one at that level, so the iteration COUNT is this configuration's own, not the reference's.)
     double wref = 0.0;
-    HIPCHK(h, hipMemcpy(&wref, w + h->fast.passes[0].sd.ref_off, 8, hipMemcpyDeviceToHost));
+    // (on the handle's stream: sdfs_solve's upload, or the caller's writes under sdfs_set_stream, precede it there; the
+    // handle's own stream does not synchronise with the null stream)
+    HIPCHK(h, hipMemcpyAsync(&wref, w + h->fast.passes[0].sd.ref_off, 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
     const double switch_tol = 64.0 * std::ldexp(1.0, -24) * std::fabs(wref) / std::max(std::fabs(h->theta), 1.0);
     if (std::isfinite(switch_tol) && switch_tol > o.tol) {
       sdfs_opts oa = o;
@@ -1709,7 +1812,54 @@ int bicgstab_dev_t(sdfs_handle* h, const sdfs_opts& o, int64_t* matvecs) {
       hipLaunchKernelGGL(k_bicg_iter_finish, dim3(1), dim3(VEC_BLOCK), 0, st, h->partial, g, h->sc, gate); }
     return 0;
   };
-  auto iteration = [&]() -> int { return merged ? iteration_merged() : iteration_plain(); };
+  // Large grids on the compile-time pair plan, fp64 Krylov storage: the p and s updates on the registers of J.v's first
+  // pass, <rhat, q> in its last (krylov_kernels.hpp) -- 31 grid streams per iteration instead of 34
+  const FastPass* const P0 = (h->fast.ok && !h->fast.passes.empty()) ? &h->fast.passes.front() : nullptr;
+  const FastPass* const PL = (h->fast.ok && !h->fast.passes.empty()) ? &h->fast.passes.back() : nullptr;
+  bool jfuse = std::is_same<T, double>::value && !merged && h->fast.ok && !h->fast.small && !h->fast.pad && !h->krylov_f32 &&
+               h->fast.passes.size() >= 2 && !P0->line && !P0->pad && PL->line && PL->ld.lrest % LINE_R == 0 &&
+               3 * PL->ld.ntiles <= (long long)MAX_PARTIAL_BLOCKS * AND_MAX_M && h->knobs.no_dot_fusion == 0;
+  long long jf_tiles0 = 0;
+  if (jfuse) {
+    const int gsl = slice_tile_slices(P0->n, S_JFIRST);
+    jf_tiles0 = (P0->sd.nslices + gsl - 1) / gsl;
+    if (h->jf_ss_n < jf_tiles0) {
+      double* d = nullptr;
+      if (hipMalloc((void**)&d, sizeof(double) * (size_t)jf_tiles0) != hipSuccess) jfuse = false;
+      else { h->misc_allocs.push_back(d); h->jf_ss = d; h->jf_ss_n = jf_tiles0; }
+    }
+    if (jfuse) {
+      hipFuncSetAttribute((const void*)slice_jfused_variant(P0->n, JF_P), hipFuncAttributeMaxDynamicSharedMemorySize, (int)slice_lds_bytes(P0->n, S_JFIRST));
+      hipFuncSetAttribute((const void*)slice_jfused_variant(P0->n, JF_S), hipFuncAttributeMaxDynamicSharedMemorySize, (int)slice_lds_bytes(P0->n, S_JFIRST));
+      hipFuncSetAttribute((const void*)line_stream_variant(PL->n, L_JLAST), hipFuncAttributeMaxDynamicSharedMemorySize, (int)line_lds_bytes(PL->n));
+    }
+  }
+  struct JfGuard { sdfs_handle* h; ~JfGuard() { h->jf.active = false; h->jf.kind = -1; h->jf.dot_with = nullptr; } } jf_guard{h};
+  auto iteration_jfused = [&]() -> int {
+    int rc2;
+    const int nt = (int)PL->ld.ntiles;
+    double* const dp = h->partial;                       // [0, nt): <out, v>, [nt, 2 nt): <out, out>, [2 nt, 3 nt): <out, rhat>
+    h->jf.active = true;
+    // q = (J - I) p, p = r + beta (p - omega q) formed in the first pass, <rhat, q> summed by the last
+    h->jf.kind = JF_P; h->jf.upd = (double*)p; h->jf.a = (const double*)r; h->jf.q = (const double*)q; h->jf.dot = nullptr; h->jf.dot_with = (const double*)rhat;
+    rc2 = run_plan(h, h->plan[0], MODE_JVP, true, true, (const double*)p, (double*)q, (const double*)p, nullptr, gate, 0.0, 1, dp);
+    h->jf.dot_with = nullptr;
+    if (rc2) return rc2;
+    { ProfScope ps(h, cvec);
+      hipLaunchKernelGGL(k_bicg_alpha_finish, dim3(1), dim3(VEC_BLOCK), 0, st, (const double*)(dp + 2 * (size_t)nt), nt, h->sc, (const unsigned long long*)gate); }
+    // t = (J - I) s, s = r - alpha q (in r) and <s, s> formed in the first pass, <t, s> and <t, t> summed by the last
+    h->jf.kind = JF_S; h->jf.upd = (double*)r; h->jf.a = nullptr; h->jf.q = (const double*)q; h->jf.dot = h->jf_ss;
+    rc2 = run_plan(h, h->plan[0], MODE_JVP, true, true, (const double*)r, (double*)t, (const double*)r, nullptr, gate, 0.0, 1, dp);
+    h->jf.kind = -1; h->jf.active = false;
+    if (rc2) return rc2;
+    { ProfScope ps(h, cvec);
+      hipLaunchKernelGGL(k_bicg_s_finish_wide, dim3(1), dim3(1024), 0, st, (const double*)h->jf_ss, (int)jf_tiles0, h->sc, (const unsigned long long*)gate);
+      hipLaunchKernelGGL(k_bicg_omega_finish, dim3(1), dim3(VEC_BLOCK), 0, st, (const double*)dp, nt, h->sc, (const unsigned long long*)gate);
+      hipLaunchKernelGGL(k_bicg_update_xr<T>, dim3(g), dim3(VEC_BLOCK), 0, st, x, r, (const T*)p, (const T*)t, (const T*)rhat, n, h->sc, h->partial, (const unsigned long long*)gate);
+      hipLaunchKernelGGL(k_bicg_iter_finish, dim3(1), dim3(VEC_BLOCK), 0, st, h->partial, g, h->sc, gate); }
+    return 0;
+  };
+  auto iteration = [&]() -> int { return jfuse ? iteration_jfused() : (merged ? iteration_merged() : iteration_plain()); };
   // Small grids are launch- and sync-bound: the iteration is captured once into a hipGraph (pointers, scalars
   // and the gate are fixed device addresses) and replayed; `chunk` iterations go out per host synchronisation.
   // Large grids (an iteration is milliseconds) keep one iteration per sync so that nothing runs past the
@@ -2000,7 +2150,7 @@ int solve_anderson(sdfs_handle* h, const sdfs_opts& o, double* w, int64_t* n_ite
     const long long unit = lcm(lcm(m, 2), o.mixing_freq);
     // (a chunk of this form ends with a launch of its own and the passes do not depend on the chunking: the default
     // polling interval is stretched, an explicit one is honoured)
-    if (o.check_every == 32) chunk = 120;
+    if (h->check_every_default) chunk = 120;
     if (unit > 4096) fusedp = false;
     else chunk = (int)(((chunk + unit - 1) / unit) * unit);      // (a chunk ends with one launch of its own: the longer the better)
   }
@@ -2431,6 +2581,8 @@ int create_common(int model, int ndim, const int64_t* shapes, const double* para
     rc = build_plan(h, h->plan[1], std::vector<int>{axis_a}, done);
     h->ax[axis_b].nloc = h->ax[axis_b].n; h->ax[axis_b].off = 0;
     if (rc) return bail(rc);
+    rc = build_stage_fast_plans(h, (int)a_lo, (int)a_len, (int)b_lo, (int)b_len);
+    if (rc) return bail(rc);
   }
   *out = h;
   return 0;
@@ -2766,7 +2918,7 @@ int sdfs_default_opts(sdfs_opts* o) {
   o->inner_atol = 1e-4;        // code/solvers.py:55
   o->inner_max_iter = 0;
   o->history = 10; o->mixing_freq = 4; o->beta = 8.0; o->ridge = 1e-6;   // code/solvers.py:104-114
-  o->check_every = 32;
+  o->check_every = 0;            // the library's choice (sdfs_solve_dev)
   o->use_graph = 1;
   o->record_errors = 0;
   o->krylov_f32 = 0;
@@ -2887,7 +3039,10 @@ int sdfs_solve_dev(sdfs_handle* h, int algo, const sdfs_opts* opts, double* w, i
   if (h->sharded) return fail(h, SDFS_ERR_ARG, "sharded handle: the multi-GPU loop lives in the host layer");
   sdfs_opts o;
   if (opts) o = *opts; else sdfs_default_opts(&o);
-  if (o.check_every < 1) o.check_every = 1;
+  // check_every <= 0: the library's choice (32; the fused small-grid Anderson loop stretches it to 120) -- an explicit
+  // value, 32 included, is honoured
+  h->check_every_default = o.check_every < 1;
+  if (o.check_every < 1) o.check_every = 32;
   if (o.max_iter < 0) return fail(h, SDFS_ERR_ARG, "max_iter < 0");
   switch (algo) {
     case SDFS_ALGO_SA: return solve_sa(h, o, w, n_iter, n_apply, final_err);
@@ -3263,6 +3418,21 @@ int sdfs_describe_plan(const sdfs_handle* h, char* buf, int64_t cap) {
     if (h->fast.small && anderson_fused_ok(h, 10))
       s += "small-grid plan, Anderson: passes in reverse order, push on the last pass, control step + update of x on the first\n";
     s += "generic plan (fp32 Krylov storage, sharded stages):\n";
+  }
+  if (h->sharded && h->sfast[0].ok) {
+    for (int st = 0; st < 2; ++st)
+      for (size_t i = 0; i < h->sfast[st].passes.size(); ++i) {
+        const FastPass& P = h->sfast[st].passes[i];
+        if (!P.line) {
+          const long long nt = (P.sd.nslices + slice_tile_slices(P.n, S_TFIRST) - 1) / slice_tile_slices(P.n, S_TFIRST);
+          snprintf(line, sizeof line, "stage %d pair-plan pass %zu: %s wave-tiles %lld\n", st, i, P.label.c_str(), nt);
+        } else {
+          snprintf(line, sizeof line, "stage %d pair-plan pass %zu: %s tiles %lld (outer %lld x %d chunks of 128 B)%s\n", st, i, P.label.c_str(),
+                   P.ld.ntiles, P.ld.nouter, P.ld.nchunks, P.stream ? " streamed" : "");
+        }
+        s += line;
+      }
+    s += "generic stage plans (fp32 Krylov storage):\n";
   }
   for (int st = 0; st < 2; ++st) {
     const Plan& pl = h->plan[st];

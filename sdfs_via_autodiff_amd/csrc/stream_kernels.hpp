@@ -279,8 +279,9 @@ line_stream_kernel(const LineDesc P, const LineIO io) {
   PowK<false> PT;
   if (CES) PT.init(P.inv_theta, lane);
   SDFS_STREAM_STAMP_DECL;
-  double rmax = 0.0, dot_yv = 0.0, dot_yy = 0.0;
+  double rmax = 0.0, dot_yv = 0.0, dot_yy = 0.0, dot_yr = 0.0;
   bool rnan = false;
+  const bool dot3 = MULE && io.dot_with != nullptr;             // uniform
 
   v2d v[EPT];
   v2d wv[OLDPF ? EPT : 1];
@@ -350,12 +351,14 @@ line_stream_kernel(const LineDesc P, const LineIO io) {
           ia3a = (unsigned)(P.out_idx[o] + P.rest_idx[pos]);
           ia3b = (unsigned)(P.out_idx[o] + P.rest_idx[pos + 1]);
         }
-        double2 sw[LOOK], cw[LOOK];
-        auto issue = [&](const int k, double2& s1, double2& s2) {
+        const char* const dwb = reinterpret_cast<const char*>(io.dot_with + tbase);
+        double2 sw[LOOK], cw[LOOK], rw[LOOK];
+        auto issue = [&](const int k, double2& s1, double2& s2, double2& s3) {
           const int u = tid + k * B;
           const bool rowok = k < EPT && (!PARTIAL || u < Geo::UNITS);
           const unsigned offc = rowok ? b0 + (unsigned)k * bstep : b0;
           if (!OLDPF && need_old) s1 = ldg_stream2(oldb + offc);
+          if (MULE && dot3) s3 = ldg_stream2(dwb + offc);
           if (CES && A3F) {
             const int row = rowok ? (u >> 3) : 0;
             const double fx = sF1[32 * par + row / N];
@@ -370,7 +373,7 @@ line_stream_kernel(const LineDesc P, const LineIO io) {
             s2 = *reinterpret_cast<const double2*>(auxb + offc);
           }
         };
-        auto unit = [&](const int k, const double2 s1, const double2 s2) {
+        auto unit = [&](const int k, const double2 s1, const double2 s2, const double2 s3) {
           const int u = tid + k * B;
           const bool rowok = !PARTIAL || u < Geo::UNITS;
           const unsigned off = b0 + (unsigned)k * bstep;
@@ -396,17 +399,18 @@ line_stream_kernel(const LineDesc P, const LineIO io) {
               dot_yv = fma(y2.x, s1.x, dot_yv); dot_yv = fma(y2.y, s1.y, dot_yv);
               dot_yy = fma(y2.x, y2.x, dot_yy); dot_yy = fma(y2.y, y2.y, dot_yy);
             }
+            if (dot3) { dot_yr = fma(y2.x, s3.x, dot_yr); dot_yr = fma(y2.y, s3.y, dot_yr); }
             *reinterpret_cast<double2*>(outb + off) = y2;
           }
         };
 #pragma unroll
-        for (int j = 0; j < LOOK; ++j) issue(j, sw[j], cw[j]);
+        for (int j = 0; j < LOOK; ++j) issue(j, sw[j], cw[j], rw[j]);
         if (OLDPF) {
 #pragma unroll
           for (int k = 0; k < EPT; ++k) {
             const v2d wk = wv[OLDPF ? k : 0];
-            unit(k, make_double2(wk.x, wk.y), cw[k % LOOK]);
-            if (k + LOOK < EPT) issue(k + LOOK, sw[k % LOOK], cw[k % LOOK]);
+            unit(k, make_double2(wk.x, wk.y), cw[k % LOOK], rw[k % LOOK]);
+            if (k + LOOK < EPT) issue(k + LOOK, sw[k % LOOK], cw[k % LOOK], rw[k % LOOK]);
             __builtin_amdgcn_sched_barrier(0);
           }
         } else {
@@ -415,13 +419,13 @@ line_stream_kernel(const LineDesc P, const LineIO io) {
           for (; kk + LOOK <= EPT; kk += LOOK) {
 #pragma unroll
             for (int j = 0; j < LOOK; ++j) {
-              unit(kk + j, sw[j], cw[j]);
-              issue(kk + j + LOOK, sw[j], cw[j]);
+              unit(kk + j, sw[j], cw[j], rw[j]);
+              issue(kk + j + LOOK, sw[j], cw[j], rw[j]);
               __builtin_amdgcn_sched_barrier(0);
             }
           }
 #pragma unroll
-          for (int j = 0; j < EPT % LOOK; ++j) unit(EPT - EPT % LOOK + j, sw[j], cw[j]);
+          for (int j = 0; j < EPT % LOOK; ++j) unit(EPT - EPT % LOOK + j, sw[j], cw[j], rw[j]);
         }
       }
       SDFS_STREAM_STAMP(7);
@@ -434,15 +438,17 @@ line_stream_kernel(const LineDesc P, const LineIO io) {
   }
   if (PERSIST && tid == 0) ticket_walk_done(io.sched, gridDim.x);
   if (MULE && io.dotp != nullptr) {
+    __shared__ double red3[8];
 #pragma unroll
-    for (int s = 32; s > 0; s >>= 1) { dot_yv += __shfl_xor(dot_yv, s); dot_yy += __shfl_xor(dot_yy, s); }
-    if (lane == 0) { red[wave] = dot_yv; red[8 + wave] = dot_yy; }
+    for (int s = 32; s > 0; s >>= 1) { dot_yv += __shfl_xor(dot_yv, s); dot_yy += __shfl_xor(dot_yy, s); dot_yr += __shfl_xor(dot_yr, s); }
+    if (lane == 0) { red[wave] = dot_yv; red[8 + wave] = dot_yy; red3[wave] = dot_yr; }
     __syncthreads();
     if (tid == 0) {
-      double a = 0.0, b = 0.0;
-      for (int w = 0; w < NW; ++w) { a += red[w]; b += red[8 + w]; }
+      double a = 0.0, b = 0.0, c = 0.0;
+      for (int w = 0; w < NW; ++w) { a += red[w]; b += red[8 + w]; c += red3[w]; }
       io.dotp[blockIdx.x] = a;
       io.dotp[gridDim.x + blockIdx.x] = b;
+      if (dot3) io.dotp[2 * gridDim.x + blockIdx.x] = c;
     }
   }
   if (CES && io.resid != nullptr) {
@@ -606,6 +612,7 @@ template <int N> inline line_fn line_stream_variant_a3f_n(int mode) {
 template <int N> inline line_fn line_stream_variant_n(int mode) {
   using G = StreamGeo<N>;
   switch (mode) {
+    case L_JLAST: return (line_fn)line_stream_kernel<N, L_JLAST, LineGeo<N>::BPC, false, G::B, false>;      // (krylov_kernels.hpp: with <out, dot_with>)
     case L_MID: return (line_fn)line_stream_kernel<N, L_MID, G::WPC_MID, false, G::B, true>;
     case L_TLAST: return (line_fn)line_stream_kernel<N, L_TLAST, G::WPC_LAST, true, G::B, false>;
     case L_TLAST_LIN: return (line_fn)line_stream_kernel<N, L_TLAST_LIN, G::WPC_LAST, true, G::B, false>;

@@ -295,6 +295,24 @@ k_bicg_s_finish(const double* __restrict__ partial, int nb, double* __restrict__
   if (threadIdx.x == 0) { sc[SC_SS] = ss; sc[SC_EARLY] = (ss < sc[SC_ATOL2]) ? 1.0 : 0.0; }
 }
 
+// the same from MANY partial sums (one per wave tile of the fused first pass, krylov_kernels.hpp: 40 000 at GCY 20^6):
+// 1024 threads, strided sums, wave shuffle + LDS
+__global__ void __launch_bounds__(1024)
+k_bicg_s_finish_wide(const double* __restrict__ partial, int nb, double* __restrict__ sc, const unsigned long long* gate = nullptr) {
+  SDFS_GATED(gate);
+  __shared__ double sm[16];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < nb; i += 1024) s += partial[i];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double ss = 0.0;
+    for (int w = 0; w < 16; ++w) ss += sm[w];
+    sc[SC_SS] = ss; sc[SC_EARLY] = (ss < sc[SC_ATOL2]) ? 1.0 : 0.0;
+  }
+}
+
 // partial sums of <t,s> and <t,t>
 template <typename T>
 __global__ void __launch_bounds__(VEC_BLOCK)

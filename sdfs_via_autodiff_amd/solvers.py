@@ -228,7 +228,12 @@ class GDState(dict):
     """State returned by "gd": ``state.iter_num`` / ``state.error`` / ``state.stepsize`` / ``state.t`` as jaxopt's
     ProxGradState names them (attribute access, as the reference's callers would use it), also a dict (``state["errors"]``
     holds the error after every iteration)."""
-    __getattr__ = dict.__getitem__
+    def __getattr__(self, name):
+        # (AttributeError, not KeyError: hasattr, copy and pickle probe optional attributes and only catch the former)
+        try:
+            return self[name]
+        except KeyError:
+            raise AttributeError(name) from None
 
 
 def _gd_loop(value_and_grad, value, axpy, dot, x, maxiter, tol, maxls, decrease_factor):

@@ -114,7 +114,8 @@ def main():
     rank = dist.get_rank()
     out = {}
     try:
-        out = body(rank, model, shapes, use_hip, plain)
+        big = len(sys.argv) > 4 and sys.argv[4] == "big"
+        out = body_big(rank, model, shapes) if big else body(rank, model, shapes, use_hip, plain)
     except Exception as e:
         import traceback
         out = {"error": f"rank {rank}: {e}\n{traceback.format_exc()}"}
@@ -236,6 +237,64 @@ def body(rank, model, shapes, use_hip, plain=False):
         out["anderson_resid"] = float(np.max(np.abs(T(op.gather_full(xa2).cpu().numpy()) - op.gather_full(xa2).cpu().numpy())))
         out["anderson_rejected"] = st.get("rejected_mixes", -1)
         return out
+
+
+def body_big(rank, model, shapes):
+    """Grids of the compile-time pair plan (GCY, extents 16 / 20 / 24 / 32 in pairs): the stages run the pair plan's
+    kernels on their blocks (sdfs_api.hip, build_stage_fast_plans).  Single applications against the C oracle on the
+    full grid; the sharded loops against the single-GPU library on the same start (the oracle's loops would take
+    minutes at this size)."""
+    import sdfs_via_autodiff_amd as S
+    from sdfs_via_autodiff_amd import distributed as D
+    from oracle.c_oracle import COperator
+    assert model == "gcy"
+    torch.cuda.set_device(0)
+    m = S.GCY()
+    arr = S.discretize_gcy(m, shapes)
+    op = D.ShardedKoopmans(model, shapes, m.params, arr)
+    out = {"plan": op.backend.describe_plan(), "mirror_ok": bool(op.mirror_ok), "sizes": (op.a_sizes, op.b_sizes)}
+    if op.backend_m is not None:
+        out["plan_mirror"] = op.backend_m.describe_plan()
+    co = COperator(model, shapes, m.params, arr)
+    w = 400 + 500 * np.random.default_rng(0).random(shapes)
+    v = np.random.default_rng(1).standard_normal(shapes)
+    w_loc = op.scatter_from_full(torch.from_numpy(w)).cuda()
+    v_loc = op.scatter_from_full(torch.from_numpy(v)).cuda()
+    want = co(w)
+    out["T"] = float(np.max(np.abs(op.gather_full(op.apply_T(w_loc)).cpu().numpy() - want) / want))
+    out["Tlin"] = float(np.max(np.abs(op.gather_full(op.linearize(w_loc)).cpu().numpy() - want) / want))
+    ref = co.jvp(w, v)
+    out["jvp"] = float(np.max(np.abs(op.gather_full(op.jvp(v_loc)).cpu().numpy() - ref)) / np.max(np.abs(ref)))
+    out["resid"] = abs(op.sup_norm_diff(op.apply_T(w_loc), w_loc) - np.max(np.abs(want - w))) / np.max(np.abs(want - w))
+    if max(out["T"], out["Tlin"], out["jvp"]) > 1e-6:
+        return out
+    del want, ref
+    # the fixed point, from the single-GPU library (every rank computes its own copy: a third of a second at 16^6)
+    one = S.KoopmansOperator(model, shapes, m.params, arr)
+    xs, ns, _ = one.solve(np.full(shapes, 800.0), "newton", tol=1e-10, inner_rtol=1e-6, inner_atol=0.0, max_iter=30)
+    near = xs + 3e-5 * (np.random.default_rng(5).random(shapes) - 0.5)            # ~25 SA iterations from tol 1e-6
+    xa, na, _ = one.solve(near, "successive_approx", tol=1e-6, max_iter=500)
+    one.close()
+    scat = lambda a: op.scatter_from_full(torch.from_numpy(np.ascontiguousarray(a))).cuda()   # noqa: E731
+    full = lambda x_loc: op.gather_full(x_loc).cpu().numpy()                      # noqa: E731
+    # (the exchanges of this test go through gloo and host memory, 0.1-0.2 s each at this size: short loops)
+    # successive approximation with the mirror schedule (both orientations of the stage plans), gated on the device
+    st = {}
+    x_loc, n = D.successive_approx_sharded(op, scat(near), tol=1e-6, max_iter=500, stats=st, check_every=8)
+    out["sa"] = (n, na, float(np.max(np.abs(full(x_loc) - xa))), st.get("mirror_iters", 0), st.get("host_syncs", -1))
+    x_loc, n = D.successive_approx_sharded(op, scat(near), tol=1e-6, max_iter=500, check_every=8, mirror=False)
+    out["sa_exact"] = (n, na, float(np.max(np.abs(full(x_loc) - xa))))
+    if dist.get_world_size() > 2:
+        return out
+    # Newton-Krylov from the reference's start, device-gated BiCGSTAB chunks (loose inner solves: ~100 J.v applications)
+    nst = {}
+    x_loc, n = D.newton_sharded(op, scat(np.full(shapes, 800.0)), tol=1e-8, max_iter=30, inner_rtol=1e-2, inner_atol=0.0, stats=nst)
+    out["newton"] = (n, float(np.max(np.abs(full(x_loc) - xs))), nst.get("krylov_host_syncs", -1), nst.get("krylov_iters", -1))
+    # Anderson, device-resident state: the residual of what it returns
+    st = {}
+    x_loc, n = D.anderson_sharded(op, scat(near), tol=1e-7, max_iter=500, stats=st, check_every=8)
+    out["anderson"] = (n, float(op.sup_norm_diff(op.apply_T(x_loc), x_loc)), float(np.max(np.abs(full(x_loc) - xs))), st.get("host_syncs", -1))
+    return out
 
 
 if __name__ == "__main__":

@@ -146,7 +146,7 @@ def test_conditional_kernels_gcy20_vs_c_oracle(S, gcy20, c_oracle):
     Tc.close()
 
 
-def test_sharded_stages_gcy20_eight_way_split(S, gcy20):
+def test_sharded_stages_gcy20_eight_way_split(S, gcy20, c_oracle):
     """The stage kernels of sdfs_create_sharded at 20^6 with the real 20-over-8 split: every rank's stage 0 on its
     z-block, the A->B exchange as host slicing, every rank's stage 1 on its h_c-block -- T with residual, linearise +
     J.v, and the mirror orientation -- against the single-GPU handle.  Also sdfs_pack_blocks at these block sizes."""
@@ -165,6 +165,11 @@ def test_sharded_stages_gcy20_eight_way_split(S, gcy20):
     want_res = T.residual()
     want_J = T.jvp(w, v)
     T.close()
+    # the reference values themselves against the C oracle on the full grid: the test stands on its own
+    ref_T = c_oracle(w)
+    assert np.max(np.abs(want_T - ref_T) / ref_T) < 1e-12
+    ref_J = c_oracle.jvp(w, v)
+    assert np.max(np.abs(want_J - ref_J)) < 1e-11 * np.max(np.abs(ref_J))
     dev = torch.device("cuda", 0)
 
     def sl(axis, lo, n):

@@ -142,44 +142,6 @@ def test_pair_plan_gcy_6d_vs_c_oracle(S, shapes):
     np.testing.assert_allclose(jp, Tc.jvp(w, v), rtol=1e-11, atol=1e-12 * np.max(np.abs(jw)))
 
 
-def test_persistent_line_kernel_variant(S):
-    """SDFS_LINE_PERSIST=3: the persistent form of the line kernel (ticket-scheduled tiles, next tile parked in
-    LDS during the epilogue).  Same numbers as one tile per workgroup, on T, the residual and the J.v dots path."""
-    shapes = (16, 16, 16, 16)
-    m = S.SSY(); arr = S.discretize_ssy(m, shapes)
-    with plan_env("pair"):
-        T0 = S.KoopmansOperator("ssy", shapes, m.params, arr)
-        os.environ["SDFS_LINE_PERSIST"] = "3"
-        try:
-            T3 = S.KoopmansOperator("ssy", shapes, m.params, arr)
-        finally:
-            del os.environ["SDFS_LINE_PERSIST"]
-    assert "persistent" in T3.describe_plan() and "persistent" not in T0.describe_plan()
-    w = wbench(shapes)
-    for _ in range(3):                      # the ticket counters must come back to zero after every launch
-        np.testing.assert_array_equal(T3(w), T0(w))
-        assert T3.residual() == T0.residual()
-    v = np.random.default_rng(1).standard_normal(shapes)
-    np.testing.assert_array_equal(T3.jvp(w, v), T0.jvp(w, v))
-    w0 = np.full(shapes, 800.0)
-    x3, n3, _ = T3.solve(w0, "newton", tol=1e-10, inner_rtol=1e-8, inner_atol=0.0)
-    x0, n0, _ = T0.solve(w0, "newton", tol=1e-10, inner_rtol=1e-8, inner_atol=0.0)
-    assert n3 == n0
-    np.testing.assert_allclose(x3, x0, rtol=0, atol=1e-9)
-    # 6-D: three passes, many tiles per persistent workgroup
-    g = S.GCY(); gs = (16,) * 6; garr = S.discretize_gcy(g, gs)
-    T0 = S.KoopmansOperator("gcy", gs, g.params, garr)
-    os.environ["SDFS_LINE_PERSIST"] = "3"
-    try:
-        T3 = S.KoopmansOperator("gcy", gs, g.params, garr)
-    finally:
-        del os.environ["SDFS_LINE_PERSIST"]
-    wg = wbench(gs)
-    for _ in range(2):
-        np.testing.assert_array_equal(T3(wg), T0(wg))
-        assert T3.residual() == T0.residual()
-
-
 def test_pair_plan_full_range_power_path(S):
     """w <= 0, NaN and huge values leave the straight-line power routine: the wave redoes its units with the
     full routine and the results equal numpy's (NaN where the reference gives NaN, residual +inf)."""
@@ -412,3 +374,37 @@ def test_newton_with_fp32_mfma_jvp(S, shapes):
     assert not any(nm.startswith("jvp32:") for nm in res[3][2]), res[3][2]          # every J.v pass ran on the fp32-MFMA kernels
     assert res[3][0] <= res[1][0] + 2 and res[3][1] <= 1.3 * res[1][1], (res[1][:2], res[3][:2])
     T.close()
+
+
+@pytest.mark.parametrize("shapes", [(16,) * 6, (20, 20, 16, 16, 16, 16)])
+def test_bicgstab_vector_updates_in_the_first_jvp_pass(S, shapes):
+    """Large grids, fp64 Krylov storage on the pair plan: BiCGSTAB's p = r + beta (p - omega q) and s = r - alpha q are
+    formed on the registers of J.v's first pass and <rhat, q> is summed by its last (csrc/krylov_kernels.hpp; the inner
+    solve is jax.scipy.sparse.linalg.bicgstab at code/solvers.py:91-93) -- 31 grid streams per iteration instead of 34.
+    Held to the loop with separate BLAS-1 kernels on the generic tiles (SDFS_PLAN=classic: another kernel family
+    altogether): the same Newton steps, the same number of J.v applications to a few per cent, the same fixed point; the
+    counters show which first passes ran."""
+    m = S.GCY()
+    arr = S.discretize_gcy(m, shapes)
+    Tf = S.KoopmansOperator("gcy", shapes, m.params, arr)
+    with plan_env("classic"):
+        Tp = S.KoopmansOperator("gcy", shapes, m.params, arr)
+    w0 = np.full(shapes, 800.0)
+    out = {}
+    for name, T in (("fused", Tf), ("plain", Tp)):
+        T.set_profiling(True); T.reset_counters()
+        x, n, info = T.solve(w0, "newton", tol=1e-8, inner_rtol=1e-6, inner_atol=0.0, max_iter=40, record_errors=True)
+        names = [c["name"] for c in T.counters() if c["launches"]]
+        T.set_profiling(False)
+        assert info["status"] == 0
+        out[name] = (x, n, info["n_apply"], info["errors"], names)
+    assert any(nm.startswith("jvp+p:") for nm in out["fused"][4]) and any(nm.startswith("jvp+s:") for nm in out["fused"][4]), out["fused"][4]
+    assert not any(nm.startswith("jvp+") for nm in out["plain"][4])
+    assert out["fused"][1] == out["plain"][1], (out["fused"][1:3], out["plain"][1:3])
+    # (BiCGSTAB's iteration count to a relative tolerance moves by a few per cent with the summation order of its inner
+    # products -- 537 against 549 applications at 16^6 between these two kernel families)
+    assert abs(out["fused"][2] - out["plain"][2]) <= max(6, out["plain"][2] // 20), (out["fused"][2], out["plain"][2])
+    # the first Newton steps: both inner solves stop at a relative residual of 1e-6, at different iterates of that size
+    np.testing.assert_allclose(out["fused"][3][:3], out["plain"][3][:3], rtol=3e-5)
+    assert np.max(np.abs(out["fused"][0] - out["plain"][0])) < 1e-8
+    Tf.close(); Tp.close()

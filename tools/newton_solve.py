@@ -1,8 +1,8 @@
 """One Newton-Krylov solve at GCY 20^6 (BASELINE configs[3]'s algorithm: code/solvers.py:51-95, inner BiCGSTAB) from
 w = 800 to 1e-8, resident on the device -- the command tools/newton_profile.sh traces.  argv: [krylov_f32 (0 / 1 / 3)] [n]"""
-import json, sys, time
+import json, os, sys, time
 import numpy as np
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))      # (rocprofv3 runs it from /tmp)
 import torch
 import sdfs_via_autodiff_amd as S
 
