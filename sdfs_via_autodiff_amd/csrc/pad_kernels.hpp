@@ -50,7 +50,11 @@ template <int NT> struct PadSliceGeo {
   static_assert((G * NT) % 16 == 0, "whole column tiles");
 };
 
-template <int MODE, int NT>
+// PAIR (round 4): 16-byte requests.  A wave tile is G * nx * ny contiguous doubles from an even element offset whenever
+// that count is even (G = 4 / 2: always; G = 1: nx * ny even), so lane l takes the double2 units l, l + 64, ... of the
+// tile -- half the load / store instructions of the element-wise form, which stays for odd 32-wide slices.  A unit may
+// straddle a row or a slice: each of its two elements has its own LDS offset, as before.
+template <int MODE, int NT, bool PAIR>
 __global__ void __launch_bounds__(256, PadSliceGeo<NT>::OCC)
 pad_slice_kernel(const PadDesc P, const SliceIO io) {
   using Geo = PadSliceGeo<NT>;
@@ -71,16 +75,32 @@ pad_slice_kernel(const PadDesc P, const SliceIO io) {
   if (s0 >= P.nslices) return;                                   // no workgroup barrier below
   const int nxy = P.nx * P.ny;
   const long long left = P.nslices - s0;
-  const int nval = (int)(left < PAD_G ? left : PAD_G) * nxy;     // elements of this tile
+  const int nval = (int)(left < PAD_G ? left : PAD_G) * nxy;     // elements of this tile (PAIR: even)
   const long long gbase = s0 * nxy;
   double* const wl = lds + wave * PAD_LT;
+  // element k of this lane within the tile
+  auto EI = [&](const int k) -> int { return PAIR ? 2 * (lane + 64 * (k >> 1)) + (k & 1) : lane + 64 * k; };
   // ---- loads, in memory order ------------------------------------------------------------------------------------
   double v[PAD_EPL], c1v[MULP ? PAD_EPL : 1];
+  if (PAIR) {
 #pragma unroll
-  for (int k = 0; k < PAD_EPL; ++k) {
-    const int e = lane + 64 * k;
-    v[k] = e < nval ? io.in[gbase + e] : (POWP ? 1.0 : 0.0);
-    if (MULP) c1v[MULP ? k : 0] = e < nval ? io.aux_in[gbase + e] : 0.0;
+    for (int k = 0; k < PAD_EPL; k += 2) {
+      const int e = EI(k);
+      const bool ok = e < nval;
+      const v2d a = ok ? *reinterpret_cast<const v2d*>(io.in + gbase + e) : (v2d){POWP ? 1.0 : 0.0, POWP ? 1.0 : 0.0};
+      v[k] = a.x; v[k + 1] = a.y;
+      if (MULP) {
+        const v2d c = ok ? *reinterpret_cast<const v2d*>(io.aux_in + gbase + e) : (v2d){0.0, 0.0};
+        c1v[MULP ? k : 0] = c.x; c1v[MULP ? k + 1 : 0] = c.y;
+      }
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < PAD_EPL; ++k) {
+      const int e = EI(k);
+      v[k] = e < nval ? io.in[gbase + e] : (POWP ? 1.0 : 0.0);
+      if (MULP) c1v[MULP ? k : 0] = e < nval ? io.aux_in[gbase + e] : 0.0;
+    }
   }
   // ---- zero image, element -> (slice, x, y) -> LDS offset -------------------------------------------------------
 #pragma unroll
@@ -89,7 +109,7 @@ pad_slice_kernel(const PadDesc P, const SliceIO io) {
   int lo[PAD_EPL];
 #pragma unroll
   for (int k = 0; k < PAD_EPL; ++k) {
-    const unsigned e = (unsigned)(lane + 64 * k);
+    const unsigned e = (unsigned)EI(k);
     const unsigned s = (e * P.mxy) >> 20, r = e - s * (unsigned)nxy;
     const unsigned x = (r * P.my) >> 20, y = r - x * (unsigned)P.ny;
     lo[k] = (int)((s * (unsigned)NT + x) * (unsigned)PAD_RS + y);
@@ -107,8 +127,12 @@ pad_slice_kernel(const PadDesc P, const SliceIO io) {
       double xw[2];
       PT.template run<2>(xin, xw);
       if (LIN) {
-        if (lane + 64 * k < nval) io.aux_out[gbase + lane + 64 * k] = xw[0] / xin[0];
-        if (lane + 64 * (k + 1) < nval) io.aux_out[gbase + lane + 64 * (k + 1)] = xw[1] / xin[1];
+        if (PAIR) {
+          if (EI(k) < nval) *reinterpret_cast<v2d*>(io.aux_out + gbase + EI(k)) = (v2d){xw[0] / xin[0], xw[1] / xin[1]};
+        } else {
+          if (EI(k) < nval) io.aux_out[gbase + EI(k)] = xw[0] / xin[0];
+          if (EI(k + 1) < nval) io.aux_out[gbase + EI(k + 1)] = xw[1] / xin[1];
+        }
       }
       v[k] = xw[0]; v[k + 1] = xw[1];
     }
@@ -116,7 +140,7 @@ pad_slice_kernel(const PadDesc P, const SliceIO io) {
 #pragma unroll
   for (int k = 0; k < PAD_EPL; ++k) {
     if (MULP) v[k] *= c1v[MULP ? k : 0];
-    if (lane + 64 * k < nval) wl[lo[k]] = v[k];
+    if (EI(k) < nval) wl[lo[k]] = v[k];
   }
   wave_lds_fence();
   const int li = lane & 15, lk = lane >> 4;
@@ -140,9 +164,15 @@ pad_slice_kernel(const PadDesc P, const SliceIO io) {
     }
   }
   wave_lds_fence();
+  if (PAIR) {
 #pragma unroll
-  for (int k = 0; k < PAD_EPL; ++k)
-    if (lane + 64 * k < nval) io.out[gbase + lane + 64 * k] = wl[lo[k]];
+    for (int k = 0; k < PAD_EPL; k += 2)
+      if (EI(k) < nval) *reinterpret_cast<v2d*>(io.out + gbase + EI(k)) = (v2d){wl[lo[k]], wl[lo[k + 1]]};
+  } else {
+#pragma unroll
+    for (int k = 0; k < PAD_EPL; ++k)
+      if (EI(k) < nval) io.out[gbase + EI(k)] = wl[lo[k]];
+  }
 }
 
 // Line form.  A tile is all (x, y) rows of R consecutive positions behind the pair (R = 16: a 128-byte line per row;
@@ -163,7 +193,9 @@ template <int NT, int R> struct PadLineGeo {
   static_assert((NT * R) % 16 == 0, "whole column tiles");
 };
 
-template <int MODE, int NT, int R>
+// EVEN (round 4): the remainder behind the pair is even, so every row of a tile starts on a 16-byte boundary and a unit is
+// one 16-byte request in every stream (both of its positions are inside the remainder or neither is).
+template <int MODE, int NT, int R, bool EVEN>
 __global__ void __launch_bounds__((PadLineGeo<NT, R>::B), (PadLineGeo<NT, R>::OCC * PadLineGeo<NT, R>::B / 256))
 pad_line_kernel(const PadDesc P, const LineIO io) {
   using Geo = PadLineGeo<NT, R>;
@@ -195,6 +227,14 @@ pad_line_kernel(const PadDesc P, const LineIO io) {
     rok = x < P.nx && y < P.ny && (!Geo::PARTIAL || tid + B * k < Geo::UNITS);
     off = ((long long)x * P.ny + y) * P.lrest;
   };
+  auto ld2 = [](const double* const q, const bool a, const bool b) -> double2 {
+    if (EVEN) return a ? *reinterpret_cast<const double2*>(q) : make_double2(0.0, 0.0);
+    return make_double2(a ? q[0] : 0.0, b ? q[1] : 0.0);
+  };
+  auto st2 = [](double* const q, const bool a, const bool b, const double x, const double y) {
+    if (EVEN) { if (a) *reinterpret_cast<double2*>(q) = make_double2(x, y); }
+    else { if (a) q[0] = x; if (b) q[1] = y; }
+  };
   // ---- loads: the tile and the side stream that crosses the contractions -----------------------------------------
   const double* const inb = io.in + tbase;
   const double* const oldb = io.old + tbase;
@@ -205,9 +245,8 @@ pad_line_kernel(const PadDesc P, const LineIO io) {
     for (int k = 0; k < EPT; ++k) {
       int x, y; bool rok; long long off;
       unit_of(k, x, y, rok, off);
-      v[k] = make_double2((pk0 && rok) ? inb[off] : 0.0, (pk1 && rok) ? inb[off + 1] : 0.0);
-      if ((CES || MULE) && need_old)
-        s1[(CES || MULE) ? k : 0] = make_double2((pk0 && rok) ? oldb[off] : 0.0, (pk1 && rok) ? oldb[off + 1] : 0.0);
+      v[k] = ld2(inb + off, pk0 && rok, pk1 && rok);
+      if ((CES || MULE) && need_old) s1[(CES || MULE) ? k : 0] = ld2(oldb + off, pk0 && rok, pk1 && rok);
     }
 #pragma unroll
     for (int k = 0; k < EPT; ++k)
@@ -267,16 +306,10 @@ pad_line_kernel(const PadDesc P, const LineIO io) {
       double uu[2];
       PT.template run<2>(ks, uu);
       const double y0 = 1.0 + P.beta * uu[0], y1 = 1.0 + P.beta * uu[1];
-      if (a) {
-        if (LINE) auxo[off] = P.beta * uu[0] / sv.x;
-        if (need_old) { const double r0 = fabs(y0 - s1[k].x); rnan |= (r0 != r0); rmax = fmax(rmax, r0); }
-        outb[off] = y0;
-      }
-      if (b) {
-        if (LINE) auxo[off + 1] = P.beta * uu[1] / sv.y;
-        if (need_old) { const double r1 = fabs(y1 - s1[k].y); rnan |= (r1 != r1); rmax = fmax(rmax, r1); }
-        outb[off + 1] = y1;
-      }
+      if (a && need_old) { const double r0 = fabs(y0 - s1[k].x); rnan |= (r0 != r0); rmax = fmax(rmax, r0); }
+      if (b && need_old) { const double r1 = fabs(y1 - s1[k].y); rnan |= (r1 != r1); rmax = fmax(rmax, r1); }
+      if (LINE) st2(auxo + off, a, b, P.beta * uu[0] / sv.x, P.beta * uu[1] / sv.y);
+      st2(outb + off, a, b, y0, y1);
     }
   } else {
     const double* const auxb = io.aux_in + tbase;
@@ -286,7 +319,7 @@ pad_line_kernel(const PadDesc P, const LineIO io) {
       for (int k = 0; k < EPT; ++k) {
         int x, y; bool rok; long long off;
         unit_of(k, x, y, rok, off);
-        s2[MULE ? k : 0] = make_double2((pk0 && rok) ? auxb[off] : 0.0, (pk1 && rok) ? auxb[off + 1] : 0.0);
+        s2[MULE ? k : 0] = ld2(auxb + off, pk0 && rok, pk1 && rok);
       }
     }
 #pragma unroll
@@ -304,8 +337,7 @@ pad_line_kernel(const PadDesc P, const LineIO io) {
           if (b) { dot_yv = fma(y2.y, o2.y, dot_yv); dot_yy = fma(y2.y, y2.y, dot_yy); }
         }
       }
-      if (a) outb[off] = y2.x;
-      if (b) outb[off + 1] = y2.y;
+      st2(outb + off, a, b, y2.x, y2.y);
     }
   }
   // ---- per-workgroup reductions ------------------------------------------------------------------------------------
@@ -336,29 +368,36 @@ pad_line_kernel(const PadDesc P, const LineIO io) {
 typedef void (*pad_slice_fn)(const PadDesc, const SliceIO);
 typedef void (*pad_line_fn)(const PadDesc, const LineIO);
 #ifndef SDFS_NO_VARIANT_TABLES
-template <int NT> inline pad_slice_fn pad_slice_variant_n(int mode) {
+template <int NT, bool PAIR> inline pad_slice_fn pad_slice_variant_n(int mode) {
   switch (mode) {
-    case S_TFIRST: return pad_slice_kernel<S_TFIRST, NT>;
-    case S_TFIRST_LIN: return pad_slice_kernel<S_TFIRST_LIN, NT>;
-    case S_JFIRST: return pad_slice_kernel<S_JFIRST, NT>;
+    case S_TFIRST: return pad_slice_kernel<S_TFIRST, NT, PAIR>;
+    case S_TFIRST_LIN: return pad_slice_kernel<S_TFIRST_LIN, NT, PAIR>;
+    case S_JFIRST: return pad_slice_kernel<S_JFIRST, NT, PAIR>;
     default: return nullptr;
   }
 }
-template <int NT, int R> inline pad_line_fn pad_line_variant_n(int mode) {
+template <int NT, int R, bool EVEN> inline pad_line_fn pad_line_variant_ne(int mode) {
   switch (mode) {
-    case L_MID: return pad_line_kernel<L_MID, NT, R>;
-    case L_TLAST: return pad_line_kernel<L_TLAST, NT, R>;
-    case L_TLAST_LIN: return pad_line_kernel<L_TLAST_LIN, NT, R>;
-    case L_JLAST: return pad_line_kernel<L_JLAST, NT, R>;
+    case L_MID: return pad_line_kernel<L_MID, NT, R, EVEN>;
+    case L_TLAST: return pad_line_kernel<L_TLAST, NT, R, EVEN>;
+    case L_TLAST_LIN: return pad_line_kernel<L_TLAST_LIN, NT, R, EVEN>;
+    case L_JLAST: return pad_line_kernel<L_JLAST, NT, R, EVEN>;
     default: return nullptr;
   }
 }
-inline pad_slice_fn pad_slice_variant(int nt, int mode) {
-  return nt == 16 ? pad_slice_variant_n<16>(mode) : (nt == 20 ? pad_slice_variant_n<20>(mode) : (nt == 24 ? pad_slice_variant_n<24>(mode) : (nt == 32 ? pad_slice_variant_n<32>(mode) : nullptr)));
+template <int NT, int R> inline pad_line_fn pad_line_variant_n(int mode, bool even) {
+  return even ? pad_line_variant_ne<NT, R, true>(mode) : pad_line_variant_ne<NT, R, false>(mode);
+}
+// (nxy = nx * ny of the slice pass: the 32-wide tiles hold one slice and pair their requests when it is even)
+inline pad_slice_fn pad_slice_variant(int nt, int mode, int nxy) {
+  return nt == 16 ? pad_slice_variant_n<16, true>(mode) : (nt == 20 ? pad_slice_variant_n<20, true>(mode) : (nt == 24 ? pad_slice_variant_n<24, true>(mode) :
+         (nt == 32 ? (nxy % 2 == 0 ? pad_slice_variant_n<32, true>(mode) : pad_slice_variant_n<32, false>(mode)) : nullptr)));
 }
 // (rows of 16 doubles on the 16-wide tiles, of 8 on the wide ones)
-inline pad_line_fn pad_line_variant(int nt, int mode) {
-  return nt == 16 ? pad_line_variant_n<16, 16>(mode) : (nt == 20 ? pad_line_variant_n<20, 8>(mode) : (nt == 24 ? pad_line_variant_n<24, 8>(mode) : (nt == 32 ? pad_line_variant_n<32, 8>(mode) : nullptr)));
+// (even: the remainder behind the pair is even -- 16-byte requests)
+inline pad_line_fn pad_line_variant(int nt, int mode, bool even) {
+  return nt == 16 ? pad_line_variant_n<16, 16>(mode, even) : (nt == 20 ? pad_line_variant_n<20, 8>(mode, even) : (nt == 24 ? pad_line_variant_n<24, 8>(mode, even) :
+         (nt == 32 ? pad_line_variant_n<32, 8>(mode, even) : nullptr)));
 }
 #endif
 inline int pad_slice_g(int nt) { return nt == 16 ? PadSliceGeo<16>::G : (nt == 20 ? PadSliceGeo<20>::G : (nt == 24 ? PadSliceGeo<24>::G : PadSliceGeo<32>::G)); }

@@ -82,7 +82,7 @@ struct EventPair { hipEvent_t a, b; int counter; };
 struct FastPass {
   bool line = false;
   bool persist = false;        // line pass: persistent workgroups with look-ahead into the next tile
-  bool stream = false;         // line pass: the fp64 T / J.v middle pass and T's last pass run stream_kernels.hpp's forms
+  int stream = 0;              // line pass: stream_kernels.hpp's forms -- bit 0: as a middle pass (T and J.v, fp64), bit 1: as T's last pass
   int n = 0;
   int ax0 = -1, ax1 = -1;      // the contracted pair (ax0 slower)
   SliceDesc sd;
@@ -126,8 +126,7 @@ struct Knobs {
   int and_fused = 1;           // SDFS_AND_FUSED: 0 = Anderson on the small-grid plan keeps push / step / update as launches of their own
   int a3_tables = 1;           // SDFS_A3_TABLES: 0 = the streamed last pass gathers a3 even where it factorises into two small tables
   int sa_fused = -1;           // SDFS_SA_FUSED: 0 = successive approximation keeps one launch per pass; 1 = fused end + start kernels;
-                               // default (-1): fused, except on the 6-D pair plan when its line passes run the streamed forms
-                               // (three streamed launches, 0.805 ms at GCY 20^6, beat slices + fused lines, 0.83 ms)
+                               // default (-1): fused on the small-grid plan, one launch per pass on the 6-D pair plan
   int ablate = 0;              // SDFS_ABLATE, honoured only by -DSDFS_DIAG builds
 };
 
@@ -883,7 +882,11 @@ int prepare_fast_passes(sdfs_handle* h, std::vector<FastPass>& passes) {
       line_fn f = line_tlast32_variant(P.n);
       if (f) hipFuncSetAttribute((const void*)f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)line_lds_bytes(P.n));
     }
-    P.stream = P.line && P.ld.lrest % LINE_R == 0 && (h->knobs.line_stream & 3) != 0 && ((h->knobs.line_stream & 4) != 0 || P.n == 20);
+    // which forms pay was measured per extent (tools/ab_plan.py, profiles/round4_ab_stream_forms.txt: 24^6 -13.7 % with
+    // both; 16^6 -2.7 % with the last pass only, its middle pass loses 11 %; 32-wide pairs -1.8 % with the middle pass
+    // only, their last pass loses 5 %); SDFS_LINE_STREAM bit 2 = both forms on every extent
+    const int pays = (h->knobs.line_stream & 4) ? 3 : (P.n == 16 ? 2 : (P.n == 32 ? 1 : 3));
+    P.stream = (P.line && P.ld.lrest % LINE_R == 0) ? (h->knobs.line_stream & 3 & pays) : 0;
     if (!P.stream) continue;
     for (int m : {(int)L_MID, (int)L_TLAST, (int)L_TLAST_LIN}) for (int a3f = 0; a3f < 2; ++a3f) {
       line_fn f = line_stream_variant(P.n, m, a3f != 0);
@@ -1130,7 +1133,7 @@ int build_pad_plan(sdfs_handle* h) {
               std::to_string(S.nx) + "x" + std::to_string(S.ny) + " on " + std::to_string(P.nt) + "x" + std::to_string(P.nt) + "]";
     if (P.line && pad_line_lds(P.nt) > 64 * 1024)
       for (int lm : {L_MID, L_TLAST, L_TLAST_LIN, L_JLAST})
-        hipFuncSetAttribute((const void*)pad_line_variant(P.nt, lm), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad_line_lds(P.nt));
+        hipFuncSetAttribute((const void*)pad_line_variant(P.nt, lm, lrest % 2 == 0), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad_line_lds(P.nt));
     if (i + 1 == pairs.size()) {
       // a3 index tables of the last pass (as build_small_plan)
       std::vector<int> outv((size_t)nouter, 0), restv((size_t)lrest, 0);
@@ -1224,7 +1227,7 @@ int run_fast_plan(sdfs_handle* h, FastPlan& fp, long long nloc, bool has_first, 
         if (h->profiling) { char nm[48]; snprintf(nm, sizeof nm, "%s:%s", tag, P.label.c_str()); cid = counter_id(h, nm, bytes, P.flops); }
         const long long ntile = (d.nslices + pad_slice_g(P.nt) - 1) / pad_slice_g(P.nt);
         ProfScope ps(h, cid);
-        hipLaunchKernelGGL(pad_slice_variant(P.nt, sm), dim3((unsigned)((ntile + 3) / 4)), dim3(256), 0, h->stream, d, io);
+        hipLaunchKernelGGL(pad_slice_variant(P.nt, sm, d.nx * d.ny), dim3((unsigned)((ntile + 3) / 4)), dim3(256), 0, h->stream, d, io);
       } else {
         LineIO io;
         memset(&io, 0, sizeof io);
@@ -1237,7 +1240,7 @@ int run_fast_plan(sdfs_handle* h, FastPlan& fp, long long nloc, bool has_first, 
         }
         if (h->profiling) { char nm[48]; snprintf(nm, sizeof nm, "%s:%s", tag, P.label.c_str()); cid = counter_id(h, nm, bytes, P.flops); }
         ProfScope ps(h, cid);
-        hipLaunchKernelGGL(pad_line_variant(P.nt, lm), dim3((unsigned)d.ntiles), dim3(pad_line_block(P.nt)), pad_line_lds(P.nt), h->stream, d, io);
+        hipLaunchKernelGGL(pad_line_variant(P.nt, lm, d.lrest % 2 == 0), dim3((unsigned)d.ntiles), dim3(pad_line_block(P.nt)), pad_line_lds(P.nt), h->stream, d, io);
       }
     } else if (P.small) {
       SmallIO io;
@@ -1329,7 +1332,7 @@ int run_fast_plan(sdfs_handle* h, FastPlan& fp, long long nloc, bool has_first, 
         fn = last ? line_tlast32_variant(P.n) : line_variant(P.n, L_MID, false, true, true);
         grid = (unsigned)d.ntiles;
         bytes -= last ? 0.5 * n8 : n8;
-      } else if (P.stream && !lf32 && ((lm == L_MID && (h->knobs.line_stream & 1)) || ((lm == L_TLAST || lm == L_TLAST_LIN) && (h->knobs.line_stream & 2)))) {
+      } else if (!lf32 && ((lm == L_MID && (P.stream & 1)) || ((lm == L_TLAST || lm == L_TLAST_LIN) && (P.stream & 2)))) {
         // stream_kernels.hpp: persistent middle pass with the next tile in flight; last pass with its side stream loaded early
         fn = line_stream_variant(P.n, lm, d.f1 != nullptr);
         grid = lm == L_MID ? stream_mid_grid(h, P) : (unsigned)d.ntiles;
@@ -1634,10 +1637,11 @@ int solve_sa(sdfs_handle* h, const sdfs_opts& o, double* w, int64_t* n_iter, int
   const bool fused = h->fast.ok && h->fast.small && !h->cont && !h->dense && h->knobs.sa_fused != 0;
   if (fused && (rc = small_sa_prologue(h, h->buf0))) return rc;
   // 6-D pair plan: plain slice pass + fused line pass per iteration
-  bool streamed = h->fast.ok && !h->fast.small && !h->fast.pad && h->fast.passes.size() == 3 && (h->knobs.line_stream & 3) == 3;
-  for (const FastPass& P : h->fast.passes) if (P.line && !P.stream) streamed = false;
-  const bool fusedbig = h->fast.ok && !h->fast.small && !h->fast.pad && h->fast.passes.size() == 3 && !h->cont && !h->dense && h->knobs.sa_fused != 0 &&
-                        !(h->knobs.sa_fused < 0 && streamed) && !h->t32_active;
+  // (round 4, tools/sa_rate.py: with this round's first and last passes the three launches of T win on every extent --
+  // 16^6 0.195 against 0.207 ms per iteration, 24^6 2.45 against 2.71, 32^4 x 16^2 4.21 against 4.45 -- so the fused form
+  // runs on request only)
+  const bool fusedbig = h->fast.ok && !h->fast.small && !h->fast.pad && h->fast.passes.size() == 3 && !h->cont && !h->dense && h->knobs.sa_fused > 0 &&
+                        !h->t32_active;
   if (fusedbig && (rc = big_sa_line(h, 2, true, h->buf0, nullptr, nullptr, nullptr, nullptr, 0.0))) return rc;
   // ... and the residual without atomics: per-workgroup maxima, reduced by the next iteration's kernels
   bool ring = false;
@@ -3410,7 +3414,9 @@ int sdfs_describe_plan(const sdfs_handle* h, char* buf, int64_t cap) {
         hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)line_variant(P.n, L_MID, P.persist, P.ld.lrest % LINE_R == 0), line_block(P.n), line_lds_bytes(P.n));
         snprintf(line, sizeof line, "pair plan pass %zu: %s lds %zu B block %d tiles %lld (outer %lld x %d chunks of 128 B) %s grid %u blocks/CU %d\n", i,
                  P.label.c_str(), line_lds_bytes(P.n), line_block(P.n), P.ld.ntiles, P.ld.nouter, P.ld.nchunks,
-                 P.stream ? "streamed (middle pass: persistent, next tile in flight; T's last pass: side stream loaded early)" :
+                 P.stream == 3 ? "streamed (middle pass: persistent, next tile in flight; T's last pass: side stream loaded early)" :
+                 P.stream == 1 ? "streamed as a middle pass (persistent, next tile in flight)" :
+                 P.stream == 2 ? "streamed as T's last pass (side stream loaded early)" :
                  P.persist ? "persistent" : "one tile per workgroup", line_grid(h, P), occ);
       }
       s += line;

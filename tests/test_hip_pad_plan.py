@@ -16,7 +16,10 @@ pytestmark = pytest.mark.gpu
 
 SHAPES = [(10,) * 6, (12, 11, 9, 13, 10, 7), (15,) * 6, (16, 15, 14, 13, 12, 11), (9, 16, 5, 16, 16, 15), (13, 13, 16, 16, 3, 4),
           # 24- and 32-wide tiles, mixed per pass; 4-D grids beyond the small-grid plan
-          (17,) * 6, (25, 19, 9, 9, 12, 7), (32, 32, 5, 5, 6, 24), (3, 30, 22, 21, 17, 18), (20,) * 4, (25, 18, 32, 7), (32,) * 4]
+          (17,) * 6, (25, 19, 9, 9, 12, 7), (32, 32, 5, 5, 6, 24), (3, 30, 22, 21, 17, 18), (20,) * 4, (25, 18, 32, 7), (32,) * 4,
+          # round 4, 16-byte requests: even remainders behind a line pair (18^6, 14^6) against odd ones (21^4, 15^6 above);
+          # 32-wide slices of an odd and of an even number of points (25 x 25, 26 x 31)
+          (18,) * 6, (14,) * 6, (21,) * 4, (25,) * 4, (27, 29, 26, 31)]
 
 
 @pytest.fixture(scope="module")

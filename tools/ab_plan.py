@@ -32,7 +32,8 @@ VARIANTS = {
 
 def main():
     wl = sys.argv[1] if len(sys.argv) > 1 else "gcy20"
-    shapes = {"gcy20": (20,) * 6, "gcy16": (16,) * 6}[wl]
+    shapes = {"gcy20": (20,) * 6, "gcy16": (16,) * 6, "gcy24": (24,) * 6, "gcy32": (32, 32, 32, 32, 16, 16),
+              "gcy24x16": (24, 24, 24, 24, 16, 16)}[wl]
     only = sys.argv[2].split(",") if len(sys.argv) > 2 else None
     m = S.GCY()
     arr = S.discretize_gcy(m, shapes)

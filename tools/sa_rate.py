@@ -1,6 +1,6 @@
 """Successive-approximation rate on the device loop: K iterations (tol = 0: never converges), one host sync.
 
-    python tools/sa_rate.py [gcy20|gcy16] [K]      prints ms per iteration for SDFS_SA_FUSED = 1 (default) and 0"""
+    python tools/sa_rate.py [gcy20|gcy16] [K]      prints ms per iteration for the default choice, SDFS_SA_FUSED = 1 and 0"""
 import os
 import sys
 import time
@@ -15,11 +15,12 @@ import sdfs_via_autodiff_amd as S  # noqa: E402
 def main():
     wl = sys.argv[1] if len(sys.argv) > 1 else "gcy20"
     K = int(sys.argv[2]) if len(sys.argv) > 2 else 60
-    shapes = {"gcy20": (20,) * 6, "gcy16": (16,) * 6}[wl]
+    shapes = {"gcy20": (20,) * 6, "gcy16": (16,) * 6, "gcy24": (24,) * 6, "gcy24x16": (24, 24, 24, 24, 16, 16),
+              "gcy32": (32, 32, 32, 32, 16, 16)}[wl]
     m = S.GCY()
     arr = S.discretize_gcy(m, shapes)
     ops = {}
-    for name, env in (("fused", {}), ("one launch per pass", {"SDFS_SA_FUSED": "0"})):
+    for name, env in (("default", {}), ("fused", {"SDFS_SA_FUSED": "1"}), ("one launch per pass", {"SDFS_SA_FUSED": "0"})):
         old = {k: os.environ.get(k) for k in env}
         os.environ.update(env)
         ops[name] = S.KoopmansOperator("gcy", shapes, m.params, arr)
