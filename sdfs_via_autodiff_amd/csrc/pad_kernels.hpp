@@ -19,6 +19,33 @@
 
 #include "fast_kernels.hpp"
 
+// workgroups per CU of the slice form by tile width (tools/README.md: build-time probes)
+#ifndef SDFS_PAD_SOCC16
+#define SDFS_PAD_SOCC16 3
+#endif
+#ifndef SDFS_PAD_SOCC24
+#define SDFS_PAD_SOCC24 3      // (round 4, 21^6: 558 -> 483 us at three, 732 at four -- spills)
+#endif
+#ifndef SDFS_PAD_SOCC32
+#define SDFS_PAD_SOCC32 3      // (25^6: 2400 -> 2004 us at three, 2700 at four)
+#endif
+#ifndef SDFS_PAD_SOCC16_J
+#define SDFS_PAD_SOCC16_J 3    // the J.v first pass (no power) on 16-wide tiles
+#endif
+// workgroups per CU of the line form where the tile would allow more than the register budget of the last pass does
+#ifndef SDFS_PAD_LOCC_MID16
+#define SDFS_PAD_LOCC_MID16 3
+#endif
+#ifndef SDFS_PAD_LOCC_MID24
+#define SDFS_PAD_LOCC_MID24 3
+#endif
+#ifndef SDFS_PAD_LOCC_MID32
+#define SDFS_PAD_LOCC_MID32 1
+#endif
+#ifndef SDFS_PAD_LOCC_LAST32
+#define SDFS_PAD_LOCC_LAST32 1
+#endif
+
 namespace sdfs {
 
 struct PadDesc {
@@ -45,7 +72,7 @@ template <int NT> struct PadSliceGeo {
   static constexpr int RS = NT + 2;
   static constexpr int LT = G * NT * RS;            // doubles of LDS per wave tile
   static constexpr int EPL = 2 * ((G * NT * NT + 127) / 128);      // elements per lane of a full tile, rounded up to even (the power runs on pairs)
-  static constexpr int OCC = NT == 16 ? 3 : 2;      // workgroups per CU the register budget is set for
+  static constexpr int OCC = NT == 16 ? SDFS_PAD_SOCC16 : (NT == 24 ? SDFS_PAD_SOCC24 : (NT == 32 ? SDFS_PAD_SOCC32 : 2));      // workgroups per CU the register budget is set for (20-wide: 56 KB of LDS per workgroup allow two)
   static_assert(EPL % 2 == 0, "the power runs on pairs");
   static_assert((G * NT) % 16 == 0, "whole column tiles");
 };
@@ -55,7 +82,7 @@ template <int NT> struct PadSliceGeo {
 // tile -- half the load / store instructions of the element-wise form, which stays for odd 32-wide slices.  A unit may
 // straddle a row or a slice: each of its two elements has its own LDS offset, as before.
 template <int MODE, int NT, bool PAIR>
-__global__ void __launch_bounds__(256, PadSliceGeo<NT>::OCC)
+__global__ void __launch_bounds__(256, ((MODE == S_JFIRST && NT == 16) ? SDFS_PAD_SOCC16_J : PadSliceGeo<NT>::OCC))
 pad_slice_kernel(const PadDesc P, const SliceIO io) {
   using Geo = PadSliceGeo<NT>;
   constexpr int PAD_G = Geo::G, PAD_RS = Geo::RS, PAD_LT = Geo::LT, PAD_EPL = Geo::EPL;
@@ -195,8 +222,12 @@ template <int NT, int R> struct PadLineGeo {
 
 // EVEN (round 4): the remainder behind the pair is even, so every row of a tile starts on a 16-byte boundary and a unit is
 // one 16-byte request in every stream (both of its positions are inside the remainder or neither is).
+template <int MODE, int NT, int R> constexpr int pad_line_occ() {
+  return (MODE == L_MID && NT == 16) ? SDFS_PAD_LOCC_MID16 : ((MODE == L_MID && NT == 24) ? SDFS_PAD_LOCC_MID24 :
+         (NT == 32 ? (MODE == L_MID ? SDFS_PAD_LOCC_MID32 : SDFS_PAD_LOCC_LAST32) : PadLineGeo<NT, R>::OCC));
+}
 template <int MODE, int NT, int R, bool EVEN>
-__global__ void __launch_bounds__((PadLineGeo<NT, R>::B), (PadLineGeo<NT, R>::OCC * PadLineGeo<NT, R>::B / 256))
+__global__ void __launch_bounds__((PadLineGeo<NT, R>::B), (pad_line_occ<MODE, NT, R>() * PadLineGeo<NT, R>::B / 256))
 pad_line_kernel(const PadDesc P, const LineIO io) {
   using Geo = PadLineGeo<NT, R>;
   constexpr int UPR = Geo::UPR;
