@@ -122,27 +122,46 @@ struct bf16r {
   __device__ __forceinline__ explicit bf16r(double d) : v(round_bf16((float)d)) {}     // "(T)x": the value as it will be stored
   __device__ __forceinline__ explicit operator double() const { return (double)v; }
 };
+// SDFS_VEC_NT / SDFS_VEC_NT_F32 (build time, bit masks): the packets of the BLAS-1 streams as non-temporal requests -- bit 0
+// loads, bit 1 stores.  Three builds side by side at GCY 20^6 (tools/ab_libs.sh, profiles/round4_vec_nt_ab.txt): fp64
+// Newton 0.782 s plain, 0.765 with both, 0.777 with loads only; Anderson 0.317 / 0.304 / 0.310; Newton with fp32 vectors
+// (krylov_f32 = 3) 0.560 / 0.539 / 0.532 -- half-size vectors still find part of themselves in the 256 MB Infinity Cache,
+// so their stores stay cacheable.
+#ifndef SDFS_VEC_NT
+#define SDFS_VEC_NT 3
+#endif
+#ifndef SDFS_VEC_NT_F32
+#define SDFS_VEC_NT_F32 1
+#endif
+typedef float vnt4f __attribute__((ext_vector_type(4)));
+typedef double vnt2d __attribute__((ext_vector_type(2)));
 template <int W>
 __device__ __forceinline__ void ldv(const double* __restrict__ p, long long e, double (&v)[W]) {
 #pragma unroll
-  for (int j = 0; j < W; j += 2) { const double2 t = *reinterpret_cast<const double2*>(p + e + j); v[j] = t.x; v[j + 1] = t.y; }
+  for (int j = 0; j < W; j += 2) {
+    const vnt2d t = (SDFS_VEC_NT & 1) ? __builtin_nontemporal_load(reinterpret_cast<const vnt2d*>(p + e + j)) : *reinterpret_cast<const vnt2d*>(p + e + j);
+    v[j] = t.x; v[j + 1] = t.y;
+  }
 }
 template <int W>
 __device__ __forceinline__ void ldv(const float* __restrict__ p, long long e, double (&v)[W]) {
   static_assert(W == 4, "float packets hold four elements");
-  const float4 t = *reinterpret_cast<const float4*>(p + e);
+  const vnt4f t = (SDFS_VEC_NT_F32 & 1) ? __builtin_nontemporal_load(reinterpret_cast<const vnt4f*>(p + e)) : *reinterpret_cast<const vnt4f*>(p + e);
   v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
 }
 template <int W>
 __device__ __forceinline__ void stv(double* __restrict__ p, long long e, const double (&v)[W]) {
 #pragma unroll
-  for (int j = 0; j < W; j += 2) { double2 t; t.x = v[j]; t.y = v[j + 1]; *reinterpret_cast<double2*>(p + e + j) = t; }
+  for (int j = 0; j < W; j += 2) {
+    const vnt2d t = {v[j], v[j + 1]};
+    if (SDFS_VEC_NT & 2) __builtin_nontemporal_store(t, reinterpret_cast<vnt2d*>(p + e + j)); else *reinterpret_cast<vnt2d*>(p + e + j) = t;
+  }
 }
 template <int W>
 __device__ __forceinline__ void stv(float* __restrict__ p, long long e, const double (&v)[W]) {
   static_assert(W == 4, "float packets hold four elements");
-  float4 t; t.x = (float)v[0]; t.y = (float)v[1]; t.z = (float)v[2]; t.w = (float)v[3];
-  *reinterpret_cast<float4*>(p + e) = t;
+  const vnt4f t = {(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+  if (SDFS_VEC_NT_F32 & 2) __builtin_nontemporal_store(t, reinterpret_cast<vnt4f*>(p + e)); else *reinterpret_cast<vnt4f*>(p + e) = t;
 }
 template <int W>
 __device__ __forceinline__ void ldv(const bf16r* __restrict__ p, long long e, double (&v)[W]) {
