@@ -148,8 +148,10 @@ def newton_roofline(op, w_host, N, krylov_f32, inner=1e-6):
     # s update 3, x / r update 7; <t, s> and <t, t> come out of J.v's last pass) = 34; with the p and s updates in J.v's
     # first pass and <rhat, q> in its last (csrc/krylov_kernels.hpp) 6 + 2 + 5, 5 + 2 + 4 and the x / r update's 7 = 31
     s64, b64 = (31, 7) if fused else (34, 16)
-    it_bytes_sum = (it64 * s64 * 8.0 + (iters - it64) * 34 * 4.0) * N
-    b1_bytes_sum = (it64 * b64 * 8.0 + (iters - it64) * 16 * 4.0) * N
+    fused32 = any(c["name"].startswith("jvpm32+") for c in cs)       # (the same on the fp32-MFMA first pass)
+    s32, b32 = (31, 7) if fused32 else (34, 16)
+    it_bytes_sum = (it64 * s64 * 8.0 + (iters - it64) * s32 * 4.0) * N
+    b1_bytes_sum = (it64 * b64 * 8.0 + (iters - it64) * b32 * 4.0) * N
     out = {"kernels": [], "newton_steps": n, "bicgstab_iterations": iters, "bicgstab_iterations_fp64": it64,
            "updates_fused_into_jvp": fused}
     t_jv = t_b1 = 0.0

@@ -194,10 +194,12 @@ int sdfs_solve_dev(sdfs_handle* h, int algo, const sdfs_opts* opts, double* w_in
 int64_t sdfs_error_trace(sdfs_handle* h, double* out, int64_t cap);
 
 /* Multi-GPU building block: run the local kernels of one operator application.
- * stage 0: everything that needs no other rank's data (input sharded on axis_a);
- * stage 1: after the grid re-shard (input sharded on axis_b): the axis_a contraction
- * and the aggregator.  `mode` 0 = T, 1 = JVP (uses the cached linearisation),
- * 2 = T + linearise. */
+ * stage 0: contractions that need no other rank's data (input sharded on axis_a);
+ * stage 1: after the grid re-shard (input sharded on axis_b): the contractions left over -- axis_a among them -- and the
+ * aggregator.  Which complete axes are contracted in which stage is the library's choice (the expectation is a Kronecker
+ * product, the order is free: 6-D grids of the compile-time pair plan leave axis_a's partner axis to stage 1, so that both
+ * stages run that plan's kernels), so what stage 0 writes is an intermediate only the same handle's stage 1 understands.
+ * `mode` 0 = T, 1 = JVP (uses the cached linearisation), 2 = T + linearise. */
 int sdfs_apply_stage_dev(sdfs_handle* h, int stage, int mode, const double* in_dev,
                          double* out_dev, const double* w_old_dev, double* resid_dev);
 

@@ -190,7 +190,10 @@ template <int N, int R> struct Line32Geo {
 };
 inline size_t line32_lds_bytes(int n, int r) { return (size_t)n * n * r * 4; }
 
-template <int N, int MODE, int R>
+// DOT3: the last pass also sums <out, io.dot_with> (fused BiCGSTAB iteration, krylov_kernels.hpp).  A variant of its own:
+// the third side stream takes the 64-byte-row kernel from 52 to 112 VGPRs and from six to four workgroups per CU (229 ->
+// 300 us at GCY 20^6), which the other application of an iteration -- no third sum -- need not pay.
+template <int N, int MODE, int R, bool DOT3 = false>
 __global__ void __launch_bounds__(256, ((MODE == L_JLAST && Line32Geo<N, R>::OCC > 4) ? 4 : Line32Geo<N, R>::OCC))   // (the last pass holds two side streams)
 line32_kernel(const LineDesc P, const LineIO io) {
   using Geo = Line32Geo<N, R>;
@@ -245,12 +248,17 @@ line32_kernel(const LineDesc P, const LineIO io) {
   // them where both would not fit the register budget (R = 32: thirteen quads per stream)
   constexpr bool C2_EARLY = EPT4 <= 8;
   v4f c2v[MUL ? EPT4 : 1], oldv[MUL ? EPT4 : 1];
+  static_assert(!DOT3 || MUL, "the third sum belongs to the last pass");
+  constexpr bool dot3 = DOT3;
+  const char* const rwb = reinterpret_cast<const char*>(reinterpret_cast<const float*>(DOT3 ? io.dot_with : nullptr) + tbase);
+  v4f rwv[(DOT3 && C2_EARLY) ? EPT4 : 1];
   if (MUL) {
 #pragma unroll
     for (int k = 0; k < EPT4; ++k) {
       const bool rowok = !PART4 || tid + k * B < Geo::UNITS4;
       if (C2_EARLY) c2v[MUL ? k : 0] = ldrow(auxb + (rowok ? b0 + k * bstep : b0));
       if (need_old) oldv[MUL ? k : 0] = ldrow(oldb + (rowok ? b0 + k * bstep : b0));
+      if (C2_EARLY && dot3) rwv[(DOT3 && C2_EARLY) ? k : 0] = ldrow(rwb + (rowok ? b0 + k * bstep : b0));
     }
   }
   __syncthreads();
@@ -275,7 +283,10 @@ line32_kernel(const LineDesc P, const LineIO io) {
       c2v[MUL ? k : 0] = ldrow(auxb + (rowok ? b0 + k * bstep : b0));
     }
   }
-  double dot_yv = 0.0, dot_yy = 0.0;
+  // third sum of the fused BiCGSTAB iteration (krylov_kernels.hpp): <out, dot_with>.  Its stream was fetched with the other
+  // side streams where all three fit the register budget (the 64-byte-row tiles: fetching it behind the contractions cost
+  // the last pass 229 -> 298 us at GCY 20^6); on the 128-byte-row tiles it is read unit by unit here
+  double dot_yv = 0.0, dot_yy = 0.0, dot_yr = 0.0;
 #pragma unroll
   for (int k = 0; k < EPT4; ++k) {
     const int u = tid + k * B;
@@ -292,20 +303,26 @@ line32_kernel(const LineDesc P, const LineIO io) {
             dot_yy = fma((double)y[j], (double)y[j], dot_yy);
           }
         }
+        if (dot3) {
+          const v4f rw = C2_EARLY ? rwv[(DOT3 && C2_EARLY) ? k : 0] : ldrow(rwb + (b0 + k * bstep));
+#pragma unroll
+          for (int j = 0; j < 4; ++j) dot_yr = fma((double)y[j], (double)rw[j], dot_yr);
+        }
       }
       *reinterpret_cast<v4f*>(outb + (b0 + k * bstep)) = y;
     }
   }
   if (MUL && io.dotp != nullptr) {
 #pragma unroll
-    for (int s = 32; s > 0; s >>= 1) { dot_yv += __shfl_xor(dot_yv, s); dot_yy += __shfl_xor(dot_yy, s); }
-    if (lane == 0) { red4[wave] = dot_yv; red4[8 + wave] = dot_yy; }
+    for (int s = 32; s > 0; s >>= 1) { dot_yv += __shfl_xor(dot_yv, s); dot_yy += __shfl_xor(dot_yy, s); dot_yr += __shfl_xor(dot_yr, s); }
+    if (lane == 0) { red4[wave] = dot_yv; red4[4 + wave] = dot_yy; red4[8 + wave] = dot_yr; }
     __syncthreads();
     if (tid == 0) {
-      double a = 0.0, b = 0.0;
-      for (int w = 0; w < Geo::W; ++w) { a += red4[w]; b += red4[8 + w]; }
+      double a = 0.0, b = 0.0, c = 0.0;
+      for (int w = 0; w < Geo::W; ++w) { a += red4[w]; b += red4[4 + w]; c += red4[8 + w]; }
       io.dotp[blockIdx.x] = a;
       io.dotp[gridDim.x + blockIdx.x] = b;
+      if (dot3) io.dotp[2 * gridDim.x + blockIdx.x] = c;
     }
   }
 }
@@ -321,19 +338,21 @@ inline slice_fn slice32_variant(int n) {
   }
 }
 // r: row length in floats (line32_row_floats)
-template <int N, int R> inline line_fn line32_variant_nr(int mode) {
-  return mode == L_MID ? (line_fn)line32_kernel<N, L_MID, R> : (mode == L_JLAST ? (line_fn)line32_kernel<N, L_JLAST, R> : nullptr);
+template <int N, int R> inline line_fn line32_variant_nr(int mode, bool dot3) {
+  if (mode == L_JLAST) return dot3 ? (line_fn)line32_kernel<N, L_JLAST, R, true> : (line_fn)line32_kernel<N, L_JLAST, R, false>;
+  return mode == L_MID ? (line_fn)line32_kernel<N, L_MID, R> : nullptr;
 }
-template <int N> inline line_fn line32_variant_n(int mode, int r) {
-  if constexpr (N <= 24) { if (r == 32) return line32_variant_nr<N, 32>(mode); }      // (32 x 32 x 32 floats would be 128 KB)
-  return r == 16 ? line32_variant_nr<N, 16>(mode) : nullptr;
+template <int N> inline line_fn line32_variant_n(int mode, int r, bool dot3) {
+  if constexpr (N <= 24) { if (r == 32) return line32_variant_nr<N, 32>(mode, dot3); }      // (32 x 32 x 32 floats would be 128 KB)
+  return r == 16 ? line32_variant_nr<N, 16>(mode, dot3) : nullptr;
 }
-inline line_fn line32_variant(int n, int mode, int r) {
+// dot3: the last pass with the third sum <out, LineIO::dot_with>
+inline line_fn line32_variant(int n, int mode, int r, bool dot3 = false) {
   switch (n) {
-    case 16: return line32_variant_n<16>(mode, r);
-    case 20: return line32_variant_n<20>(mode, r);
-    case 24: return line32_variant_n<24>(mode, r);
-    case 32: return line32_variant_n<32>(mode, r);
+    case 16: return line32_variant_n<16>(mode, r, dot3);
+    case 20: return line32_variant_n<20>(mode, r, dot3);
+    case 24: return line32_variant_n<24>(mode, r, dot3);
+    case 32: return line32_variant_n<32>(mode, r, dot3);
     default: return nullptr;
   }
 }

@@ -1450,8 +1450,15 @@ __global__ void __launch_bounds__(64) small_sa_finish(const double* part, int n,
 // CU instead of twelve; the last of the four column tiles repeats four columns).  Measured with the power routine and the
 // non-temporal streams of round 4: 0.231-0.233 against 0.240 ms (profiles/round4_kernel_bench.txt); the other roles keep
 // four slices (their streams and register sets differ).
+#ifndef SDFS_SLICE16_G
+#define SDFS_SLICE16_G 0
+#endif
+#ifndef SDFS_SLICE16_OCC
+#define SDFS_SLICE16_OCC 3
+#endif
 template <int N> struct SliceTFirst { static constexpr int G = 0, OCC = 3; };
 template <> struct SliceTFirst<20> { static constexpr int G = 3, OCC = 4; };
+template <> struct SliceTFirst<16> { static constexpr int G = SDFS_SLICE16_G, OCC = SDFS_SLICE16_OCC; };
 typedef void (*small_fn)(const SmallDesc, const SmallIO);
 typedef void (*small_and_fn)(const SmallDesc, const SmallIO, const AndArgs);
 typedef void (*slice_fn)(const SliceDesc, const SliceIO);
@@ -1553,6 +1560,7 @@ inline line_fn line_variant(int n, int mode, bool persist, bool fullc, bool f32 
 // slices per wave tile / LDS bytes per workgroup of slice_variant(n, mode)
 inline int slice_tile_slices(int n, int mode) {
   if (mode == S_TFIRST && n == 20) return SliceTFirst<20>::G;
+  if (mode == S_TFIRST && n == 16 && SliceTFirst<16>::G) return SliceTFirst<16>::G;
   return n == 16 ? SliceGeo<16>::G : n == 20 ? SliceGeo<20>::G : n == 24 ? SliceGeo<24>::G : SliceGeo<32>::G;
 }
 inline size_t slice_lds_bytes(int n, int mode) { return (size_t)slice_tile_slices(n, mode) * n * (n == 20 ? n : n + 2) * 8 * 4; }

@@ -13,6 +13,7 @@
 // 31 streams per iteration instead of 34, the same arithmetic (the sums are added in another order).
 // fp64 Krylov storage on the compile-time pair plan; the other plans and the fp32 forms keep the separate kernels.
 #pragma once
+#include "f32_kernels.hpp"
 #include "stream_kernels.hpp"
 #include "vec_kernels.hpp"
 
@@ -136,10 +137,150 @@ slice_jfused_kernel(const SliceDesc P, const JFusedIO io) {
   }
 }
 
+// The same on the fp32-MFMA first pass (opts.krylov_f32 = 3, f32_kernels.hpp): Krylov vectors, c1 and the pass's output are
+// floats; the update is formed in fp64 and rounded to the stored float, <s, s> is summed in fp64 from the rounded values --
+// what k_bicg_update_p<float> / k_bicg_s<float> do -- and the product with c1 is the fp32 one of slice32_kernel.  Here the
+// separate BLAS-1 kernels are 47 % of an iteration (they run at 4.4-4.5 TB/s, the fused passes at the first pass's 5.7).
+struct JFused32IO {
+  float* upd; const float* a; const float* q; const float* c1; float* out;
+  const double* sc; double* dot; const unsigned long long* gate;
+};
+
+template <int N, int KIND>
+__global__ void __launch_bounds__(256, 4)
+slice32_jfused_kernel(const SliceDesc P, const JFused32IO io) {
+  using Geo = Slice32Geo<N>;
+  constexpr int BU = 2;                                            // float4 units per batch (two batches in flight)
+  constexpr int NB = (Geo::EPT4 + BU - 1) / BU;
+  extern __shared__ double lds_[];
+  float* const lds = reinterpret_cast<float*>(lds_);
+  SDFS_GATED(io.gate);
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const long long tile = (long long)blockIdx.x * Geo::WAVES + wave;
+  const long long s0 = tile * Geo::G;
+  if (s0 >= P.nslices) return;                                     // no workgroup barrier below
+  const long long rem = (P.nslices - s0) * (N * N / 4);
+  const int nvalid4 = rem < Geo::UNITS4 ? (int)rem : Geo::UNITS4;
+  float* const wl = lds + wave * Geo::LTILE;
+  auto lofs = [](const int e) -> int { return (e / N) * Geo::RS + (e % N); };
+  const long long gbase = s0 * (N * N);
+  const unsigned lb = (unsigned)lane * 16u;
+  char* const updb = reinterpret_cast<char*>(io.upd + gbase);
+  const char* const ab = reinterpret_cast<const char*>(io.a + gbase);
+  const char* const qb = reinterpret_cast<const char*>(io.q + gbase);
+  const char* const cb = reinterpret_cast<const char*>(io.c1 + gbase);
+  const double c_a = KIND == JF_P ? io.sc[SC_BETA] : io.sc[SC_ALPHA];
+  const double c_b = KIND == JF_P ? io.sc[SC_OMEGA] : 0.0;
+  struct Unit { v4f u, a, q, c; };
+  auto load = [&](Unit (&B)[BU], const int b) {
+#pragma unroll
+    for (int j = 0; j < BU; ++j) {
+      const int k = b * BU + j;
+      const unsigned off = (k < Geo::EPT4 && lane + 64 * k < nvalid4) ? lb + 1024u * k : lb;      // (as slice32_kernel: unit 0 again)
+      B[j].u = *reinterpret_cast<const v4f*>(updb + off);
+      if (KIND == JF_P) B[j].a = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(ab + off));
+      B[j].q = *reinterpret_cast<const v4f*>(qb + off);
+      B[j].c = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(cb + off));
+    }
+  };
+  double ss = 0.0;
+  auto work = [&](const Unit (&B)[BU], const int b) {
+#pragma unroll
+    for (int j = 0; j < BU; ++j) {
+      const int k = b * BU + j;
+      if (k >= Geo::EPT4) continue;
+      const int u = lane + 64 * k;
+      v4f nv;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const double d = KIND == JF_P ? (double)B[j].a[e] + c_a * ((double)B[j].u[e] - c_b * (double)B[j].q[e])     // p = r + beta (p - omega q)
+                                      : (double)B[j].u[e] - c_a * (double)B[j].q[e];                               // s = r - alpha q
+        nv[e] = (float)d;
+      }
+      if (u < nvalid4) {
+        *reinterpret_cast<v4f*>(updb + (lb + 1024u * k)) = nv;
+        if (KIND == JF_S) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) ss = fma((double)nv[e], (double)nv[e], ss);
+        }
+      }
+      if (Geo::UNITS4 % 64 == 0 || u < Geo::UNITS4) {
+        const v4f x = nv * B[j].c;
+        float* const pl = wl + lofs(4 * u);
+        *reinterpret_cast<v2f*>(pl) = (v2f){x.x, x.y};
+        *reinterpret_cast<v2f*>(pl + 2) = (v2f){x.z, x.w};
+      }
+    }
+  };
+  {
+    Unit B0[BU], B1[BU];
+    load(B0, 0);
+#pragma unroll
+    for (int b = 0; b < NB; b += 2) {
+      if (b + 1 < NB) load(B1, b + 1);
+      work(B0, b);
+      if (b + 2 < NB) load(B0, b + 2);
+      if (b + 1 < NB) work(B1, b + 1);
+    }
+  }
+  if (KIND == JF_S) {
+    ss = wave_sum(ss);
+    if (lane == 0) io.dot[tile] = ss;
+  }
+  QFrag32<N> qf;
+  qf.load(P.Qf, lane);
+  wave_lds_fence();
+  const int li = lane & 15, lk = lane >> 4;
+#pragma unroll
+  for (int ct = 0; ct < Geo::NCT; ++ct) {
+    const bool rep = Geo::CPAD > 0 && ct == Geo::NCT - 1;
+    ctile32<N, 1>(wl + (ct * 16 + li - ((rep && li >= 16 - Geo::CPAD) ? Geo::CPAD : 0)) * Geo::RS, lk, qf);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  wave_lds_fence();
+  {
+    QFrag32<N> qe;
+    qe.load(P.Qe, lane);
+#pragma unroll
+    for (int ct = 0; ct < Geo::NCT; ++ct) {
+      const bool rep = Geo::CPAD > 0 && ct == Geo::NCT - 1;
+      const int c = 16 * ct + li - ((rep && li >= 16 - Geo::CPAD) ? Geo::CPAD : 0);
+      const int g = c / N, f = c - g * N;
+      ctile32<N, Geo::RS>(wl + g * (N * Geo::RS) + f, lk, qe);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  wave_lds_fence();
+  char* const outb = reinterpret_cast<char*>(io.out + gbase);
+#pragma unroll
+  for (int k = 0; k < Geo::EPT4; ++k) {
+    const int u = lane + 64 * k;
+    if (u < nvalid4) {
+      const float* const pl = wl + lofs(4 * u);
+      const v2f a = *reinterpret_cast<const v2f*>(pl), b = *reinterpret_cast<const v2f*>(pl + 2);
+      *reinterpret_cast<v4f*>(outb + (lb + 1024u * k)) = (v4f){a.x, a.y, b.x, b.y};
+    }
+  }
+}
+
+typedef void (*jfused32_fn)(const SliceDesc, const JFused32IO);
 typedef void (*jfused_fn)(const SliceDesc, const JFusedIO);
 #ifndef SDFS_NO_VARIANT_TABLES
 template <int N> inline jfused_fn slice_jfused_variant_n(int kind) {
   return kind == JF_P ? (jfused_fn)slice_jfused_kernel<N, JF_P> : (jfused_fn)slice_jfused_kernel<N, JF_S>;
+}
+template <int N> inline jfused32_fn slice32_jfused_variant_n(int kind) {
+  return kind == JF_P ? (jfused32_fn)slice32_jfused_kernel<N, JF_P> : (jfused32_fn)slice32_jfused_kernel<N, JF_S>;
+}
+inline jfused32_fn slice32_jfused_variant(int n, int kind) {
+  switch (n) {
+    case 16: return slice32_jfused_variant_n<16>(kind);
+    case 20: return slice32_jfused_variant_n<20>(kind);
+    case 24: return slice32_jfused_variant_n<24>(kind);
+    case 32: return slice32_jfused_variant_n<32>(kind);
+    default: return nullptr;
+  }
 }
 inline jfused_fn slice_jfused_variant(int n, int kind) {
   switch (n) {

@@ -868,8 +868,8 @@ int prepare_fast_passes(sdfs_handle* h, std::vector<FastPass>& passes) {
       hipFuncSetAttribute((const void*)f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)line_lds_bytes(P.n));
       line_fn f32 = line_variant(P.n, m, false, true, true);
       if (f32) hipFuncSetAttribute((const void*)f32, hipFuncAttributeMaxDynamicSharedMemorySize, (int)line_lds_bytes(P.n));
-      for (int r32 = 16; r32 <= 32; r32 += 16)
-        if (line_fn m32 = line32_variant(P.n, m, r32)) hipFuncSetAttribute((const void*)m32, hipFuncAttributeMaxDynamicSharedMemorySize, (int)line32_lds_bytes(P.n, r32));
+      for (int r32 = 16; r32 <= 32; r32 += 16) for (int d3 = 0; d3 < 2; ++d3)
+        if (line_fn m32 = line32_variant(P.n, m, r32, d3 != 0)) hipFuncSetAttribute((const void*)m32, hipFuncAttributeMaxDynamicSharedMemorySize, (int)line32_lds_bytes(P.n, r32));
     }
   }
   if (!h->sched) {
@@ -1298,6 +1298,24 @@ int run_fast_plan(sdfs_handle* h, FastPlan& fp, long long nloc, bool has_first, 
         HIPCHK(h, hipGetLastError());
         continue;
       }
+      if (mode == MODE_JVP && !vjp && f32 && h->krylov_mfma32 && h->jf.active && h->jf.kind >= 0) {
+        // ... and on the fp32-MFMA first pass (vectors, c1 and the output are floats)
+        jfused32_fn jfn = slice32_jfused_variant(P.n, h->jf.kind);
+        if (!jfn) return fail(h, SDFS_ERR_UNSUPPORTED, "no fused fp32 first pass for this extent");
+        JFused32IO jio;
+        memset(&jio, 0, sizeof jio);
+        jio.upd = (float*)h->jf.upd; jio.a = (const float*)h->jf.a; jio.q = (const float*)h->jf.q; jio.c1 = (const float*)h->c1;
+        jio.out = (float*)pout; jio.sc = h->sc; jio.dot = h->jf.dot; jio.gate = gate;
+        bytes = 0.5 * (h->jf.kind == JF_P ? 6.0 : 5.0) * n8 + P.q_bytes;
+        int cid = -1;
+        if (h->profiling) { char nm[48]; snprintf(nm, sizeof nm, "jvpm32+%s:%s", h->jf.kind == JF_P ? "p" : "s", P.label.c_str()); cid = counter_id(h, nm, bytes, P.flops); }
+        const int gsl = slice32_tile_slices(P.n);
+        const long long ntile = (P.sd.nslices + gsl - 1) / gsl;
+        ProfScope ps(h, cid);
+        hipLaunchKernelGGL(jfn, dim3((unsigned)((ntile + 3) / 4)), dim3(256), slice32_lds_bytes(P.n), h->stream, P.sd, jio);
+        HIPCHK(h, hipGetLastError());
+        continue;
+      }
       // opts.krylov_f32 = 3: fp32 LDS tile + fp32 MFMA for the J.v passes (f32_kernels.hpp)
       const bool m32 = f32 && h->krylov_mfma32 && mode == MODE_JVP;
       slice_fn fn = m32 ? slice32_variant(P.n) : slice_variant(P.n, sm, f32);
@@ -1346,7 +1364,13 @@ int run_fast_plan(sdfs_handle* h, FastPlan& fp, long long nloc, bool has_first, 
       }
       const bool m32 = lf32 && h->krylov_mfma32 && mode == MODE_JVP && !t32;
       const int r32 = line32_row_floats(P.n, P.ld.lrest);
-      if (m32) { fn = line32_variant(P.n, lm, r32); grid = (unsigned)(d.ntiles * LINE_R / r32); }
+      if (m32) {
+        fn = line32_variant(P.n, lm, r32); grid = (unsigned)(d.ntiles * LINE_R / r32);
+        if (lm == L_JLAST && !vjp && h->jf.active) {
+          io.dot_with = h->jf.dot_with; bytes += n8;      // (halved below: the mean of the two applications)
+          if (io.dot_with) fn = line32_variant(P.n, lm, r32, true);
+        }
+      }
       if (!fn) return fail(h, SDFS_ERR_UNSUPPORTED, "no line kernel variant");
       if (f32 && mode == MODE_JVP) bytes *= 0.5;
       int cid = -1;
@@ -1816,23 +1840,35 @@ int bicgstab_dev_t(sdfs_handle* h, const sdfs_opts& o, int64_t* matvecs) {
       hipLaunchKernelGGL(k_bicg_iter_finish, dim3(1), dim3(VEC_BLOCK), 0, st, h->partial, g, h->sc, gate); }
     return 0;
   };
-  // Large grids on the compile-time pair plan, fp64 Krylov storage: the p and s updates on the registers of J.v's first
-  // pass, <rhat, q> in its last (krylov_kernels.hpp) -- 31 grid streams per iteration instead of 34
+  // Large grids on the compile-time pair plan: the p and s updates on the registers of J.v's first pass, <rhat, q> in its
+  // last (krylov_kernels.hpp) -- 31 grid streams per iteration instead of 34
   const FastPass* const P0 = (h->fast.ok && !h->fast.passes.empty()) ? &h->fast.passes.front() : nullptr;
   const FastPass* const PL = (h->fast.ok && !h->fast.passes.empty()) ? &h->fast.passes.back() : nullptr;
-  bool jfuse = std::is_same<T, double>::value && !merged && h->fast.ok && !h->fast.small && !h->fast.pad && !h->krylov_f32 &&
-               h->fast.passes.size() >= 2 && !P0->line && !P0->pad && PL->line && PL->ld.lrest % LINE_R == 0 &&
-               3 * PL->ld.ntiles <= (long long)MAX_PARTIAL_BLOCKS * AND_MAX_M && h->knobs.no_dot_fusion == 0;
+  // (fp64 storage on the fp64 kernels; fp32 storage on the fp32-MFMA kernels, opts.krylov_f32 = 3)
+#ifdef SDFS_NO_JF32      // (build-time probe: the fp32-MFMA loop with the separate BLAS-1 kernels)
+  const bool jf32 = false;
+#else
+  const bool jf32 = std::is_same<T, float>::value && h->krylov_f32 && h->krylov_mfma32 && !h->krylov_bf16 && h->fast.f32_ok;
+#endif
+  bool jfuse = ((std::is_same<T, double>::value && !h->krylov_f32) || jf32) && !merged && h->fast.ok && !h->fast.small && !h->fast.pad &&
+               h->fast.passes.size() >= 2 && !P0->line && !P0->pad && PL->line && PL->ld.lrest % LINE_R == 0 && h->knobs.no_dot_fusion == 0;
+  // workgroups of the last pass (one partial sum each per inner product), wave tiles of the first
+  const long long jf_last = jfuse ? (jf32 ? PL->ld.ntiles * LINE_R / line32_row_floats(PL->n, PL->ld.lrest) : PL->ld.ntiles) : 0;
+  if (3 * jf_last > (long long)MAX_PARTIAL_BLOCKS * AND_MAX_M) jfuse = false;
   long long jf_tiles0 = 0;
   if (jfuse) {
-    const int gsl = slice_tile_slices(P0->n, S_JFIRST);
+    const int gsl = jf32 ? slice32_tile_slices(P0->n) : slice_tile_slices(P0->n, S_JFIRST);
     jf_tiles0 = (P0->sd.nslices + gsl - 1) / gsl;
     if (h->jf_ss_n < jf_tiles0) {
       double* d = nullptr;
       if (hipMalloc((void**)&d, sizeof(double) * (size_t)jf_tiles0) != hipSuccess) jfuse = false;
       else { h->misc_allocs.push_back(d); h->jf_ss = d; h->jf_ss_n = jf_tiles0; }
     }
-    if (jfuse) {
+    if (jfuse && jf32) {
+      if (!slice32_jfused_variant(P0->n, JF_P)) jfuse = false;
+      else for (int kd : {(int)JF_P, (int)JF_S})
+        hipFuncSetAttribute((const void*)slice32_jfused_variant(P0->n, kd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)slice32_lds_bytes(P0->n));
+    } else if (jfuse) {
       hipFuncSetAttribute((const void*)slice_jfused_variant(P0->n, JF_P), hipFuncAttributeMaxDynamicSharedMemorySize, (int)slice_lds_bytes(P0->n, S_JFIRST));
       hipFuncSetAttribute((const void*)slice_jfused_variant(P0->n, JF_S), hipFuncAttributeMaxDynamicSharedMemorySize, (int)slice_lds_bytes(P0->n, S_JFIRST));
       hipFuncSetAttribute((const void*)line_stream_variant(PL->n, L_JLAST), hipFuncAttributeMaxDynamicSharedMemorySize, (int)line_lds_bytes(PL->n));
@@ -1841,7 +1877,7 @@ int bicgstab_dev_t(sdfs_handle* h, const sdfs_opts& o, int64_t* matvecs) {
   struct JfGuard { sdfs_handle* h; ~JfGuard() { h->jf.active = false; h->jf.kind = -1; h->jf.dot_with = nullptr; } } jf_guard{h};
   auto iteration_jfused = [&]() -> int {
     int rc2;
-    const int nt = (int)PL->ld.ntiles;
+    const int nt = (int)jf_last;
     double* const dp = h->partial;                       // [0, nt): <out, v>, [nt, 2 nt): <out, out>, [2 nt, 3 nt): <out, rhat>
     h->jf.active = true;
     // q = (J - I) p, p = r + beta (p - omega q) formed in the first pass, <rhat, q> summed by the last
@@ -1850,7 +1886,7 @@ int bicgstab_dev_t(sdfs_handle* h, const sdfs_opts& o, int64_t* matvecs) {
     h->jf.dot_with = nullptr;
     if (rc2) return rc2;
     { ProfScope ps(h, cvec);
-      hipLaunchKernelGGL(k_bicg_alpha_finish, dim3(1), dim3(VEC_BLOCK), 0, st, (const double*)(dp + 2 * (size_t)nt), nt, h->sc, (const unsigned long long*)gate); }
+      hipLaunchKernelGGL(k_bicg_alpha_finish, dim3(1), dim3(1024), 0, st, (const double*)(dp + 2 * (size_t)nt), nt, h->sc, (const unsigned long long*)gate); }
     // t = (J - I) s, s = r - alpha q (in r) and <s, s> formed in the first pass, <t, s> and <t, t> summed by the last
     h->jf.kind = JF_S; h->jf.upd = (double*)r; h->jf.a = nullptr; h->jf.q = (const double*)q; h->jf.dot = h->jf_ss;
     rc2 = run_plan(h, h->plan[0], MODE_JVP, true, true, (const double*)r, (double*)t, (const double*)r, nullptr, gate, 0.0, 1, dp);
@@ -1858,7 +1894,7 @@ int bicgstab_dev_t(sdfs_handle* h, const sdfs_opts& o, int64_t* matvecs) {
     if (rc2) return rc2;
     { ProfScope ps(h, cvec);
       hipLaunchKernelGGL(k_bicg_s_finish_wide, dim3(1), dim3(1024), 0, st, (const double*)h->jf_ss, (int)jf_tiles0, h->sc, (const unsigned long long*)gate);
-      hipLaunchKernelGGL(k_bicg_omega_finish, dim3(1), dim3(VEC_BLOCK), 0, st, (const double*)dp, nt, h->sc, (const unsigned long long*)gate);
+      hipLaunchKernelGGL(k_bicg_omega_finish, dim3(1), dim3(1024), 0, st, (const double*)dp, nt, h->sc, (const unsigned long long*)gate);
       hipLaunchKernelGGL(k_bicg_update_xr<T>, dim3(g), dim3(VEC_BLOCK), 0, st, x, r, (const T*)p, (const T*)t, (const T*)rhat, n, h->sc, h->partial, (const unsigned long long*)gate);
       hipLaunchKernelGGL(k_bicg_iter_finish, dim3(1), dim3(VEC_BLOCK), 0, st, h->partial, g, h->sc, gate); }
     return 0;

@@ -64,7 +64,7 @@ __device__ __forceinline__ void block_partials(const double (&v)[NV], double* __
 // nb <= 0: `partial` already holds the finished (multi-GPU: all-reduced) sums, one per stream
 __device__ __forceinline__ double finish_sum(const double* __restrict__ partial, int nb, int k) {
   if (nb <= 0) return partial[k];
-  __shared__ double sm[VEC_BLOCK / 64];
+  __shared__ double sm[16];                  // (up to 1024 threads: the finishing kernels of the fused iteration sum 10^4 partials)
   double s = 0.0;
   for (int i = threadIdx.x; i < nb; i += blockDim.x) s += partial[i + (size_t)k * nb];
   s = wave_sum(s);
@@ -133,42 +133,45 @@ struct bf16r {
 #ifndef SDFS_VEC_NT_F32
 #define SDFS_VEC_NT_F32 1
 #endif
+// ... on vectors beyond the L2-resident sizes only: at SSY 15^4 (405 KB vectors) the non-temporal packets cost the graph-
+// replayed Newton solve 3 % (13.5 against 13.0 ms)
+constexpr long long VEC_NT_MIN = 1LL << 22;
 typedef float vnt4f __attribute__((ext_vector_type(4)));
 typedef double vnt2d __attribute__((ext_vector_type(2)));
 template <int W>
-__device__ __forceinline__ void ldv(const double* __restrict__ p, long long e, double (&v)[W]) {
+__device__ __forceinline__ void ldv(const double* __restrict__ p, long long e, double (&v)[W], const bool nt) {
 #pragma unroll
   for (int j = 0; j < W; j += 2) {
-    const vnt2d t = (SDFS_VEC_NT & 1) ? __builtin_nontemporal_load(reinterpret_cast<const vnt2d*>(p + e + j)) : *reinterpret_cast<const vnt2d*>(p + e + j);
+    const vnt2d t = ((SDFS_VEC_NT & 1) && nt) ? __builtin_nontemporal_load(reinterpret_cast<const vnt2d*>(p + e + j)) : *reinterpret_cast<const vnt2d*>(p + e + j);
     v[j] = t.x; v[j + 1] = t.y;
   }
 }
 template <int W>
-__device__ __forceinline__ void ldv(const float* __restrict__ p, long long e, double (&v)[W]) {
+__device__ __forceinline__ void ldv(const float* __restrict__ p, long long e, double (&v)[W], const bool nt) {
   static_assert(W == 4, "float packets hold four elements");
-  const vnt4f t = (SDFS_VEC_NT_F32 & 1) ? __builtin_nontemporal_load(reinterpret_cast<const vnt4f*>(p + e)) : *reinterpret_cast<const vnt4f*>(p + e);
+  const vnt4f t = ((SDFS_VEC_NT_F32 & 1) && nt) ? __builtin_nontemporal_load(reinterpret_cast<const vnt4f*>(p + e)) : *reinterpret_cast<const vnt4f*>(p + e);
   v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
 }
 template <int W>
-__device__ __forceinline__ void stv(double* __restrict__ p, long long e, const double (&v)[W]) {
+__device__ __forceinline__ void stv(double* __restrict__ p, long long e, const double (&v)[W], const bool nt) {
 #pragma unroll
   for (int j = 0; j < W; j += 2) {
     const vnt2d t = {v[j], v[j + 1]};
-    if (SDFS_VEC_NT & 2) __builtin_nontemporal_store(t, reinterpret_cast<vnt2d*>(p + e + j)); else *reinterpret_cast<vnt2d*>(p + e + j) = t;
+    if ((SDFS_VEC_NT & 2) && nt) __builtin_nontemporal_store(t, reinterpret_cast<vnt2d*>(p + e + j)); else *reinterpret_cast<vnt2d*>(p + e + j) = t;
   }
 }
 template <int W>
-__device__ __forceinline__ void stv(float* __restrict__ p, long long e, const double (&v)[W]) {
+__device__ __forceinline__ void stv(float* __restrict__ p, long long e, const double (&v)[W], const bool nt) {
   static_assert(W == 4, "float packets hold four elements");
   const vnt4f t = {(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
-  if (SDFS_VEC_NT_F32 & 2) __builtin_nontemporal_store(t, reinterpret_cast<vnt4f*>(p + e)); else *reinterpret_cast<vnt4f*>(p + e) = t;
+  if ((SDFS_VEC_NT_F32 & 2) && nt) __builtin_nontemporal_store(t, reinterpret_cast<vnt4f*>(p + e)); else *reinterpret_cast<vnt4f*>(p + e) = t;
 }
 template <int W>
-__device__ __forceinline__ void ldv(const bf16r* __restrict__ p, long long e, double (&v)[W]) {
-  ldv<W>(reinterpret_cast<const float*>(p), e, v);
+__device__ __forceinline__ void ldv(const bf16r* __restrict__ p, long long e, double (&v)[W], const bool nt) {
+  ldv<W>(reinterpret_cast<const float*>(p), e, v, nt);
 }
 template <int W>
-__device__ __forceinline__ void stv(bf16r* __restrict__ p, long long e, const double (&v)[W]) {
+__device__ __forceinline__ void stv(bf16r* __restrict__ p, long long e, const double (&v)[W], const bool) {
   static_assert(W == 4, "float packets hold four elements");
   float4 t; t.x = round_bf16((float)v[0]); t.y = round_bf16((float)v[1]); t.z = round_bf16((float)v[2]); t.w = round_bf16((float)v[3]);
   *reinterpret_cast<float4*>(p + e) = t;
@@ -181,32 +184,33 @@ __device__ __forceinline__ void stv(bf16r* __restrict__ p, long long e, const do
     const long long gid_ = (long long)blockIdx.x * VEC_BLOCK + threadIdx.x;                 \
     const long long str_ = (long long)gridDim.x * VEC_BLOCK;                                \
     const long long np_ = (n) / W;                                                          \
+    const bool nt_ = (n) > VEC_NT_MIN;                                                      \
     for (long long ip_ = gid_; ip_ < np_; ip_ += str_) { const long long e = ip_ * W; BODY(W) } \
     for (long long e = np_ * W + gid_; e < (n); e += str_) { BODY(1) }                      \
   }
 template <int W>
-__device__ __forceinline__ void LDx(const double* __restrict__ p, long long e, double (&v)[W]) {
-  if constexpr (W == 1) v[0] = p[e]; else ldv<W>(p, e, v);
+__device__ __forceinline__ void LDx(const double* __restrict__ p, long long e, double (&v)[W], const bool nt) {
+  if constexpr (W == 1) v[0] = p[e]; else ldv<W>(p, e, v, nt);
 }
 template <int W>
-__device__ __forceinline__ void LDx(const float* __restrict__ p, long long e, double (&v)[W]) {
-  if constexpr (W == 1) v[0] = (double)p[e]; else ldv<W>(p, e, v);
+__device__ __forceinline__ void LDx(const float* __restrict__ p, long long e, double (&v)[W], const bool nt) {
+  if constexpr (W == 1) v[0] = (double)p[e]; else ldv<W>(p, e, v, nt);
 }
 template <int W>
-__device__ __forceinline__ void STx(double* __restrict__ p, long long e, const double (&v)[W]) {
-  if constexpr (W == 1) p[e] = v[0]; else stv<W>(p, e, v);
+__device__ __forceinline__ void STx(double* __restrict__ p, long long e, const double (&v)[W], const bool nt) {
+  if constexpr (W == 1) p[e] = v[0]; else stv<W>(p, e, v, nt);
 }
 template <int W>
-__device__ __forceinline__ void STx(float* __restrict__ p, long long e, const double (&v)[W]) {
-  if constexpr (W == 1) p[e] = (float)v[0]; else stv<W>(p, e, v);
+__device__ __forceinline__ void STx(float* __restrict__ p, long long e, const double (&v)[W], const bool nt) {
+  if constexpr (W == 1) p[e] = (float)v[0]; else stv<W>(p, e, v, nt);
 }
 template <int W>
-__device__ __forceinline__ void LDx(const bf16r* __restrict__ p, long long e, double (&v)[W]) {
-  LDx<W>(reinterpret_cast<const float*>(p), e, v);
+__device__ __forceinline__ void LDx(const bf16r* __restrict__ p, long long e, double (&v)[W], const bool nt) {
+  LDx<W>(reinterpret_cast<const float*>(p), e, v, nt);
 }
 template <int W>
-__device__ __forceinline__ void STx(bf16r* __restrict__ p, long long e, const double (&v)[W]) {
-  if constexpr (W == 1) p[e].v = round_bf16((float)v[0]); else stv<W>(p, e, v);
+__device__ __forceinline__ void STx(bf16r* __restrict__ p, long long e, const double (&v)[W], const bool nt) {
+  if constexpr (W == 1) p[e].v = round_bf16((float)v[0]); else stv<W>(p, e, v, nt);
 }
 // the J.v kernels write fp32 streams: under bf16r emulation their output is rounded by a launch of its own
 __global__ void __launch_bounds__(256) k_round_bf16(float* __restrict__ p, long long n, const unsigned long long* __restrict__ gate) {
@@ -227,8 +231,8 @@ template <typename T>
 __global__ void __launch_bounds__(VEC_BLOCK)
 k_bicg_init(const double* __restrict__ b, T* __restrict__ r, T* __restrict__ rhat,
             T* __restrict__ p, T* __restrict__ q, T* __restrict__ x, long long n) {
-#define BODY(W_) { double v[W_], z[W_]; LDx<W_>(b, e, v); _Pragma("unroll") for (int j = 0; j < W_; ++j) z[j] = 0.0; \
-                   STx<W_>(r, e, v); STx<W_>(rhat, e, v); STx<W_>(p, e, v); STx<W_>(q, e, v); STx<W_>(x, e, z); }
+#define BODY(W_) { double v[W_], z[W_]; LDx<W_>(b, e, v, nt_); _Pragma("unroll") for (int j = 0; j < W_; ++j) z[j] = 0.0; \
+                   STx<W_>(r, e, v, nt_); STx<W_>(rhat, e, v, nt_); STx<W_>(p, e, v, nt_); STx<W_>(q, e, v, nt_); STx<W_>(x, e, z, nt_); }
   SDFS_PACKET_LOOP(T, n, BODY)
 #undef BODY
 }
@@ -240,7 +244,7 @@ k_dot(const T* __restrict__ a, const T* __restrict__ b, long long n, double* __r
       const unsigned long long* gate = nullptr) {
   SDFS_GATED(gate);
   double acc[1] = {0.0};
-#define BODY(W_) { double x_[W_], y_[W_]; LDx<W_>(a, e, x_); LDx<W_>(b, e, y_); \
+#define BODY(W_) { double x_[W_], y_[W_]; LDx<W_>(a, e, x_, nt_); LDx<W_>(b, e, y_, nt_); \
                    _Pragma("unroll") for (int j = 0; j < W_; ++j) acc[0] += x_[j] * y_[j]; }
   SDFS_PACKET_LOOP(T, n, BODY)
 #undef BODY
@@ -274,15 +278,15 @@ k_bicg_update_p(const T* __restrict__ r, T* __restrict__ p, const T* __restrict_
                 long long n, const double* __restrict__ sc, const unsigned long long* gate = nullptr) {
   SDFS_GATED(gate);
   const double beta = sc[SC_BETA], omega = sc[SC_OMEGA];
-#define BODY(W_) { double r_[W_], p_[W_], q_[W_]; LDx<W_>(r, e, r_); LDx<W_>((const T*)p, e, p_); LDx<W_>(q, e, q_); \
+#define BODY(W_) { double r_[W_], p_[W_], q_[W_]; LDx<W_>(r, e, r_, nt_); LDx<W_>((const T*)p, e, p_, nt_); LDx<W_>(q, e, q_, nt_); \
                    _Pragma("unroll") for (int j = 0; j < W_; ++j) p_[j] = r_[j] + beta * (p_[j] - omega * q_[j]); \
-                   STx<W_>(p, e, p_); }
+                   STx<W_>(p, e, p_, nt_); }
   SDFS_PACKET_LOOP(T, n, BODY)
 #undef BODY
 }
 
 // alpha = rho_new / <rhat, q>
-__global__ void __launch_bounds__(VEC_BLOCK)
+__global__ void __launch_bounds__(1024)
 k_bicg_alpha_finish(const double* __restrict__ partial, int nb, double* __restrict__ sc,
                     const unsigned long long* gate = nullptr) {
   SDFS_GATED(gate);
@@ -298,9 +302,9 @@ k_bicg_s(T* __restrict__ r, const T* __restrict__ q, long long n,
   SDFS_GATED(gate);
   const double alpha = sc[SC_ALPHA];
   double acc[1] = {0.0};
-#define BODY(W_) { double r_[W_], q_[W_]; LDx<W_>((const T*)r, e, r_); LDx<W_>(q, e, q_); \
+#define BODY(W_) { double r_[W_], q_[W_]; LDx<W_>((const T*)r, e, r_, nt_); LDx<W_>(q, e, q_, nt_); \
                    _Pragma("unroll") for (int j = 0; j < W_; ++j) { const double s = (double)(T)(r_[j] - alpha * q_[j]); r_[j] = s; acc[0] += s * s; } \
-                   STx<W_>(r, e, r_); }
+                   STx<W_>(r, e, r_, nt_); }
   SDFS_PACKET_LOOP(T, n, BODY)
 #undef BODY
   block_partials<1>(acc, partial);
@@ -339,14 +343,14 @@ k_dot2(const T* __restrict__ t, const T* __restrict__ s, long long n, double* __
        const unsigned long long* gate = nullptr) {
   SDFS_GATED(gate);
   double acc[2] = {0.0, 0.0};
-#define BODY(W_) { double t_[W_], s_[W_]; LDx<W_>(t, e, t_); LDx<W_>(s, e, s_); \
+#define BODY(W_) { double t_[W_], s_[W_]; LDx<W_>(t, e, t_, nt_); LDx<W_>(s, e, s_, nt_); \
                    _Pragma("unroll") for (int j = 0; j < W_; ++j) { acc[0] += t_[j] * s_[j]; acc[1] += t_[j] * t_[j]; } }
   SDFS_PACKET_LOOP(T, n, BODY)
 #undef BODY
   block_partials<2>(acc, partial);
 }
 
-__global__ void __launch_bounds__(VEC_BLOCK)
+__global__ void __launch_bounds__(1024)
 k_bicg_omega_finish(const double* __restrict__ partial, int nb, double* __restrict__ sc,
                     const unsigned long long* gate = nullptr) {
   SDFS_GATED(gate);
@@ -367,14 +371,14 @@ k_bicg_update_xr(T* __restrict__ x, T* __restrict__ r, const T* __restrict__ p,
   const bool early = sc[SC_EARLY] != 0.0;
   const double omega = early ? 0.0 : sc[SC_OMEGA];
   double acc[2] = {0.0, 0.0};
-#define BODY(W_) { double x_[W_], r_[W_], p_[W_], t_[W_], h_[W_]; LDx<W_>((const T*)x, e, x_); LDx<W_>((const T*)r, e, r_); \
-                   LDx<W_>(p, e, p_); LDx<W_>(t, e, t_); LDx<W_>(rhat, e, h_); \
+#define BODY(W_) { double x_[W_], r_[W_], p_[W_], t_[W_], h_[W_]; LDx<W_>((const T*)x, e, x_, nt_); LDx<W_>((const T*)r, e, r_, nt_); \
+                   LDx<W_>(p, e, p_, nt_); LDx<W_>(t, e, t_, nt_); LDx<W_>(rhat, e, h_, nt_); \
                    _Pragma("unroll") for (int j = 0; j < W_; ++j) { \
                      const double s = r_[j]; \
                      const double rn = (double)(T)(early ? s : s - omega * t_[j]); \
                      x_[j] = x_[j] + alpha * p_[j] + omega * s; r_[j] = rn; \
                      acc[0] += rn * rn; acc[1] += h_[j] * rn; } \
-                   STx<W_>(x, e, x_); STx<W_>(r, e, r_); }
+                   STx<W_>(x, e, x_, nt_); STx<W_>(r, e, r_, nt_); }
   SDFS_PACKET_LOOP(T, n, BODY)
 #undef BODY
   block_partials<2>(acc, partial);
@@ -417,9 +421,9 @@ k_bicg_s_m(T* __restrict__ r, const T* __restrict__ q, long long n, double* __re
   const double alpha = sc[SC_RHO_NEW] / d;
   if (blockIdx.x == 0 && threadIdx.x == 0) { sc[SC_RHAT_Q] = d; sc[SC_ALPHA] = alpha; }
   double acc[1] = {0.0};
-#define BODY(W_) { double r_[W_], q_[W_]; LDx<W_>((const T*)r, e, r_); LDx<W_>(q, e, q_); \
+#define BODY(W_) { double r_[W_], q_[W_]; LDx<W_>((const T*)r, e, r_, nt_); LDx<W_>(q, e, q_, nt_); \
                    _Pragma("unroll") for (int j = 0; j < W_; ++j) { const double s = (double)(T)(r_[j] - alpha * q_[j]); r_[j] = s; acc[0] += s * s; } \
-                   STx<W_>(r, e, r_); }
+                   STx<W_>(r, e, r_, nt_); }
   SDFS_PACKET_LOOP(T, n, BODY)
 #undef BODY
   block_partials<1>(acc, pss);
@@ -444,14 +448,14 @@ k_bicg_update_xr_m(T* __restrict__ x, T* __restrict__ r, const T* __restrict__ p
   }
   const double omega = early ? 0.0 : omega_full;
   double acc[2] = {0.0, 0.0};
-#define BODY(W_) { double x_[W_], r_[W_], p_[W_], t_[W_], h_[W_]; LDx<W_>((const T*)x, e, x_); LDx<W_>((const T*)r, e, r_); \
-                   LDx<W_>(p, e, p_); LDx<W_>(t, e, t_); LDx<W_>(rhat, e, h_); \
+#define BODY(W_) { double x_[W_], r_[W_], p_[W_], t_[W_], h_[W_]; LDx<W_>((const T*)x, e, x_, nt_); LDx<W_>((const T*)r, e, r_, nt_); \
+                   LDx<W_>(p, e, p_, nt_); LDx<W_>(t, e, t_, nt_); LDx<W_>(rhat, e, h_, nt_); \
                    _Pragma("unroll") for (int j = 0; j < W_; ++j) { \
                      const double s = r_[j]; \
                      const double rn = (double)(T)(early ? s : s - omega * t_[j]); \
                      x_[j] = x_[j] + alpha * p_[j] + omega * s; r_[j] = rn; \
                      acc[0] += rn * rn; acc[1] += h_[j] * rn; } \
-                   STx<W_>(x, e, x_); STx<W_>(r, e, r_); }
+                   STx<W_>(x, e, x_, nt_); STx<W_>(r, e, r_, nt_); }
   SDFS_PACKET_LOOP(T, n, BODY)
 #undef BODY
   block_partials<2>(acc, prr);
@@ -495,10 +499,10 @@ k_and_push(const double* __restrict__ x, const double* __restrict__ fx, AndPtrs 
   for (int j = 0; j < AND_MAX_M; ++j) acc[j] = 0.0;
   // every history stream is requested before the first one is used (a load inside the branch that consumes it
   // would cost one memory round trip per stream)
-#define BODY(W_) { double x_[W_], f_[W_], r_[W_], o_[AND_MAX_M][W_]; LDx<W_>(x, e, x_); LDx<W_>(fx, e, f_); \
-                   _Pragma("unroll") for (int j = 0; j < AND_MAX_M; ++j) { if (j < m && j != pos) LDx<W_>((const double*)h.R[j], e, o_[j]); } \
+#define BODY(W_) { double x_[W_], f_[W_], r_[W_], o_[AND_MAX_M][W_]; LDx<W_>(x, e, x_, nt_); LDx<W_>(fx, e, f_, nt_); \
+                   _Pragma("unroll") for (int j = 0; j < AND_MAX_M; ++j) { if (j < m && j != pos) LDx<W_>((const double*)h.R[j], e, o_[j], nt_); } \
                    _Pragma("unroll") for (int q = 0; q < W_; ++q) r_[q] = f_[q] - x_[q]; \
-                   STx<W_>(h.X[pos], e, x_); STx<W_>(h.R[pos], e, r_); \
+                   STx<W_>(h.X[pos], e, x_, nt_); STx<W_>(h.R[pos], e, r_, nt_); \
                    _Pragma("unroll") for (int j = 0; j < AND_MAX_M; ++j) { \
                      if (j < m) { \
                        if (j == pos) { _Pragma("unroll") for (int q = 0; q < W_; ++q) acc[j] += r_[q] * r_[q]; } \
@@ -532,10 +536,10 @@ k_and_mix(AndPtrs h, AndCoef c, int m, double beta, double* __restrict__ xnext, 
 #define BODY(W_) { double xa[W_], ra[W_]; \
                    _Pragma("unroll") for (int q = 0; q < W_; ++q) { xa[q] = 0.0; ra[q] = 0.0; } \
                    _Pragma("unroll") for (int j = 0; j < AND_MAX_M; ++j) { \
-                     if (j < m) { double x_[W_], r_[W_]; LDx<W_>((const double*)h.X[j], e, x_); LDx<W_>((const double*)h.R[j], e, r_); \
+                     if (j < m) { double x_[W_], r_[W_]; LDx<W_>((const double*)h.X[j], e, x_, nt_); LDx<W_>((const double*)h.R[j], e, r_, nt_); \
                        _Pragma("unroll") for (int q = 0; q < W_; ++q) { xa[q] += c.a[j] * x_[q]; ra[q] += c.a[j] * r_[q]; } } } \
                    _Pragma("unroll") for (int q = 0; q < W_; ++q) xa[q] = xa[q] + beta * ra[q]; \
-                   STx<W_>(xnext, e, xa); }
+                   STx<W_>(xnext, e, xa, nt_); }
   SDFS_PACKET_LOOP(double, n, BODY)
 #undef BODY
 }
@@ -570,7 +574,7 @@ k_and_mix_dev(AndPtrs h, const AndState* __restrict__ S, int m, double beta, dou
   if (S->mix_rel != rel) return;
   const int mode = S->mix_mode;
   if (mode == 0) {
-#define BODY(W_) { double f_[W_]; LDx<W_>(fx, e, f_); STx<W_>(x, e, f_); }
+#define BODY(W_) { double f_[W_]; LDx<W_>(fx, e, f_, nt_); STx<W_>(x, e, f_, nt_); }
     SDFS_PACKET_LOOP(double, n, BODY)
 #undef BODY
     return;
@@ -581,14 +585,14 @@ k_and_mix_dev(AndPtrs h, const AndState* __restrict__ S, int m, double beta, dou
   const double be = mode == 2 ? S->mix_beta : beta;
 #define BODY(W_) { double xa[W_], ra[W_], xs_[AND_MAX_M][W_], rs_[AND_MAX_M][W_]; \
                    _Pragma("unroll") for (int j = 0; j < AND_MAX_M; ++j) { \
-                     if (j < m && !(mode == 2 && j == pos)) { LDx<W_>((const double*)h.X[j], e, xs_[j]); LDx<W_>((const double*)h.R[j], e, rs_[j]); } } \
+                     if (j < m && !(mode == 2 && j == pos)) { LDx<W_>((const double*)h.X[j], e, xs_[j], nt_); LDx<W_>((const double*)h.R[j], e, rs_[j], nt_); } } \
                    _Pragma("unroll") for (int q = 0; q < W_; ++q) { xa[q] = 0.0; ra[q] = 0.0; } \
                    _Pragma("unroll") for (int j = 0; j < AND_MAX_M; ++j) { \
                      if (j < m && !(mode == 2 && j == pos)) { \
                        _Pragma("unroll") for (int q = 0; q < W_; ++q) { xa[q] += ca[j] * xs_[j][q]; ra[q] += ca[j] * rs_[j][q]; } } } \
                    _Pragma("unroll") for (int q = 0; q < W_; ++q) xa[q] = xa[q] + be * ra[q]; \
-                   STx<W_>(x, e, xa); \
-                   if (mode == 2) { double z_[W_]; _Pragma("unroll") for (int q = 0; q < W_; ++q) z_[q] = 0.0; STx<W_>(h.R[pos], e, z_); } }
+                   STx<W_>(x, e, xa, nt_); \
+                   if (mode == 2) { double z_[W_]; _Pragma("unroll") for (int q = 0; q < W_; ++q) z_[q] = 0.0; STx<W_>(h.R[pos], e, z_, nt_); } }
   SDFS_PACKET_LOOP(double, n, BODY)
 #undef BODY
 }
@@ -609,9 +613,9 @@ k_and_push_lite(const double* __restrict__ x, const double* __restrict__ fx, dou
                 double beta, long long n, double* __restrict__ partial, const unsigned long long* gate) {
   SDFS_GATED(gate);
   double acc[1] = {0.0};
-#define BODY(W_) { double x_[W_], f_[W_], r_[W_], y_[W_]; LDx<W_>(x, e, x_); LDx<W_>(fx, e, f_); \
+#define BODY(W_) { double x_[W_], f_[W_], r_[W_], y_[W_]; LDx<W_>(x, e, x_, nt_); LDx<W_>(fx, e, f_, nt_); \
                    _Pragma("unroll") for (int q = 0; q < W_; ++q) { r_[q] = f_[q] - x_[q]; y_[q] = fma(beta, r_[q], x_[q]); acc[0] = fma(r_[q], r_[q], acc[0]); } \
-                   STx<W_>(ypos, e, y_); STx<W_>(rpos, e, r_); }
+                   STx<W_>(ypos, e, y_, nt_); STx<W_>(rpos, e, r_, nt_); }
   SDFS_PACKET_LOOP(double, n, BODY)
 #undef BODY
   block_partials<1>(acc, partial);
@@ -708,7 +712,7 @@ k_and_mix_y(AndPtrs h, const AndState* __restrict__ S, int m, double beta, doubl
   const int mode = S->mix_mode;
   if (mode == 0) {
     if (x == fx) return;                  // (the caller alternates its buffers: T x already sits where the next pass reads)
-#define BODY(W_) { double f_[W_]; LDx<W_>(fx, e, f_); STx<W_>(x, e, f_); }
+#define BODY(W_) { double f_[W_]; LDx<W_>(fx, e, f_, nt_); STx<W_>(x, e, f_, nt_); }
     SDFS_PACKET_LOOP(double, n, BODY)
 #undef BODY
     return;
@@ -718,10 +722,10 @@ k_and_mix_y(AndPtrs h, const AndState* __restrict__ S, int m, double beta, doubl
 #pragma unroll
     for (int j = 0; j < AND_LAZY_M; ++j) ca[j] = j < m ? S->coef[j] : 0.0;
 #define BODY(W_) { double xa[W_], ys_[AND_LAZY_M][W_]; \
-                   _Pragma("unroll") for (int j = 0; j < AND_LAZY_M; ++j) { if (j < m) LDx<W_>((const double*)h.X[j], e, ys_[j]); } \
+                   _Pragma("unroll") for (int j = 0; j < AND_LAZY_M; ++j) { if (j < m) LDx<W_>((const double*)h.X[j], e, ys_[j], nt_); } \
                    _Pragma("unroll") for (int q = 0; q < W_; ++q) xa[q] = 0.0; \
                    _Pragma("unroll") for (int j = 0; j < AND_LAZY_M; ++j) { if (j < m) { _Pragma("unroll") for (int q = 0; q < W_; ++q) xa[q] = fma(ca[j], ys_[j][q], xa[q]); } } \
-                   STx<W_>(x, e, xa); }
+                   STx<W_>(x, e, xa, nt_); }
     SDFS_PACKET_LOOP(double, n, BODY)
 #undef BODY
     return;
@@ -733,9 +737,9 @@ k_and_mix_y(AndPtrs h, const AndState* __restrict__ S, int m, double beta, doubl
 #pragma unroll
   for (int j = 1; j < AND_LAZY_M; ++j)
     if (j == prev) { py = h.X[j]; pr = h.R[j]; }
-#define BODY(W_) { double y_[W_], r_[W_], z_[W_]; LDx<W_>(py, e, y_); LDx<W_>(pr, e, r_); \
+#define BODY(W_) { double y_[W_], r_[W_], z_[W_]; LDx<W_>(py, e, y_, nt_); LDx<W_>(pr, e, r_, nt_); \
                    _Pragma("unroll") for (int q = 0; q < W_; ++q) { y_[q] = fma(1.0 - beta, r_[q], y_[q]); z_[q] = 0.0; } \
-                   STx<W_>(x, e, y_); STx<W_>(yclr, e, y_); STx<W_>(rclr, e, z_); }
+                   STx<W_>(x, e, y_, nt_); STx<W_>(yclr, e, y_, nt_); STx<W_>(rclr, e, z_, nt_); }
   double* yclr = h.X[0];
   double* rclr = h.R[0];
 #pragma unroll

@@ -372,6 +372,10 @@ def test_newton_with_fp32_mfma_jvp(S, shapes):
     assert any(nm.startswith("jvpm32:") for nm in res[3][2]), res[3][2]
     assert not any(nm.startswith("jvpm32:") for nm in res[1][2])
     assert not any(nm.startswith("jvp32:") for nm in res[3][2]), res[3][2]          # every J.v pass ran on the fp32-MFMA kernels
+    # ... and BiCGSTAB's p / s updates rode on their first pass (csrc/krylov_kernels.hpp, slice32_jfused_kernel; the
+    # fp32-storage loop of mode 1 keeps the separate BLAS-1 kernels: the comparison above is fused against unfused)
+    assert any(nm.startswith("jvpm32+p:") for nm in res[3][2]) and any(nm.startswith("jvpm32+s:") for nm in res[3][2]), res[3][2]
+    assert not any(nm.startswith("jvpm32:slices") for nm in res[3][2]), res[3][2]
     assert res[3][0] <= res[1][0] + 2 and res[3][1] <= 1.3 * res[1][1], (res[1][:2], res[3][:2])
     T.close()
 
