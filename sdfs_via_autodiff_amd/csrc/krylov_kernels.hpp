@@ -265,6 +265,120 @@ slice32_jfused_kernel(const SliceDesc P, const JFused32IO io) {
 }
 
 typedef void (*jfused32_fn)(const SliceDesc, const JFused32IO);
+// ---------------------------------------------------------------------------------------------------
+// line32_stream_mid_kernel: the middle pass of J.v on the fp32-MFMA tiles (f32_kernels.hpp, line32_kernel<N, L_MID, R>) as
+// a persistent workgroup walking tiles with the next tile's loads in flight during the contractions -- the form that took
+// the fp64 middle pass from 0.59 to 0.72 of the HBM peak (stream_kernels.hpp, line_stream_kernel<..., PERSIST>).  The
+// registers a tile arrives in are free again once it is parked, so the next tile's loads are issued right there; a thread
+// parks and stores the same LDS units, so no barrier separates a tile's stores from the next tile's park.
+template <int N, int R, int WPC>
+__global__ void __launch_bounds__(256, WPC)
+line32_stream_mid_kernel(const LineDesc P, const LineIO io) {
+  using Geo = Line32Geo<N, R>;
+  constexpr int B = Geo::B, EPT4 = Geo::EPT4, Q4 = Geo::Q4;
+  constexpr bool PART4 = Geo::UNITS4 % B != 0;
+  extern __shared__ double lds_[];
+  float* const lds = reinterpret_cast<float*>(lds_);
+  __shared__ unsigned tk[2];
+  SDFS_GATED(io.gate);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 15, lk = lane >> 4;
+  const unsigned cpo = (unsigned)P.nchunks * LINE_R / R;        // tiles per outer index (whole chunks of R floats)
+  const long long ntiles = P.nouter * (long long)cpo;
+  const unsigned b0 = ((unsigned)(tid / Q4) * (unsigned)P.lrest + 4u * (tid % Q4)) * 4u;
+  const unsigned bstep = (unsigned)(B / Q4) * (unsigned)P.lrest * 4u;
+  const TicketWalk W(ntiles, blockIdx.x, io.sched);
+  unsigned cur, nxt;
+  int par = 0;
+  if (tid == 0) { const unsigned t0 = W.draw(); tk[0] = t0; tk[1] = t0 != NO_TILE ? W.draw() : NO_TILE; }
+  __syncthreads();
+  cur = tk[0]; nxt = tk[1];
+  __syncthreads();
+  QFrag32<N> qx, qy;
+  qx.load(P.Qx, lane);
+  qy.load(P.Qy, lane);
+  auto tile_base = [&](const unsigned t) -> long long {
+    const unsigned o = t / cpo;
+    return (long long)o * (N * N) * P.lrest + (long long)(t - o * cpo) * R;
+  };
+  v4f v[EPT4];
+  auto load_tile = [&](const unsigned t) {
+    const char* const inb = reinterpret_cast<const char*>(reinterpret_cast<const float*>(io.in) + tile_base(t));
+#pragma unroll
+    for (int k = 0; k < EPT4; ++k) {
+      const bool rowok = !PART4 || tid + k * B < Geo::UNITS4;
+      const char* const q = inb + (rowok ? b0 + k * bstep : b0);
+      v[k] = R == 32 ? __builtin_nontemporal_load(reinterpret_cast<const v4f*>(q)) : *reinterpret_cast<const v4f*>(q);      // (line32_kernel: nt on whole lines only)
+    }
+  };
+  if (cur != NO_TILE) {
+    load_tile(cur);
+    for (;;) {
+#pragma unroll
+      for (int k = 0; k < EPT4; ++k) {
+        const int u = tid + k * B;
+        if (!PART4 || u < Geo::UNITS4) *reinterpret_cast<v4f*>(lds + 4 * u) = v[k];
+      }
+      const bool has_next = nxt != NO_TILE;                     // uniform over the workgroup
+      const long long tbase = tile_base(cur);
+      if (has_next) load_tile(nxt);
+      unsigned nn = NO_TILE;                                     // (published before the third barrier: by then it has returned)
+      if (tid == 0 && has_next) nn = W.draw();
+      __syncthreads();
+      constexpr int NCT = N * R / 16;
+#pragma unroll
+      for (int j = 0; j < NCT / Geo::W; ++j) { ctile32<N, Geo::LX>(lds + (wave + j * Geo::W) * 16 + li, lk, qx); __builtin_amdgcn_sched_barrier(0); }
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < NCT / Geo::W; ++j) {
+        const int c = (wave + j * Geo::W) * 16;
+        ctile32<N, R>(lds + (c / R) * Geo::LX + (c % R) + li, lk, qy);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (tid == 0) tk[par] = nn;
+      __syncthreads();
+      char* const outb = reinterpret_cast<char*>(reinterpret_cast<float*>(io.out) + tbase);
+#pragma unroll
+      for (int k = 0; k < EPT4; ++k) {
+        const int u = tid + k * B;
+        if (!PART4 || u < Geo::UNITS4) *reinterpret_cast<v4f*>(outb + (b0 + k * bstep)) = *reinterpret_cast<const v4f*>(lds + 4 * u);
+      }
+      if (!has_next) break;
+      cur = nxt;
+      nxt = tk[par];
+      par ^= 1;
+    }
+  }
+  if (tid == 0) ticket_walk_done(io.sched, gridDim.x);
+}
+
+// workgroups per CU of the persistent fp32 middle pass (LDS: 51 KB tiles at 20 x 20 x 32 floats)
+template <int N, int R> struct Line32Stream { static constexpr int WPC = Line32Geo<N, R>::BPC >= 3 ? 3 : (Line32Geo<N, R>::BPC < 1 ? 1 : Line32Geo<N, R>::BPC); };
+inline int line32_stream_wpc(int n, int r) {
+  switch (n) {
+    case 16: return r == 32 ? Line32Stream<16, 32>::WPC : Line32Stream<16, 16>::WPC;
+    case 20: return r == 32 ? Line32Stream<20, 32>::WPC : Line32Stream<20, 16>::WPC;
+    case 24: return r == 32 ? Line32Stream<24, 32>::WPC : Line32Stream<24, 16>::WPC;
+    default: return Line32Stream<32, 16>::WPC;
+  }
+}
+#ifndef SDFS_NO_VARIANT_TABLES
+template <int N> inline line_fn line32_stream_mid_variant_n(int r) {
+  if constexpr (N <= 24) { if (r == 32) return (line_fn)line32_stream_mid_kernel<N, 32, Line32Stream<N, 32>::WPC>; }
+  return r == 16 ? (line_fn)line32_stream_mid_kernel<N, 16, Line32Stream<N, 16>::WPC> : nullptr;
+}
+inline line_fn line32_stream_mid_variant(int n, int r) {
+  switch (n) {
+    case 16: return line32_stream_mid_variant_n<16>(r);
+    case 20: return line32_stream_mid_variant_n<20>(r);
+    case 24: return line32_stream_mid_variant_n<24>(r);
+    case 32: return line32_stream_mid_variant_n<32>(r);
+    default: return nullptr;
+  }
+}
+#endif
+
 typedef void (*jfused_fn)(const SliceDesc, const JFusedIO);
 #ifndef SDFS_NO_VARIANT_TABLES
 template <int N> inline jfused_fn slice_jfused_variant_n(int kind) {

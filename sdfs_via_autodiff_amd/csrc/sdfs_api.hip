@@ -109,6 +109,7 @@ struct FastPlan {
 struct Knobs {
   int tile_budget = 0, filler_chunk = -1, force_waves = 0, no_occ_blocks = 0, no_pad = 0, no_vec2 = 0, no_vec4 = 0;
   int no_dot_fusion = 0, no_slice_merge = 0, cont_no_tensor = 0, cont_lds_cap = 4000;
+  int no_f32_stream = 0;       // SDFS_NO_F32_STREAM: 1 = the fp32-MFMA middle pass keeps one tile per workgroup
   int line_persist = 0;        // SDFS_LINE_PERSIST bit 0: middle line passes persistent, bit 1: last line pass persistent
                                // (round 2's look-ahead form; measured equal to one tile per workgroup at GCY 20^6: off by default)
   int line_stream = 3;         // SDFS_LINE_STREAM: stream_kernels.hpp forms of the fp64 line passes; bit 0: middle pass, bit 1: T's
@@ -293,6 +294,7 @@ Knobs read_knobs() {
   k.a3_tables = env_int("SDFS_A3_TABLES", 1);
 #endif
   k.no_slice_merge = env_int("SDFS_NO_SLICE_MERGE", 0);
+  k.no_f32_stream = env_int("SDFS_NO_F32_STREAM", 0);
   k.line_stream = env_int("SDFS_LINE_STREAM", 3);
   k.small_plan = env_int("SDFS_SMALL_PLAN", 1);
   k.small_r = env_int("SDFS_SMALL_R", 0);
@@ -870,6 +872,8 @@ int prepare_fast_passes(sdfs_handle* h, std::vector<FastPass>& passes) {
       if (f32) hipFuncSetAttribute((const void*)f32, hipFuncAttributeMaxDynamicSharedMemorySize, (int)line_lds_bytes(P.n));
       for (int r32 = 16; r32 <= 32; r32 += 16) for (int d3 = 0; d3 < 2; ++d3)
         if (line_fn m32 = line32_variant(P.n, m, r32, d3 != 0)) hipFuncSetAttribute((const void*)m32, hipFuncAttributeMaxDynamicSharedMemorySize, (int)line32_lds_bytes(P.n, r32));
+      for (int r32 = 16; r32 <= 32; r32 += 16)
+        if (line_fn s32 = line32_stream_mid_variant(P.n, r32)) hipFuncSetAttribute((const void*)s32, hipFuncAttributeMaxDynamicSharedMemorySize, (int)line32_lds_bytes(P.n, r32));
     }
   }
   if (!h->sched) {
@@ -1366,6 +1370,14 @@ int run_fast_plan(sdfs_handle* h, FastPlan& fp, long long nloc, bool has_first, 
       const int r32 = line32_row_floats(P.n, P.ld.lrest);
       if (m32) {
         fn = line32_variant(P.n, lm, r32); grid = (unsigned)(d.ntiles * LINE_R / r32);
+        if (lm == L_MID && (P.stream & 1) && grid >= 8u * TK_SUB && h->knobs.no_f32_stream == 0) {
+          // persistent form, next tile in flight (krylov_kernels.hpp); a multiple of 8 workgroups, one ticket range per XCD
+          if (line_fn sf = line32_stream_mid_variant(P.n, r32)) {
+            long long g = std::min<long long>(grid, (long long)line32_stream_wpc(P.n, r32) * h->num_cus);
+            g -= g % (8 * TK_SUB);
+            fn = sf; grid = (unsigned)g;
+          }
+        }
         if (lm == L_JLAST && !vjp && h->jf.active) {
           io.dot_with = h->jf.dot_with; bytes += n8;      // (halved below: the mean of the two applications)
           if (io.dot_with) fn = line32_variant(P.n, lm, r32, true);
