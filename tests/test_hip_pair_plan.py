@@ -348,7 +348,7 @@ def test_sa_with_fp32_intermediates(S, shapes):
     T.close()
 
 
-@pytest.mark.parametrize("shapes", [(16,) * 6, (20, 20, 16, 16, 16, 16)])
+@pytest.mark.parametrize("shapes", [(16,) * 6, (20, 20, 16, 16, 16, 16), (24, 24, 20, 20, 16, 16), (32, 32, 16, 16, 16, 16)])
 def test_newton_with_fp32_mfma_jvp(S, shapes):
     """BASELINE config 5 "on MFMA" (opts.krylov_f32 = 3; new work, the reference is fp64 only): the J.v passes of the inner
     solve on an fp32 LDS tile with v_mfma_f32_16x16x4_f32 (csrc/f32_kernels.hpp), everything the fixed point depends on --
