@@ -120,6 +120,20 @@ def test_newton_krylov_gcy20_distance_to_fixed_point(S, gcy20, c_oracle):
     assert i32["status"] == 0
     d32 = float(np.max(np.abs(x32 - xs)))
     assert d32 < 5e-9, d32
+    del x32
+    # config 5 "on MFMA" (round 4): fp32 LDS tiles + v_mfma_f32 for the J.v passes, BiCGSTAB's vector updates on their
+    # first pass, the persistent fp32 middle pass -- the same distance to the same fixed point; and the relative-ridge
+    # Anderson loop (opt-in) to the metric's tolerance
+    xm, nm, im = T.solve(w0, "newton", tol=1e-8, inner_rtol=1e-6, inner_atol=0.0, krylov_f32=3)
+    assert im["status"] == 0 and nm < 25
+    dm = float(np.max(np.abs(xm - xs)))
+    assert dm < 5e-9, dm
+    del xm
+    xa, na, ia = T.solve(w0, "anderson", tol=1e-8, max_iter=2000, ridge=-1e-6)
+    assert ia["status"] == 0 and na < 542, (na, ia)          # (542 = successive approximation's count from the same start)
+    da = float(np.max(np.abs(xa - xs)))
+    assert da < 2e-5, da                                     # |T x - x|_2 <= 1e-8 at modulus 0.9988: within tol / (1 - modulus) of x*
+    assert float(np.max(np.abs(c_oracle(xa) - xa))) < 1e-7
     T.close()
 
 
