@@ -1503,7 +1503,7 @@ template <int N> inline slice_fn slice_variant_n(int mode, bool f32) {
     case S_TFIRST_LIN: return f32 ? (slice_fn)slice_kernel<N, S_TFIRST_LIN, true> : (slice_fn)slice_kernel<N, S_TFIRST_LIN, false>;
     case S_JFIRST: return f32 ? (slice_fn)slice_kernel<N, S_JFIRST, true> : (slice_fn)slice_kernel<N, S_JFIRST, false>;
     case S_MID: return f32 ? nullptr : (slice_fn)slice_kernel<N, S_MID, false>;
-    case S_TFIRST32: return f32 ? nullptr : (slice_fn)slice_kernel<N, S_TFIRST32, false>;
+    case S_TFIRST32: return f32 ? nullptr : (slice_fn)slice_kernel<N, S_TFIRST32, false, 4, false, SliceTFirst<N>::G, SliceTFirst<N>::OCC>;
     default: return nullptr;
   }
 }
@@ -1559,8 +1559,8 @@ inline line_fn line_variant(int n, int mode, bool persist, bool fullc, bool f32 
 #endif
 // slices per wave tile / LDS bytes per workgroup of slice_variant(n, mode)
 inline int slice_tile_slices(int n, int mode) {
-  if (mode == S_TFIRST && n == 20) return SliceTFirst<20>::G;
-  if (mode == S_TFIRST && n == 16 && SliceTFirst<16>::G) return SliceTFirst<16>::G;
+  if ((mode == S_TFIRST || mode == S_TFIRST32) && n == 20) return SliceTFirst<20>::G;
+  if ((mode == S_TFIRST || mode == S_TFIRST32) && n == 16 && SliceTFirst<16>::G) return SliceTFirst<16>::G;
   return n == 16 ? SliceGeo<16>::G : n == 20 ? SliceGeo<20>::G : n == 24 ? SliceGeo<24>::G : SliceGeo<32>::G;
 }
 inline size_t slice_lds_bytes(int n, int mode) { return (size_t)slice_tile_slices(n, mode) * n * (n == 20 ? n : n + 2) * 8 * 4; }

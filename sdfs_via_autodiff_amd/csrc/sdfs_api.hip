@@ -896,6 +896,8 @@ int prepare_fast_passes(sdfs_handle* h, std::vector<FastPass>& passes) {
       line_fn f = line_stream_variant(P.n, m, a3f != 0);
       if (!f) return 1;
       hipFuncSetAttribute((const void*)f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)line_lds_bytes(P.n));
+      if (line_fn f32 = line_stream_t32_variant(P.n, m, a3f != 0))
+        hipFuncSetAttribute((const void*)f32, hipFuncAttributeMaxDynamicSharedMemorySize, (int)line_lds_bytes(P.n));
     }
   }
   return 0;
@@ -1354,6 +1356,17 @@ int run_fast_plan(sdfs_handle* h, FastPlan& fp, long long nloc, bool has_first, 
         fn = last ? line_tlast32_variant(P.n) : line_variant(P.n, L_MID, false, true, true);
         grid = (unsigned)d.ntiles;
         bytes -= last ? 0.5 * n8 : n8;
+        // ... on the streamed forms where the fp64 passes run them (stream_kernels.hpp, IN32 / OUT32)
+        if ((P.stream & (last ? 2 : 1)) && h->knobs.no_f32_stream == 0) {
+          if (line_fn sf = line_stream_t32_variant(P.n, last ? L_TLAST : L_MID, d.f1 != nullptr)) {
+            fn = sf;
+            if (!last) {
+              long long g = std::min<long long>(P.ld.ntiles, (long long)line_stream_wpc_mid32(P.n) * h->num_cus);
+              g -= g % 8;
+              grid = (unsigned)std::max<long long>(g, 8);
+            }
+          }
+        }
       } else if (!lf32 && ((lm == L_MID && (P.stream & 1)) || ((lm == L_TLAST || lm == L_TLAST_LIN) && (P.stream & 2)))) {
         // stream_kernels.hpp: persistent middle pass with the next tile in flight; last pass with its side stream loaded early
         fn = line_stream_variant(P.n, lm, d.f1 != nullptr);

@@ -232,7 +232,11 @@ slice_walk_kernel(const SliceDesc P, const SliceIO io) {
 // set at a time -- the OLDPF side-stream load on its own, at a register budget that admits three workgroups per CU.
 // A3F (one tile per workgroup): the aggregator's scale from the two small tables of LineDesc::f1 / f2 -- 20 doubles per
 // tile through LDS and one 16-byte piece per thread -- instead of two gathers and their index arithmetic per unit.
-template <int N, int MODE, int WPC, bool OLDPF = false, int B = LineGeo<N>::B, bool PERSIST = true, bool A3F = false>
+// IN32 / OUT32 (round 4, opts.t_f32): the tile arrives as / leaves as scaled floats -- 16-byte units of four, row u >> 2,
+// float4 u & 3 of its 16 positions -- and is converted at the park / at the store; everything between (fp64 LDS tile,
+// contractions, epilogue) is the fp64 form's.  IN32 in the last pass of T multiplies by 2^-k (t32_scale_of) at the park.
+template <int N, int MODE, int WPC, bool OLDPF = false, int B = LineGeo<N>::B, bool PERSIST = true, bool A3F = false, bool IN32 = false,
+          bool OUT32 = false>
 __global__ void __launch_bounds__(B, WPC * B / 256)
 line_stream_kernel(const LineDesc P, const LineIO io) {
   using Geo = LineGeo<N>;
@@ -243,6 +247,10 @@ line_stream_kernel(const LineDesc P, const LineIO io) {
   constexpr bool MULE = MODE == L_JLAST;
   constexpr bool PARTIAL = Geo::UNITS % B != 0;
   static_assert(MODE != L_TFUSED, "the fused end + start form stays with line_kernel");
+  static_assert(!OUT32 || MODE == L_MID, "fp32 output: the middle pass");
+  static_assert(!IN32 || MODE == L_MID || MODE == L_TLAST, "fp32 input: the passes of a plain T application");
+  constexpr int EPT4 = Geo::EPT4;
+  constexpr bool PART4 = Geo::UNITS4 % B != 0;
   static_assert(!A3F || CES, "two-table a3: the last pass of T");
   extern __shared__ double lds[];
   __shared__ double red[16];
@@ -283,18 +291,46 @@ line_stream_kernel(const LineDesc P, const LineIO io) {
   bool rnan = false;
   const bool dot3 = MULE && io.dot_with != nullptr;             // uniform
 
-  v2d v[EPT];
+  v2d v[IN32 ? 1 : EPT];
+  float4 vf[IN32 ? EPT4 : 1];
+  // float units: element offset of unit 0 against the tile base, and between two units of a thread
+  const unsigned e0 = (unsigned)(tid >> 2) * (unsigned)P.lrest + 4u * (tid & 3);
+  const unsigned estep = (unsigned)(B / 4) * (unsigned)P.lrest;
+  auto load32 = [&](const long long base) {
+    const char* const inb = reinterpret_cast<const char*>(reinterpret_cast<const float*>(io.in) + base);
+#pragma unroll
+    for (int k = 0; k < EPT4; ++k) {
+      const bool rowok = !PART4 || tid + k * B < Geo::UNITS4;
+      vf[IN32 ? k : 0] = *reinterpret_cast<const float4*>(inb + (rowok ? e0 + k * estep : e0) * 4u);
+    }
+  };
+  double unscale32 = 1.0;
+  if (IN32 && CES) { const PowLane PL0 = pow_lane_init(lane); unscale32 = t32_scale_of(io.old[P.ref_off], P.theta, PL0, true); }
   v2d wv[OLDPF ? EPT : 1];
   if (cur != NO_TILE) {
     {
       unsigned o0; int ch0;
-      line_tile_load<EPT, B, Geo::UNITS>(v, io.in + line_tile_base(P, cur, N * N, o0, ch0), tid, b0, bstep);
+      const long long base0 = line_tile_base(P, cur, N * N, o0, ch0);
+      if constexpr (IN32) load32(base0);
+      else line_tile_load<EPT, B, Geo::UNITS>(v, io.in + base0, tid, b0, bstep);
     }
     for (;;) {
       SDFS_STREAM_STAMP(0);
+      if constexpr (IN32) {
 #pragma unroll
-      for (int k = 0; k < EPT; ++k)
-        if (!PARTIAL || tid + k * B < Geo::UNITS) *reinterpret_cast<v2d*>(lds + 2 * (tid + k * B)) = v[k];
+        for (int k = 0; k < EPT4; ++k) {
+          const int u = tid + k * B;
+          if (!PART4 || u < Geo::UNITS4) {
+            const float4 f = vf[IN32 ? k : 0];
+            *reinterpret_cast<v2d*>(lds + 4 * u) = (v2d){(double)f.x * unscale32, (double)f.y * unscale32};
+            *reinterpret_cast<v2d*>(lds + 4 * u + 2) = (v2d){(double)f.z * unscale32, (double)f.w * unscale32};
+          }
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < EPT; ++k)
+          if (!PARTIAL || tid + k * B < Geo::UNITS) *reinterpret_cast<v2d*>(lds + 2 * (tid + k * B)) = v[k];
+      }
       const bool has_next = PERSIST && nxt != NO_TILE;            // uniform over the workgroup
       unsigned o; int chunk;
       const long long tbase = line_tile_base(P, cur, N * N, o, chunk);
@@ -305,8 +341,11 @@ line_stream_kernel(const LineDesc P, const LineIO io) {
       }
       if constexpr (OLDPF) { if (need_old) line_tile_load<EPT, B, Geo::UNITS>(wv, io.old + tbase, tid, b0, bstep); }
       unsigned o1; int ch1;
-      const char* const nxb = reinterpret_cast<const char*>(io.in + line_tile_base(P, has_next ? nxt : cur, N * N, o1, ch1));
-      if (has_next) line_tile_load<EPT, B, Geo::UNITS>(v, reinterpret_cast<const double*>(nxb), tid, b0, bstep);
+      const long long nbase = line_tile_base(P, has_next ? nxt : cur, N * N, o1, ch1);
+      if (has_next) {
+        if constexpr (IN32) load32(nbase);
+        else line_tile_load<EPT, B, Geo::UNITS>(v, io.in + nbase, tid, b0, bstep);
+      }
       unsigned nn = NO_TILE;                                         // (published before the third barrier: by then it has returned)
       if (PERSIST && tid == 0 && has_next) nn = W.draw();
       SDFS_STREAM_STAMP(1);
@@ -331,7 +370,17 @@ line_stream_kernel(const LineDesc P, const LineIO io) {
       __syncthreads();
       SDFS_STREAM_STAMP(6);
       char* const outb = reinterpret_cast<char*>(io.out + tbase);
-      if (!CES && !MULE) {
+      if constexpr (OUT32) {
+        char* const outb4 = reinterpret_cast<char*>(reinterpret_cast<float*>(io.out) + tbase);
+#pragma unroll
+        for (int k = 0; k < EPT4; ++k) {
+          const int u = tid + k * B;
+          if (!PART4 || u < Geo::UNITS4) {
+            const v2d a = *reinterpret_cast<const v2d*>(lds + 4 * u), b = *reinterpret_cast<const v2d*>(lds + 4 * u + 2);
+            *reinterpret_cast<float4*>(outb4 + (e0 + k * estep) * 4u) = make_float4((float)a.x, (float)a.y, (float)b.x, (float)b.y);
+          }
+        }
+      } else if (!CES && !MULE) {
 #pragma unroll
         for (int k = 0; k < EPT; ++k) {
           const int u = tid + k * B;
@@ -599,6 +648,7 @@ line_tlast32_kernel(const LineDesc P, const LineIO io) {
 template <int N> struct StreamGeo {
   static constexpr int B = LineGeo<N>::B;
   static constexpr int WPC_MID = N == 32 ? 1 : 2;                       // persistent middle pass: workgroups per CU launched
+  static constexpr int WPC_MID32 = N <= 20 ? 3 : WPC_MID;               // ... with fp32 streams: the tile is in flight in half the registers
   static constexpr int WPC_LAST = N == 16 ? 3 : LineGeo<N>::BPC;        // one tile per workgroup: register budget of the last pass
 };
 template <int N> inline line_fn line_stream_variant_a3f_n(int mode) {
@@ -638,7 +688,25 @@ inline line_fn line_stream_variant(int n, int mode, bool a3f = false) {
     default: return nullptr;
   }
 }
+// opts.t_f32: the streamed forms on fp32 intermediates (middle pass: floats in, floats out; last pass of T: floats in)
+template <int N> inline line_fn line_stream_t32_variant_n(int mode, bool a3f) {
+  using G = StreamGeo<N>;
+  if (mode == L_MID) return (line_fn)line_stream_kernel<N, L_MID, G::WPC_MID32, false, G::B, true, false, true, true>;
+  if (mode == L_TLAST) return a3f ? (line_fn)line_stream_kernel<N, L_TLAST, G::WPC_LAST, true, G::B, false, true, true, false>
+                                  : (line_fn)line_stream_kernel<N, L_TLAST, G::WPC_LAST, true, G::B, false, false, true, false>;
+  return nullptr;
+}
+inline line_fn line_stream_t32_variant(int n, int mode, bool a3f) {
+  switch (n) {
+    case 16: return line_stream_t32_variant_n<16>(mode, a3f);
+    case 20: return line_stream_t32_variant_n<20>(mode, a3f);
+    case 24: return line_stream_t32_variant_n<24>(mode, a3f);
+    case 32: return line_stream_t32_variant_n<32>(mode, a3f);
+    default: return nullptr;
+  }
+}
 inline int line_stream_wpc_mid(int n) { return n == 32 ? 1 : 2; }
+inline int line_stream_wpc_mid32(int n) { return n <= 20 ? 3 : line_stream_wpc_mid(n); }
 inline line_fn line_tlast32_variant(int n) {
   switch (n) {
     case 16: return (line_fn)line_tlast32_kernel<16, 3>;
