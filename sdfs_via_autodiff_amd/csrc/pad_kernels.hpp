@@ -150,6 +150,9 @@ pad_slice_kernel(const PadDesc P, const SliceIO io) {
     PT.init(P.theta, lane);
 #pragma unroll
     for (int k = 0; k < PAD_EPL; k += 2) {
+      // (uniform: no lane's pair lies inside the tile -- 25 x 25 on 32 x 32 fills ten of the 16 units: 25^6 2004 -> 1835 us.
+      // Only there: on the 20- / 24-wide tiles the exits cost the unrolled routines their interleaving, 21^6 483 -> 918 us)
+      if (NT == 32 && (PAIR ? 128 * (k >> 1) : 64 * k) >= nval) break;
       const double xin[2] = {v[k], v[k + 1]};                     // (masked lanes were loaded as 1)
       double xw[2];
       PT.template run<2>(xin, xw);
