@@ -23,6 +23,10 @@
 #define SDFS_STREAM_STAMP_DECL
 #endif
 
+#ifndef SDFS_LAST_SB           // units of the last pass's epilogue between two scheduling barriers (build-time probe)
+#define SDFS_LAST_SB 1
+#endif
+
 namespace sdfs {
 
 
@@ -460,7 +464,7 @@ line_stream_kernel(const LineDesc P, const LineIO io) {
             const v2d wk = wv[OLDPF ? k : 0];
             unit(k, make_double2(wk.x, wk.y), cw[k % LOOK], rw[k % LOOK]);
             if (k + LOOK < EPT) issue(k + LOOK, sw[k % LOOK], cw[k % LOOK], rw[k % LOOK]);
-            __builtin_amdgcn_sched_barrier(0);
+            if (k % SDFS_LAST_SB == SDFS_LAST_SB - 1) __builtin_amdgcn_sched_barrier(0);      // (units the scheduler may interleave)
           }
         } else {
           int kk = 0;
