@@ -272,6 +272,15 @@ int sdfs_anderson_state(sdfs_handle* h, double* out8_host, double* errs_host, in
  * power-of-two scale of c1 / c2. */
 int sdfs_set_krylov_f32(sdfs_handle* h, int on, double w_ref);
 
+/* Sharded handles whose stages run the pair plan's kernels (6-D grids, sdfs_describe_plan says "pair-plan"): fp32
+ * intermediates for the plain applications of T that follow (mode 0; opts.t_f32 of the single-GPU successive
+ * approximation, code/solvers.py:19-48 is the loop).  Stage 0 then WRITES scaled floats -- the re-shard between the stages
+ * moves half the bytes -- and stage 1 reads them; w, T w and the residual stay fp64.  One stored float carries 2^-24
+ * relative, ~ w 2^-24 / |theta| on T w: the caller runs this form while the step is well above that and finishes in fp64
+ * (sdfs_via_autodiff_amd/distributed.py, successive_approx_sharded(t_f32=True)).  `w_ref` as for sdfs_set_krylov_f32: every
+ * rank and both stages derive the same power-of-two scale from it.  SDFS_ERR_UNSUPPORTED on handles with generic stage plans. */
+int sdfs_set_t_f32(sdfs_handle* h, int on, double w_ref);
+
 /* Profiling: when enabled every kernel launch is bracketed by HIP events on the
  * handle's stream; sdfs_get_counters synchronises and sums them. */
 int sdfs_set_profiling(sdfs_handle* h, int on);

@@ -84,6 +84,7 @@ SYMBOLS = {
     "sdfs_anderson_step": (C.c_int, [_P, C.c_int, C.c_int64, _P, _P, _P]),
     "sdfs_anderson_state": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int64]),
     "sdfs_set_krylov_f32": (C.c_int, [_P, C.c_int, C.c_double]),
+    "sdfs_set_t_f32": (C.c_int, [_P, C.c_int, C.c_double]),
     "sdfs_set_profiling": (C.c_int, [_P, C.c_int]),
     "sdfs_reset_counters": (C.c_int, [_P]),
     "sdfs_get_counters": (C.c_int, [_P, C.POINTER(sdfs_counters)]),

@@ -189,6 +189,7 @@ struct SliceDesc {
   const double* Qe;         // matrix of the second-fastest axis
   double theta;
   long long ref_off;        // C-order offset of the mid-grid point (fp32 linearisation scale)
+  double t32_ref;           // > 0: reference value of the t_f32 scale (sharded stages: the mid-grid point may live on another rank)
 };
 
 struct SliceIO {
@@ -328,7 +329,7 @@ slice_kernel(const SliceDesc P, const SliceIO io) {
     const PowLane PT = pow_lane_init(lane);
     double lin_scale = 1.0;
     if (LIN && F32) lin_scale = lin_scale_of(io.in[P.ref_off], P.theta, PT, false);
-    const double t32_scale = T32 ? t32_scale_of(io.in[P.ref_off], P.theta, PT, false) : 1.0;
+    const double t32_scale = T32 ? t32_scale_of(P.t32_ref > 0.0 ? P.t32_ref : io.in[P.ref_off], P.theta, PT, false) : 1.0;
     char* const auxo = LIN ? (F32 ? reinterpret_cast<char*>(reinterpret_cast<float*>(io.aux_out) + gbase)
                                   : reinterpret_cast<char*>(io.aux_out + gbase)) : nullptr;
 #pragma unroll 1
@@ -419,6 +420,7 @@ struct LineDesc {
   int a3x, a3y;
   int minus_identity;
   long long ref_off;        // C-order offset of the mid-grid point (fp32 linearisation scale)
+  double t32_ref;           // > 0: reference value of the t_f32 scale (sharded stages: the mid-grid point may live on another rank)
   // a3 as two small tables where it factorises (build_fast_plan): a3 = f1[o * n + x] * f2[o * lrest + position]; else null.
   // Read by the streamed last pass (stream_kernels.hpp, A3F).  The same form as a run-time branch in line_kernel's own
   // epilogue lost at GCY 16^6 (last pass 0.0905 against 0.0863 ms): that kernel stays with the gathers.

@@ -177,6 +177,7 @@ struct sdfs_handle {
   bool krylov_f32 = false;
   std::vector<double> a3_host;       // host copy of the a3 table (the pair plan looks for its two-table form)
   bool t32_active = false;           // successive approximation, opts.t_f32: T applications keep their intermediates as scaled floats
+  double t32_ref = 0.0;              // sharded handles (sdfs_set_t_f32): the reference value of that scale, the same on every rank
   bool check_every_default = false;  // the running solve was given check_every <= 0 (sdfs_solve_dev)
   bool krylov_mfma32 = false;        // ... with the J.v passes of the pair plan on an fp32 LDS tile and fp32 MFMA (opts.krylov_f32 = 3: f32_kernels.hpp)
   bool krylov_bf16 = false;          // ... with every store of those fp32 containers rounded to bfloat16 (opts.krylov_f32 = 2: bf16r, vec_kernels.hpp)
@@ -988,6 +989,8 @@ int build_stage_fast_plans(sdfs_handle* h, int a_lo, int a_len, int b_lo, int b_
   if ((rc = prepare_fast_passes(h, s0)) || (rc = prepare_fast_passes(h, s1))) return rc == 1 ? 0 : rc;
   h->sfast[0].passes = s0; h->sfast[1].passes = s1;
   h->sfast[0].ok = h->sfast[1].ok = true;
+  h->sfast[0].f32_ok = s0[1].ld.lrest % LINE_R == 0;
+  h->sfast[1].f32_ok = s1[0].ld.lrest % LINE_R == 0;
   return 0;
 }
 
@@ -1208,7 +1211,9 @@ int run_fast_plan(sdfs_handle* h, FastPlan& fp, long long nloc, bool has_first, 
   // and writes only c1 (first pass) and c2 (last pass) as scaled floats
   const bool f32 = !vjp && h->krylov_f32 && mode != MODE_T;
   // opts.t_f32: the intermediates between the passes of a plain T application as scaled floats (whole chunks everywhere)
-  const bool t32 = mode == MODE_T && h->t32_active && fp.f32_ok && !fp.small && has_first && has_last;
+  // (a sharded handle's stages, sdfs_set_t_f32: stage 0 then WRITES floats -- the exchange moves half the bytes -- and stage 1
+  // reads them)
+  const bool t32 = mode == MODE_T && h->t32_active && fp.f32_ok && !fp.small && ((has_first && has_last) || (h->sharded && h->t32_ref > 0.0));
   const char* tag = t32 ? "T32" : vjp ? "vjp" : (mode == MODE_JVP) ? (f32 ? "jvp32" : "jvp") : (mode == MODE_T_LIN ? "Tlin" : "T");
   for (int i = 0; i < np; ++i) {
     FastPass& P = fp.passes[i];
@@ -1287,6 +1292,7 @@ int run_fast_plan(sdfs_handle* h, FastPlan& fp, long long nloc, bool has_first, 
       else if (mode == MODE_JVP) { sm = S_JFIRST; io.aux_in = vjp ? h->c2 : h->c1; bytes += n8; }
       SliceDesc sd = P.sd;
       if (vjp) { sd.Qf = h->ax[P.ax1].Qt; sd.Qe = h->ax[P.ax0].Qt; }
+      if (h->sharded) sd.t32_ref = h->t32_ref;
       if (mode == MODE_JVP && !vjp && !f32 && h->jf.active && h->jf.kind >= 0) {
         // BiCGSTAB's p / s update on the registers of this pass (krylov_kernels.hpp)
         jfused_fn jfn = slice_jfused_variant(P.n, h->jf.kind);
@@ -1340,6 +1346,7 @@ int run_fast_plan(sdfs_handle* h, FastPlan& fp, long long nloc, bool has_first, 
       io.sched = h->sched + SCHED_WORDS * i;
       LineDesc d = P.ld;
       d.minus_identity = minus_identity;
+      if (h->sharded) d.t32_ref = h->t32_ref;
       if (h->knobs.a3_tables == 0) { d.f1 = nullptr; d.f2 = nullptr; }
       if (vjp) { d.Qx = h->ax[P.ax0].Qt; d.Qy = h->ax[P.ax1].Qt; }
       int lm = L_MID;
@@ -3382,6 +3389,19 @@ int sdfs_set_krylov_f32(sdfs_handle* h, int on, double w_ref) {
   if (on && !(w_ref > 0.0 && std::isfinite(w_ref))) return fail(h, SDFS_ERR_ARG, "reference value must be positive and finite");
   h->krylov_f32 = on != 0;
   h->lin_ref = on ? w_ref : 0.0;
+  return 0;
+}
+
+int sdfs_set_t_f32(sdfs_handle* h, int on, double w_ref) {
+  int rc = check(h); if (rc) return rc;
+  if (!h->sharded) return fail(h, SDFS_ERR_ARG, "sdfs_set_t_f32 is for sharded handles (opts.t_f32 otherwise)");
+  if (!h->sfast[0].ok || !h->sfast[1].ok) return fail(h, SDFS_ERR_UNSUPPORTED, "fp32 intermediates need the stages on the pair plan's kernels");
+  for (int st = 0; st < 2; ++st)
+    for (const FastPass& P : h->sfast[st].passes)
+      if (P.line && P.ld.lrest % LINE_R != 0) return fail(h, SDFS_ERR_UNSUPPORTED, "fp32 intermediates need whole 16-element chunks in every line pass");
+  if (on && !(w_ref > 0.0 && std::isfinite(w_ref))) return fail(h, SDFS_ERR_ARG, "reference value must be positive and finite");
+  h->t32_active = on != 0;
+  h->t32_ref = on ? w_ref : 0.0;
   return 0;
 }
 

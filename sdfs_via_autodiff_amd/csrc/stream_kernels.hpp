@@ -309,7 +309,7 @@ line_stream_kernel(const LineDesc P, const LineIO io) {
     }
   };
   double unscale32 = 1.0;
-  if (IN32 && CES) { const PowLane PL0 = pow_lane_init(lane); unscale32 = t32_scale_of(io.old[P.ref_off], P.theta, PL0, true); }
+  if (IN32 && CES) { const PowLane PL0 = pow_lane_init(lane); unscale32 = t32_scale_of(P.t32_ref > 0.0 ? P.t32_ref : io.old[P.ref_off], P.theta, PL0, true); }
   v2d wv[OLDPF ? EPT : 1];
   if (cur != NO_TILE) {
     {
@@ -577,7 +577,7 @@ line_tlast32_kernel(const LineDesc P, const LineIO io) {
     }
   }
   const PowLane PT = pow_lane_init(lane);
-  const double unscale = t32_scale_of(io.old[P.ref_off], P.theta, PT, true);
+  const double unscale = t32_scale_of(P.t32_ref > 0.0 ? P.t32_ref : io.old[P.ref_off], P.theta, PT, true);
   PowK<false> PK;
   PK.init(P.inv_theta, lane);
   __syncthreads();

@@ -101,13 +101,32 @@ class HipStages:
         check(lib.sdfs_set_krylov_f32(self._h, int(on), float(w_ref)), self._h)
         self.f32 = bool(on)
 
+    def set_t_f32(self, on, w_ref=0.0):
+        """fp32 intermediates for the plain applications of T that follow (sdfs_set_t_f32): stage 0 writes scaled floats,
+        the re-shard moves half the bytes, stage 1 reads them.  Returns False (and changes nothing) on handles whose
+        stages run the generic plans."""
+        rc = lib.sdfs_set_t_f32(self._h, int(on), float(w_ref))
+        if rc == _lib.SDFS_ERR_UNSUPPORTED:
+            return False
+        check(rc, self._h)
+        self.t32 = bool(on)
+        return True
+
+    def dtypes(self, stage, mode):
+        """(input, output) element types of a stage call."""
+        if getattr(self, "f32", False) and mode == MODE_JVP:
+            return torch.float32, torch.float32
+        if getattr(self, "t32", False) and mode == MODE_T:
+            return (torch.float64, torch.float32) if stage == 0 else (torch.float32, torch.float64)
+        return torch.float64, torch.float64
+
     def run(self, stage, mode, x, old=None, resid=None, out=None, gate=None, gate_tol=0.0):
         """resid: 1-element device tensor that receives max|out - old| (stage 1, T modes).  out: preallocated result
         (contiguous, the stage's shape).  gate: 1-element device tensor; if its value is <= gate_tol the stage's kernels
         return at once, `out` keeps its contents and `resid` stays 0 (sdfs_apply_stage_gated_dev)."""
-        dt = torch.float32 if (getattr(self, "f32", False) and mode == MODE_JVP) else torch.float64
-        if x.dtype != dt:
-            raise TypeError(f"stage input is {x.dtype}, expected {dt}")
+        dt_in, dt = self.dtypes(stage, mode)
+        if x.dtype != dt_in:
+            raise TypeError(f"stage input is {x.dtype}, expected {dt_in}")
         shp = self.shape0 if stage == 0 else self.shape1
         if out is None:
             out = torch.empty(shp, dtype=dt, device=self.device)
@@ -188,6 +207,7 @@ class ShardedKoopmans:
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
         self.model = model
+        self.params = tuple(float(v) for v in params)
         self.shapes = tuple(int(s) for s in shapes)
         self.axis_a, self.axis_b = SHARD_AXES[model]
         if min(self.shapes[self.axis_a], self.shapes[self.axis_b]) < self.world:
@@ -354,7 +374,7 @@ class ShardedKoopmans:
     def _stage(self, be, stage, mode, x, role, **kw):
         """A stage launch into an operator-owned buffer (two alternate per role and shape)."""
         shp = be.shape0 if stage == 0 else be.shape1
-        dt = torch.float32 if (getattr(be, "f32", False) and mode == MODE_JVP) else x.dtype
+        dt = be.dtypes(stage, mode)[1] if hasattr(be, "dtypes") else x.dtype
         return be.run(stage, mode, x, out=self.buf(self._flip(role), shp, dt, x.device), **kw)
 
     def apply_mirror(self, w, orient, old=None, out=None, res=None, gate=None, gate_tol=0.0):
@@ -464,7 +484,8 @@ def _first_at_most(vals, thr):
     return None
 
 
-def successive_approx_sharded(op, w_loc, tol=1e-7, max_iter=1000000, errors=None, mirror=True, stats=None, check_every=16):
+def successive_approx_sharded(op, w_loc, tol=1e-7, max_iter=1000000, errors=None, mirror=True, stats=None, check_every=16,
+                              t_f32=False):
     """Successive approximation on a sharded grid, the reference's stopping rule (code/solvers.py:34-36).
 
     Mirror phase (one exchange per iteration): the two-step difference max|w_(k+1) - w_(k-1)| is the screen (see
@@ -477,7 +498,13 @@ def successive_approx_sharded(op, w_loc, tol=1e-7, max_iter=1000000, errors=None
     below the threshold they are no-ops and the iterate buffers keep their contents), and the host reads the ring
     every `check_every` iterations -- as the single-GPU loop does (csrc/sdfs_api.hip, solve_sa).  Iterates live in
     buffers allocated once.  `errors` receives the one-step error where it was computed and the two-step screen (as
-    a negative number) elsewhere; stats: mirror_iters, host_syncs."""
+    a negative number) elsewhere; stats: mirror_iters, host_syncs, t32_iters.
+
+    t_f32 (HIP stages on the pair plan's kernels, mirror schedule): the first part of the mirror phase keeps the
+    intermediate between the stages -- what the exchange moves -- as scaled floats (sdfs_set_t_f32: half the bytes per
+    link), down to a screen of 64 float roundings of T w (~ 64 w 2^-24 / |theta|, the single-GPU opts.t_f32 rule,
+    csrc/sdfs_api.hip solve_sa), and carries on in fp64 from there.  The iterate path differs from the all-fp64 one at
+    that level, so the iteration count is this configuration's own; the stopping rule at the end is the fp64 one."""
     dev = w_loc.device
     check_every = max(int(check_every), 1)
     host_syncs = 0
@@ -486,44 +513,72 @@ def successive_approx_sharded(op, w_loc, tol=1e-7, max_iter=1000000, errors=None
     it = 0
     diverged = False
     if mirror and op.mirror_ok and max_iter > 0:
-        thr = SCREEN * tol
         shape_b = list(op.shapes); shape_b[op.axis_b] = op.b_sizes[op.rank]
         # w_(2m) lives in A[m & 1] (sharded on A), w_(2m+1) in B[m & 1] (sharded on B)
         A = [w_loc.contiguous().clone(), torch.empty_like(w_loc)]
         B = [torch.empty(shape_b, dtype=w_loc.dtype, device=dev) for _ in range(2)]
-        done = False
-        slots[0] = inf                        # the first gate is open
-        while it < max_iter and not done:
-            n = min(check_every, max_iter - it)
-            for j in range(n):
-                k = it + j
-                if k & 1 == 0:
-                    src, dst, old = A[(k >> 1) & 1], B[(k >> 1) & 1], (B[((k >> 1) - 1) & 1] if k >= 2 else None)
+
+        def mirror_phase(thr):
+            """mirror iterations from `it` until the screen is at or below thr (or max_iter); returns diverged"""
+            nonlocal it, host_syncs
+            done = bad = False
+            slots[0] = inf                        # the first gate is open
+            while it < max_iter and not done:
+                n = min(check_every, max_iter - it)
+                for j in range(n):
+                    k = it + j
+                    if k & 1 == 0:
+                        src, dst, old = A[(k >> 1) & 1], B[(k >> 1) & 1], (B[((k >> 1) - 1) & 1] if k >= 2 else None)
+                    else:
+                        src, dst, old = B[(k >> 1) & 1], A[((k + 1) >> 1) & 1], A[(k >> 1) & 1]
+                    gate = slots[j:j + 1]            # the previous iteration's screen (slot 0: the chunk before, or open)
+                    res = slots[j + 1:j + 2]
+                    if old is None:
+                        res.fill_(inf)               # iteration 0 has nothing to compare with: its slot stays open
+                        op.apply_mirror(src, k & 1, out=dst, gate=gate, gate_tol=thr)
+                    else:
+                        op.apply_mirror(src, k & 1, old=old, out=dst, res=res, gate=gate, gate_tol=thr)
+                vals = slots[1:n + 1].tolist()       # the one host read of the chunk
+                host_syncs += 1
+                first = 0 if it > 0 else 1           # iteration 0's slot is the open sentinel
+                j = _first_at_most(vals[first:], thr)
+                if j is not None:
+                    j += first
+                    if errors is not None:
+                        errors.extend(-v for v in vals[:j + 1])
+                    it += j + 1
+                    done = True
+                    bad = not np.isfinite(vals[j])
                 else:
-                    src, dst, old = B[(k >> 1) & 1], A[((k + 1) >> 1) & 1], A[(k >> 1) & 1]
-                gate = slots[j:j + 1]            # the previous iteration's screen (slot 0: the chunk before, or open)
-                res = slots[j + 1:j + 2]
-                if old is None:
-                    res.fill_(inf)               # iteration 0 has nothing to compare with: its slot stays open
-                    op.apply_mirror(src, k & 1, out=dst, gate=gate, gate_tol=thr)
-                else:
-                    op.apply_mirror(src, k & 1, old=old, out=dst, res=res, gate=gate, gate_tol=thr)
-            vals = slots[1:n + 1].tolist()       # the one host read of the chunk
+                    if errors is not None:
+                        errors.extend(-v for v in vals)
+                    it += n
+                    slots[0:1].copy_(slots[n:n + 1])                  # gate of the next chunk's first iteration
+            return bad
+
+        # opts.t_f32: the first part of the phase with fp32 intermediates between the stages
+        thr = SCREEN * tol
+        if t_f32 and hasattr(op.backend, "set_t_f32") and hasattr(op.backend_m, "set_t_f32"):
+            from .single_index import _theta
+            mm = torch.stack([w_loc.max(), -w_loc.min()]).to(torch.float64)
+            op.allreduce_max(mm)
+            hi, lo = float(mm[0].item()), -float(mm[1].item())
             host_syncs += 1
-            first = 0 if it > 0 else 1           # iteration 0's slot is the open sentinel
-            j = _first_at_most(vals[first:], thr)
-            if j is not None:
-                j += first
-                if errors is not None:
-                    errors.extend(-v for v in vals[:j + 1])
-                it += j + 1
-                done = True
-                diverged = not np.isfinite(vals[j])
-            else:
-                if errors is not None:
-                    errors.extend(-v for v in vals)
-                it += n
-                slots[0:1].copy_(slots[n:n + 1])                  # gate of the next chunk's first iteration
+            if lo > 0.0 and np.isfinite(hi):
+                w_ref = float(np.sqrt(hi * lo))
+                thr_a = SCREEN * 64.0 * 2.0 ** -24 * w_ref / max(abs(_theta(op.model, op.params)[1]), 1.0)
+                if thr_a > thr and op.backend.set_t_f32(True, w_ref):
+                    if op.backend_m.set_t_f32(True, w_ref):
+                        try:
+                            diverged = mirror_phase(thr_a)
+                        finally:
+                            op.backend.set_t_f32(False); op.backend_m.set_t_f32(False)
+                        if stats is not None:
+                            stats["t32_iters"] = it
+                    else:
+                        op.backend.set_t_f32(False)
+        if not diverged:
+            diverged = mirror_phase(thr)
         if stats is not None:
             stats["mirror_iters"] = it
         # w_it, back in the A-sharded layout and in a buffer this call owns (never the operator's re-shard buffer, which
@@ -1013,6 +1068,32 @@ def bench_sharded(S, model, shapes, params, arrays, args, rank, local_rank, worl
     dom = max(counters, key=lambda c: c["total_ms"])
     avg_ms = dom["total_ms"] / max(dom["launches"], 1)
     achieved = dom["alg_bytes"] / (avg_ms * 1e-3) / 1e9
+    # the same step with fp32 intermediates between the stages (successive_approx_sharded(t_f32=True): half the bytes per
+    # exchange while the iteration is far from its tolerance); reported beside the fp64 step, never as `value`
+    t32 = None
+    if mirror and all(hasattr(b, "set_t_f32") for b in backends):
+        ref = torch.tensor([float(w.max()), -float(w.min())], dtype=torch.float64, device="cuda")
+        op.allreduce_max(ref)
+        hi, lo = float(ref[0].item()), -float(ref[1].item())
+        if lo > 0.0 and all(b.set_t_f32(True, float(np.sqrt(hi * lo))) for b in backends):
+            try:
+                for _ in range(max(args.warmup, 2)):
+                    w = step(w)
+                dist.barrier()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(args.steps):
+                    w = step(w)
+                torch.cuda.synchronize()
+                dist.barrier()
+                d32 = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
+                dist.all_reduce(d32, op=dist.ReduceOp.MAX)
+                t32 = {"ms_per_step": float(d32.item()) / args.steps * 1e3,
+                       "bytes_per_peer_link_per_exchange": 4.0 * N / world / world,
+                       "note": "opt-in (t_f32): fp32 intermediates between the stages, fp64 iterate and residual"}
+            finally:
+                for b in backends:
+                    b.set_t_f32(False)
     return {
         "metric": "fixed-point iterations/sec",
         "value": args.steps / dt,
@@ -1039,6 +1120,7 @@ def bench_sharded(S, model, shapes, params, arrays, args, rank, local_rank, worl
         "exchange": {"per_iteration": n_exch / max(args.steps, 1),
                      "bytes_sent_per_rank_per_exchange": 8.0 * N / world * (world - 1) / world,
                      "bytes_per_peer_link_per_exchange": 8.0 * N / world / world},
+        "t_f32_step": t32,
         "last_residual": float(res.item()) if state["have_res"] else None,
         "residual_kind": "two-step max|w_(k+1) - w_(k-1)| (mirror schedule)" if mirror else "one-step max|w_(k+1) - w_k|",
     }

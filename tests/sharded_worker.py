@@ -274,6 +274,7 @@ def body_big(rank, model, shapes):
     xs, ns, _ = one.solve(np.full(shapes, 800.0), "newton", tol=1e-10, inner_rtol=1e-6, inner_atol=0.0, max_iter=30)
     near = xs + 3e-5 * (np.random.default_rng(5).random(shapes) - 0.5)            # ~25 SA iterations from tol 1e-6
     xa, na, _ = one.solve(near, "successive_approx", tol=1e-6, max_iter=500)
+    x24, _, _ = one.solve(np.full(shapes, 800.0), "successive_approx", tol=0.0, max_iter=24)
     one.close()
     scat = lambda a: op.scatter_from_full(torch.from_numpy(np.ascontiguousarray(a))).cuda()   # noqa: E731
     full = lambda x_loc: op.gather_full(x_loc).cpu().numpy()                      # noqa: E731
@@ -286,6 +287,12 @@ def body_big(rank, model, shapes):
     out["sa_exact"] = (n, na, float(np.max(np.abs(full(x_loc) - xa))))
     if dist.get_world_size() > 2:
         return out
+    # opts.t_f32 on the sharded grid: fp32 intermediates between the stages (half the bytes per exchange) while the step is
+    # far above their resolution -- 24 iterations from the reference's start, against the single-GPU fp64 iterate
+    st = {}
+    x_loc, n = D.successive_approx_sharded(op, scat(np.full(shapes, 800.0)), tol=1e-8, max_iter=24, check_every=8, stats=st, t_f32=True)
+    out["sa_t32"] = (n, st.get("t32_iters", -1), float(np.max(np.abs(full(x_loc) - x24))))
+    del x24
     # Newton-Krylov from the reference's start, device-gated BiCGSTAB chunks (loose inner solves: ~100 J.v applications)
     nst = {}
     x_loc, n = D.newton_sharded(op, scat(np.full(shapes, 800.0)), tol=1e-8, max_iter=30, inner_rtol=1e-2, inner_atol=0.0, stats=nst)
