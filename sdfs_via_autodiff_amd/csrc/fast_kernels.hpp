@@ -441,6 +441,12 @@ struct LineIO {
   unsigned* sched;          // persistent form: {next tile ticket, finished workgroups}, both zero between launches
   const double* dot_with;   // streamed last pass of J.v (stream_kernels.hpp): also <out, dot_with> into dotp[2][gridDim.x]
                             // (BiCGSTAB's <rhat, q>, krylov_kernels.hpp)
+  // streamed last pass of T, Anderson on large grids (round 4): the push of the pass rides on it -- r = T x - x into
+  // and_r, y = x + beta r into and_y, the workgroup's part of <r, r> into and_dot[blockIdx.x] (k_and_push_lite's outputs)
+  double* and_y;
+  double* and_r;
+  double and_beta;
+  double* and_dot;
 };
 
 template <int N> struct LineGeo {

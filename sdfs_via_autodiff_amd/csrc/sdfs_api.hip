@@ -109,6 +109,7 @@ struct FastPlan {
 struct Knobs {
   int tile_budget = 0, filler_chunk = -1, force_waves = 0, no_occ_blocks = 0, no_pad = 0, no_vec2 = 0, no_vec4 = 0;
   int no_dot_fusion = 0, no_slice_merge = 0, cont_no_tensor = 0, cont_lds_cap = 4000;
+  int no_and_push_fusion = 0;  // SDFS_NO_AND_PUSH_FUSION: 1 = Anderson on large grids keeps the push as a kernel of its own
   int no_f32_stream = 0;       // SDFS_NO_F32_STREAM: 1 = the fp32-MFMA middle pass keeps one tile per workgroup
   int line_persist = 0;        // SDFS_LINE_PERSIST bit 0: middle line passes persistent, bit 1: last line pass persistent
                                // (round 2's look-ahead form; measured equal to one tile per workgroup at GCY 20^6: off by default)
@@ -219,6 +220,9 @@ struct sdfs_handle {
 
   // graph cache for the SA chunk
   const double* jvp_dot_with = nullptr;                // set around a J.v call: the last pass also sums <out, this> (small-grid plan)
+  // set around an application of T by the large-grid Anderson loop: the streamed last pass also does the pass's push
+  // (LineIO::and_*); `tiles` comes back as the number of partial sums it wrote (0: the pass was not a streamed one)
+  struct { double* y = nullptr; double* r = nullptr; double beta = 0.0; double* dot = nullptr; long long tiles = 0; } andpush;
   // set around the J.v calls of a fused BiCGSTAB iteration on the compile-time pair plan (krylov_kernels.hpp): the first
   // pass forms p or s on its registers (kind JF_P / JF_S, -1: plain first pass), the last pass is the streamed form with
   // one workgroup per tile and, where dot_with is set, a third sum
@@ -296,6 +300,7 @@ Knobs read_knobs() {
 #endif
   k.no_slice_merge = env_int("SDFS_NO_SLICE_MERGE", 0);
   k.no_f32_stream = env_int("SDFS_NO_F32_STREAM", 0);
+  k.no_and_push_fusion = env_int("SDFS_NO_AND_PUSH_FUSION", 0);
   k.line_stream = env_int("SDFS_LINE_STREAM", 3);
   k.small_plan = env_int("SDFS_SMALL_PLAN", 1);
   k.small_r = env_int("SDFS_SMALL_R", 0);
@@ -1378,6 +1383,11 @@ int run_fast_plan(sdfs_handle* h, FastPlan& fp, long long nloc, bool has_first, 
         // stream_kernels.hpp: persistent middle pass with the next tile in flight; last pass with its side stream loaded early
         fn = line_stream_variant(P.n, lm, d.f1 != nullptr);
         grid = lm == L_MID ? stream_mid_grid(h, P) : (unsigned)d.ntiles;
+        if (lm == L_TLAST && h->andpush.r != nullptr && old != nullptr && d.ntiles <= (long long)MAX_PARTIAL_BLOCKS * AND_MAX_M) {
+          io.and_y = h->andpush.y; io.and_r = h->andpush.r; io.and_beta = h->andpush.beta; io.and_dot = h->andpush.dot;
+          h->andpush.tiles = d.ntiles;
+          bytes += 3 * n8;                                   // x read, y and r written
+        }
       }
       if (lm == L_JLAST && !lf32 && !vjp && h->jf.active) {
         // fused BiCGSTAB iteration: the streamed last pass, one workgroup per tile (the partial sums are counted per tile)
@@ -2359,15 +2369,23 @@ int solve_anderson(sdfs_handle* h, const sdfs_opts& o, double* w, int64_t* n_ite
       // a mixing step writes over T x, which the push has consumed
       double* const xi = (i & 1) ? fx : x;
       double* const xo = (i & 1) ? x : fx;
+      // the push rides on T's last pass where that is the streamed form (stream_kernels.hpp, LineIO::and_*): x is read
+      // once, T x is not read back -- 9 grid streams per pass instead of 10, on a pass that is bound by its power, not its bytes
+      h->andpush.y = hp.X[pos]; h->andpush.r = hp.R[pos]; h->andpush.beta = o.beta; h->andpush.dot = h->partial; h->andpush.tiles = 0;
+      if (h->knobs.no_and_push_fusion) h->andpush.r = nullptr;
       int r2 = apply_T_dev(h, xi, xo, nullptr, &S->gate, 0.0);
+      const long long ptiles = h->andpush.tiles;
+      h->andpush.r = nullptr; h->andpush.y = nullptr; h->andpush.tiles = 0;
       if (r2) return r2;
       ProfScope ps(h, cvec);
-      hipLaunchKernelGGL(k_and_push_lite, dim3(g), dim3(VEC_BLOCK), 0, st, (const double*)xi, (const double*)xo, hp.X[pos], hp.R[pos], o.beta, n, h->partial,
-                         (const unsigned long long*)&S->gate);
+      if (ptiles == 0)
+        hipLaunchKernelGGL(k_and_push_lite, dim3(g), dim3(VEC_BLOCK), 0, st, (const double*)xi, (const double*)xo, hp.X[pos], hp.R[pos], o.beta, n, h->partial,
+                           (const unsigned long long*)&S->gate);
+      const int gpush = ptiles ? (int)ptiles : g;
       const int refresh = ((i + 1) % (int)o.mixing_freq) == 0 ? 1 : 0;
       if (refresh)
         hipLaunchKernelGGL(k_and_gram_full, dim3(gb), dim3(VEC_BLOCK), 0, st, hp, m, (int)o.mixing_freq, n, h->and_gram_partial, (const AndState*)S);
-      hipLaunchKernelGGL(k_and_step_lazy, dim3(1), dim3(VEC_BLOCK), 0, st, (const double*)h->partial, g, (const double*)h->and_gram_partial, gb, refresh,
+      hipLaunchKernelGGL(k_and_step_lazy, dim3(1), dim3(gpush > 4096 ? 1024 : VEC_BLOCK), 0, st, (const double*)h->partial, gpush, (const double*)h->and_gram_partial, gb, refresh,
                          m, pos, i, S, h->and_err + i, h->and_kind + i, o.tol, (double)o.max_iter, (int)o.mixing_freq, o.ridge);
       hipLaunchKernelGGL(k_and_mix_y, dim3(g), dim3(VEC_BLOCK), 0, st, hp, (const AndState*)S, m, o.beta, xo, (const double*)xo, pos, i, n);
     }

@@ -269,7 +269,8 @@ line_stream_kernel(const LineDesc P, const LineIO io) {
   const int c2 = tid & 7;
   const unsigned b0 = ((unsigned)(tid >> 3) * (unsigned)P.lrest + 2u * c2) * 8u;
   const unsigned bstep = (unsigned)(B / 8) * (unsigned)P.lrest * 8u;
-  const bool need_old = CES ? (io.resid != nullptr) : (MULE && P.minus_identity);
+  const bool andp = CES && !LINE && io.and_r != nullptr;     // uniform: Anderson's push rides on this pass
+  const bool need_old = CES ? (io.resid != nullptr || andp) : (MULE && P.minus_identity);
   const char* const a3b = reinterpret_cast<const char*>(P.a3);
   const unsigned a3x = (unsigned)P.a3x, a3y = (unsigned)P.a3y;
   const TicketWalk W(P.ntiles, blockIdx.x, io.sched);
@@ -443,6 +444,13 @@ line_stream_kernel(const LineDesc P, const LineIO io) {
                 rnan |= (r0 != r0) | (r1 != r1);
                 rmax = fmax(rmax, fmax(r0, r1));
               }
+              if (andp) {                                          // k_and_push_lite on the registers of this unit
+                const double2 rr2 = make_double2(y2.x - s1.x, y2.y - s1.y);
+                *reinterpret_cast<double2*>(reinterpret_cast<char*>(io.and_r + tbase) + off) = rr2;
+                *reinterpret_cast<double2*>(reinterpret_cast<char*>(io.and_y + tbase) + off) =
+                    make_double2(fma(io.and_beta, rr2.x, s1.x), fma(io.and_beta, rr2.y, s1.y));
+                dot_yy = fma(rr2.x, rr2.x, dot_yy); dot_yy = fma(rr2.y, rr2.y, dot_yy);
+              }
               stg_stream2<NT_LAST>(outb + off, y2);
             }
           } else if (rowok) {
@@ -490,6 +498,19 @@ line_stream_kernel(const LineDesc P, const LineIO io) {
     }
   }
   if (PERSIST && tid == 0) ticket_walk_done(io.sched, gridDim.x);
+  if (CES && !LINE) {
+    if (andp) {                                                    // (uniform; `red` is free until the residual's reduction below)
+#pragma unroll
+      for (int s = 32; s > 0; s >>= 1) dot_yy += __shfl_xor(dot_yy, s);
+      if (lane == 0) red[8 + wave] = dot_yy;
+      __syncthreads();
+      if (tid == 0) {
+        double a = 0.0;
+        for (int w = 0; w < NW; ++w) a += red[8 + w];
+        io.and_dot[blockIdx.x] = a;
+      }
+    }
+  }
   if (MULE && io.dotp != nullptr) {
     __shared__ double red3[8];
 #pragma unroll

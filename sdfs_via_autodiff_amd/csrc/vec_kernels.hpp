@@ -669,7 +669,7 @@ k_and_gram_full(AndPtrs h, int m, int mixing_freq, long long n, double* __restri
 }
 
 // the control step of that loop: <r, r> of the pass, the fresh matrix where a solve is due, then and_step_wave in place
-__global__ void __launch_bounds__(VEC_BLOCK)
+__global__ void __launch_bounds__(1024)          // (256 threads, or 1024 where <r, r> arrives as one partial sum per line tile)
 k_and_step_lazy(const double* __restrict__ partial_rr, int nb, const double* __restrict__ gram_partial, int gb, int refresh,
                 int m, int pos, int rel, AndState* S, double* __restrict__ err_slot, int* __restrict__ kind_slot,
                 double tol, double max_iter, int mixing_freq, double ridge) {

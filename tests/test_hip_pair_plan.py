@@ -412,3 +412,33 @@ def test_bicgstab_vector_updates_in_the_first_jvp_pass(S, shapes):
     np.testing.assert_allclose(out["fused"][3][:3], out["plain"][3][:3], rtol=3e-5)
     assert np.max(np.abs(out["fused"][0] - out["plain"][0])) < 1e-8
     Tf.close(); Tp.close()
+
+
+@pytest.mark.parametrize("shapes", [(16,) * 6, (20, 20, 16, 16, 20, 20)])
+def test_anderson_push_on_the_last_pass_of_T(S, shapes):
+    """Large grids, Anderson (code/solvers.py:98-124): the pass's push -- r = T x - x, y = x + beta r, <r, r> -- rides on
+    the streamed last pass of T (stream_kernels.hpp, LineIO::and_*) instead of a kernel that reads x and T x again.  Held
+    to the loop with the separate push (SDFS_NO_AND_PUSH_FUSION=1) pass by pass on a well-conditioned system (a ridge
+    that dwarfs the Gram matrix: rounding is not amplified) -- every kind of pass, chunk boundaries -- and to the same
+    fixed point with the opt-in relative ridge."""
+    m = S.GCY()
+    arr = S.discretize_gcy(m, shapes)
+    Tf = S.KoopmansOperator("gcy", shapes, m.params, arr)
+    os.environ["SDFS_NO_AND_PUSH_FUSION"] = "1"
+    try:
+        Tu = S.KoopmansOperator("gcy", shapes, m.params, arr)
+    finally:
+        del os.environ["SDFS_NO_AND_PUSH_FUSION"]
+    w0 = np.full(shapes, 800.0)
+    for k in (3, 9, 18):
+        xf, nf, inf_ = Tf.solve(w0, "anderson", tol=0.0, max_iter=k, ridge=1e9, record_errors=True)
+        xu, nu, inu = Tu.solve(w0, "anderson", tol=0.0, max_iter=k, ridge=1e9, record_errors=True)
+        assert nf == nu == k
+        np.testing.assert_allclose(inf_["errors"], inu["errors"], rtol=1e-10)
+        assert np.max(np.abs(xf - xu)) < 1e-9 * np.max(np.abs(xu))
+    xf, nf, inf_ = Tf.solve(w0, "anderson", tol=1e-8, max_iter=3000, ridge=-1e-6)
+    xu, nu, inu = Tu.solve(w0, "anderson", tol=1e-8, max_iter=3000, ridge=-1e-6)
+    assert inf_["status"] == 0 and inu["status"] == 0
+    assert np.max(np.abs(xf - xu)) < 1e-4                      # both within tol / (1 - modulus) of the fixed point
+    assert nf <= 1.5 * nu + 10 and nu <= 1.5 * nf + 10, (nf, nu)
+    Tf.close(); Tu.close()
