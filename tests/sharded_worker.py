@@ -285,14 +285,14 @@ def body_big(rank, model, shapes):
     out["sa"] = (n, na, float(np.max(np.abs(full(x_loc) - xa))), st.get("mirror_iters", 0), st.get("host_syncs", -1))
     x_loc, n = D.successive_approx_sharded(op, scat(near), tol=1e-6, max_iter=500, check_every=8, mirror=False)
     out["sa_exact"] = (n, na, float(np.max(np.abs(full(x_loc) - xa))))
-    if dist.get_world_size() > 2:
-        return out
     # opts.t_f32 on the sharded grid: fp32 intermediates between the stages (half the bytes per exchange) while the step is
     # far above their resolution -- 24 iterations from the reference's start, against the single-GPU fp64 iterate
     st = {}
     x_loc, n = D.successive_approx_sharded(op, scat(np.full(shapes, 800.0)), tol=1e-8, max_iter=24, check_every=8, stats=st, t_f32=True)
     out["sa_t32"] = (n, st.get("t32_iters", -1), float(np.max(np.abs(full(x_loc) - x24))))
     del x24
+    if dist.get_world_size() > 2:
+        return out
     # Newton-Krylov from the reference's start, device-gated BiCGSTAB chunks (loose inner solves: ~100 J.v applications)
     nst = {}
     x_loc, n = D.newton_sharded(op, scat(np.full(shapes, 800.0)), tol=1e-8, max_iter=30, inner_rtol=1e-2, inner_atol=0.0, stats=nst)

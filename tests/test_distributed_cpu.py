@@ -170,12 +170,12 @@ def test_sharded_stages_on_the_pair_plan_kernels(world):
     assert abs(n - na) <= 1 and err < 1e-6 and mirror_iters > 0.5 * n and syncs <= n / 8 + 4, out["sa"]   # (the mirror phase stops on a two-step difference)
     n, na, err = out["sa_exact"]
     assert n == na and err < 1e-9, out["sa_exact"]
-    if world > 2:
-        return
     # fp32 intermediates between the stages (sdfs_set_t_f32): all 24 iterations ran in that form; one stored float carries
     # 2^-24 relative, ~ w 2^-24 / |theta| = 1.3e-6 on T w per application
     n, n32, d = out["sa_t32"]
     assert n == 24 and n32 == 24 and 0.0 < d < 1e-4, out["sa_t32"]
+    if world > 2:
+        return
     n, err, syncs, its = out["newton"]
     assert n < 20 and err < 1e-7, out["newton"]
     assert 0 < syncs <= its / 8 + 2 * n + 2, out["newton"]
