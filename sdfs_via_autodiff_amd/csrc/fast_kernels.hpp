@@ -239,7 +239,7 @@ slice_kernel(const SliceDesc P, const SliceIO io) {
   constexpr bool MULP = MODE == S_JFIRST;
   constexpr bool JV32 = F32 && MULP;
   static_assert(!T32 || !F32, "S_TFIRST32 is its own storage form");
-  constexpr bool POWREG = MODE == S_TFIRST;                       // the power on the registers, before the tile is parked
+  constexpr bool POWREG = MODE == S_TFIRST || T32;                // the power on the registers, before the tile is parked
   static_assert(!F32 || (MODE != S_TFIRST && MODE != S_MID), "plain T has no fp32 form");
   extern __shared__ double lds[];
   if (io.gate != nullptr) {
@@ -308,6 +308,8 @@ slice_kernel(const SliceDesc P, const SliceIO io) {
     // GCY 20^6, tools/probes/kernel_bench.hip).  The linearising and fp32-intermediate forms keep the rolled loop below.
     PowK<true> PTr;
     if (POWREG) PTr.init(P.theta, lane);
+    double t32s = 1.0;                                             // fp32-intermediate form: x * 2^k (t32_scale_of)
+    if (T32) { const PowLane PL0 = pow_lane_init(lane); t32s = t32_scale_of(P.t32_ref > 0.0 ? P.t32_ref : io.in[P.ref_off], P.theta, PL0, false); }
 #pragma unroll
     for (int k = 0; k < Geo::EPT; ++k) {
       const int u = lane + 64 * k;
@@ -316,7 +318,7 @@ slice_kernel(const SliceDesc P, const SliceIO io) {
         const double xin[2] = {v[k].x, v[k].y};       // (masked lanes were loaded as 1)
         double xw[2];
         PTr.template run<2>(xin, xw);
-        v[k] = make_double2(xw[0], xw[1]);
+        v[k] = T32 ? make_double2(xw[0] * t32s, xw[1] * t32s) : make_double2(xw[0], xw[1]);
       }
       if (Geo::UNITS % 64 == 0 || u < Geo::UNITS) *reinterpret_cast<double2*>(wl + lofs(2 * u)) = v[k];
     }
