@@ -536,6 +536,35 @@ def main():
         sec["gcy15_padded_pair_plan"] = {"ms_per_step": t15 * 1e3, "iterations_per_s": 1.0 / t15, "points": 15 ** 6,
                                          "alg_GBps": 56.0 * 15 ** 6 / t15 / 1e9, "plan": T15.describe_plan().strip().split("\n")[:3]}
         T15.close(); del a15
+        # BASELINE config 4's second grid, GCY 16^6, device-resident from w = 800: the step, and time-to-converge (1e-8) of
+        # successive approximation, Newton-Krylov (fp64; fp32-MFMA J.v at inner 1e-4: config 5) and Anderson (reference's
+        # ridge; the opt-in relative one)
+        g16 = S.GCY(); shp16 = (16,) * 6
+        T16 = S.gcy_operator(shp16, g16.params, S.discretize_gcy(g16, shp16))
+        a16 = torch.empty(shp16, dtype=torch.float64, device=dev)
+        sec16 = {}
+        for key, algo, kw in (("step_sa_device_loop", "successive_approx", dict(tol=0.0, max_iter=200, check_every=100)),
+                              ("successive_approx_1e-8", "successive_approx", dict(tol=1e-8)),
+                              ("newton_1e-8", "newton", dict(tol=1e-8, inner_rtol=1e-6, inner_atol=0.0)),
+                              ("newton_1e-8_f32_mfma_inner_1e-4", "newton", dict(tol=1e-8, inner_rtol=1e-4, inner_atol=0.0, krylov_f32=3)),
+                              ("anderson_1e-8", "anderson", dict(tol=1e-8, max_iter=5000)),
+                              ("anderson_1e-8_relative_ridge_1e-6", "anderson", dict(tol=1e-8, max_iter=5000, ridge=-1e-6))):
+            best = None
+            for rep in range(2):                      # (the first run of a loop form captures its graph / sizes its buffers)
+                a16.fill_(800.0)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                n16, info16 = T16.solve_dev(a16.data_ptr(), algo, **kw)
+                torch.cuda.synchronize()
+                t = time.perf_counter() - t0
+                if best is None or t < best[0]:
+                    best = (t, n16, info16)
+            t, n16, info16 = best
+            sec16[key] = {"iterations": n16, "operator_applies": info16["n_apply"], "seconds": t, "status": info16["status"]}
+            if key == "step_sa_device_loop":
+                sec16[key] = {"ms_per_step": t / n16 * 1e3, "iterations_per_s": n16 / t, "alg_GBps": 56.0 * 16 ** 6 / (t / n16) / 1e9}
+        sec["gcy16"] = sec16
+        T16.close(); del a16
         if not args.no_cpu:
             sec["cpu_literal_formulation"] = cpu_literal_apply()
         # continuous-state SSY at the reference's default size (10, 10, 10, 20; Gauss-Hermite d = 5)
