@@ -423,6 +423,8 @@ struct LineDesc {
   int minus_identity;
   long long ref_off;        // C-order offset of the mid-grid point (fp32 linearisation scale)
   double t32_ref;           // > 0: reference value of the t_f32 scale (sharded stages: the mid-grid point may live on another rank)
+  int cached_out;           // the grid is small enough for the next application's first pass to find T w in the Infinity Cache:
+                            // the last pass then stores it with the default policy, not non-temporally
   // a3 as two small tables where it factorises (build_fast_plan): a3 = f1[o * n + x] * f2[o * lrest + position]; else null.
   // Read by the streamed last pass (stream_kernels.hpp, A3F).  The same form as a run-time branch in line_kernel's own
   // epilogue lost at GCY 16^6 (last pass 0.0905 against 0.0863 ms): that kernel stays with the gathers.

@@ -805,6 +805,7 @@ int make_line_pass(sdfs_handle* h, const int* shp, const int* off, int a, bool t
   L.cbt = (double)powl((long double)h->beta, (long double)h->theta);
   L.a3x = h->ax[a].a3s; L.a3y = h->ax[a + 1].a3s;
   for (int c = D - 1; c >= 0; --c) L.ref_off += (long long)(shp[c] / 2) * stride[c];
+  L.cached_out = 8.0 * (double)nloc <= 192.0 * 1024 * 1024 ? 1 : 0;       // (the Infinity Cache holds 256 MB)
   P.q_bytes = 2 * 8.0 * n * n; P.flops = 2.0 * (double)nloc * 2 * n;
   P.label = std::string("lines[") + h->ax[a].name + "," + h->ax[a + 1].name + "|" + std::to_string(n) + "x" +
             std::to_string(n) + "x16 tile]";
